@@ -1,0 +1,169 @@
+// ch_api.cpp -- the C ABI of libctrlhair_hip.so (see include/ctrlhair_hip.h for the contract).
+#include "../../include/ctrlhair_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "sean_model.h"
+
+struct ch_handle {
+    int device = 0;
+    std::string err;
+    chk::TensorStore tensors[1];
+    chk::SeanModel sean;
+    bool sean_ready = false;
+};
+
+namespace {
+int fail(ch_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+}  // namespace
+
+extern "C" {
+
+int ch_abi_version(void) { return CH_ABI_VERSION; }
+
+int ch_create(int device, ch_handle** out) {
+    if (!out) return CH_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CH_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return CH_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CH_ERR_HIP;
+    ch_handle* h = new (std::nothrow) ch_handle();
+    if (!h) return CH_ERR_HIP;
+    h->device = device;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // kernels are built for gfx950 only; refuse instead of failing at the first launch
+        h->err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only";
+        *out = h;
+        return CH_ERR_HIP;
+    }
+    *out = h;
+    return CH_OK;
+}
+
+void ch_destroy(ch_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    h->sean.destroy();
+    delete h;
+}
+
+const char* ch_last_error(const ch_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ch_load_tensor(ch_handle* h, int model, const char* name, const void* host, int dtype, const int64_t* shape,
+                   int ndim) {
+    if (!h || !name || !host || ndim < 0 || ndim > 8 || (ndim > 0 && !shape)) return fail(h, CH_ERR_ARG, "bad argument");
+    if (model != CH_MODEL_SEAN) return fail(h, CH_ERR_ARG, "unknown model id");
+    if (dtype != CH_F32 && dtype != CH_I64) return fail(h, CH_ERR_ARG, "unsupported dtype");
+    try {
+        chk::HostTensor t;
+        t.dtype = dtype;
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) {
+            if (shape[i] < 0) return fail(h, CH_ERR_ARG, "negative dimension");
+            t.shape.push_back(shape[i]);
+            n *= (size_t)shape[i];
+        }
+        const size_t bytes = n * (dtype == CH_F32 ? 4 : 8);
+        t.data.assign(static_cast<const char*>(host), static_cast<const char*>(host) + bytes);
+        h->tensors[model][name] = std::move(t);
+    } catch (const std::exception& e) {
+        return fail(h, CH_ERR_WEIGHTS, std::string("ch_load_tensor: ") + e.what());
+    }
+    return CH_OK;
+}
+
+int ch_finalize(ch_handle* h, int model, int max_batch, int max_size) {
+    if (!h) return CH_ERR_ARG;
+    if (model != CH_MODEL_SEAN) return fail(h, CH_ERR_ARG, "unknown model id");
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, CH_ERR_HIP, "hipSetDevice failed");
+    try {
+        h->sean.destroy();
+        h->sean_ready = false;
+        std::string e = h->sean.build(h->tensors[model], max_batch, max_size);
+        if (!e.empty()) {
+            h->sean.destroy();
+            return fail(h, CH_ERR_WEIGHTS, "ch_finalize: " + e);
+        }
+        h->tensors[model].clear();   // host copies no longer needed
+        h->sean_ready = true;
+    } catch (const std::exception& e) {
+        return fail(h, CH_ERR_WEIGHTS, std::string("ch_finalize: ") + e.what());
+    }
+    return CH_OK;
+}
+
+size_t ch_sean_noise_floats(const ch_handle* h, int S) {
+    if (!h || !h->sean_ready || S <= 0) return 0;
+    return h->sean.noise_floats(S);
+}
+
+int ch_sean_generate(ch_handle* h, const uint8_t* labels, const float* codes, const float* noise, uint64_t seed,
+                     float* out, int B, int S, ch_stream_t stream) {
+    if (!h) return CH_ERR_ARG;
+    if (!h->sean_ready) return fail(h, CH_ERR_STATE, "ch_sean_generate: SEAN weights not finalized");
+    if (!labels || !codes || !out) return fail(h, CH_ERR_ARG, "ch_sean_generate: null pointer");
+    try {
+        std::string e = h->sean.generate(labels, codes, noise, seed, out, B, S, static_cast<hipStream_t>(stream));
+        if (!e.empty()) return fail(h, CH_ERR_HIP, "ch_sean_generate: " + e);
+    } catch (const std::exception& e) {
+        return fail(h, CH_ERR_HIP, std::string("ch_sean_generate: ") + e.what());
+    }
+    return CH_OK;
+}
+
+int ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr) {
+    if (!h || !name) return CH_ERR_ARG;
+    if (dev_ptr) h->sean.taps[name] = dev_ptr;
+    else h->sean.taps.erase(name);
+    return CH_OK;
+}
+
+int ch_profile_enable(ch_handle* h, int on) {
+    if (!h) return CH_ERR_ARG;
+    h->sean.prof_on = on != 0;
+    return CH_OK;
+}
+
+int ch_profile_read(ch_handle* h, int kind, int* launches, double* total_ms, double* flops, double* bytes) {
+    if (!h) return CH_ERR_ARG;
+    int n = 0;
+    double ms = 0, fl = 0, by = 0;
+    for (auto& r : h->sean.prof) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) return fail(h, CH_ERR_HIP, "hipEventSynchronize failed");
+        if (kind < 0 || r.kind == kind) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return fail(h, CH_ERR_HIP, "hipEventElapsedTime failed");
+            ms += t;
+            fl += r.flops;
+            by += r.bytes;
+            ++n;
+        }
+    }
+    if (kind < 0 || true) {
+        // records are consumed only by a read with kind < 0 (read specific kinds first)
+        if (kind < 0) {
+            for (auto& r : h->sean.prof) {
+                h->sean.ev_pool.push_back(r.e0);
+                h->sean.ev_pool.push_back(r.e1);
+            }
+            h->sean.prof.clear();
+        }
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return CH_OK;
+}
+
+}  // extern "C"

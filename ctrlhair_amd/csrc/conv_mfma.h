@@ -1,0 +1,344 @@
+// conv_mfma.h -- implicit-GEMM convolution for gfx950 on the exact-f32 matrix cores
+// (v_mfma_f32_32x32x2_f32), stride 1, "same" zero padding, KS in {1,3}.
+//
+//   GEMM view:  D[row][pixel] = sum_{ci,tap} A[row][(ci,tap)] * X[ci][pixel + tap]
+//     A : weights, pre-packed on the host into per-lane MFMA A-fragments (pack_conv_weights, sean_model.cpp),
+//         streamed straight from L2 into VGPRs as 16-byte loads (4 k-steps per load) -- never through LDS.
+//     X : the un-expanded input patch (tile + halo) of CK input channels, staged once per chunk into LDS and
+//         shared by the 4 waves; the im2col is only a per-tap LDS address offset (ds_read_b32, lanes along x
+//         -> conflict-free banks).
+//   Block = 256 threads = 4 wave64.  Each wave owns 64 GEMM rows (2 M-subtiles) x 128 pixels (4 N-subtiles):
+//   8 independent 32x32 accumulators (128 AGPR/VGPR), 6 operand VGPRs per k-step -> the 64-cycle f32 MFMA is
+//   the only busy pipe; 2 blocks/CU hide the staging barrier.
+//
+// Epilogues (fused, so modulation tensors never reach HBM):
+//   EPI_PLAIN : + bias[row] (+ residual, optionally nearest-x2 addressed) (+ activation)   -> NCHW
+//   EPI_ACE   : rows are (gamma | beta) pairs of the SPADE conv (normalization.py:249-257); adds the style LUT
+//               gather (exact form of conv_gamma/conv_beta on the piecewise-constant style map,
+//               normalization.py:117-153,172-173), the blend (:177-181), eval-BN + noise (:111-112) of x,
+//               out = normalized*(1+gamma)+beta (:182), optional leaky_relu(0.2) (architecture.py:95)  -> NCHW
+//   EPI_NHWC  : operands swapped (D^T), rows contiguous per pixel -> [pixel][row]; used to build the style LUT
+//               (rows = (tap, gamma|beta, channel), pixels = (sample, label)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_PLAIN = 0, EPI_ACE = 1, EPI_NHWC = 2 };
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3 };
+
+struct ConvParams {
+    const float* in;        // [B][Cin][H][W]
+    const float* wpk;       // packed A fragments
+    float* out;
+    int B, Cin, H, W;
+    int Mrows;              // real GEMM rows (Cout; 2*C for EPI_ACE is NOT used: see C)
+    int nchunks;            // ceil(Cin / CK)
+    int mtiles;             // ceil(rows / (64*WM)) (block tiles along M)
+    int tiles_x, tiles_y, tiles_b;
+    // EPI_PLAIN
+    const float* bias;      // [Mrows] or null
+    const float* res;       // [B][Mrows][H>>res_up][W>>res_up] or null
+    int res_up;
+    int act;
+    // EPI_ACE
+    const float* x;         // [B][C][H>>x_up][W>>x_up]
+    int x_up;
+    int C;
+    const float* bias_g;    // [C] blended biases
+    const float* bias_b;
+    const float* bn_a;      // rstd
+    const float* bn_d;      // -mean*rstd
+    const float* nv;        // noise_var*rstd
+    const float* noise;     // plane base for this ACE; sample stride noise_bstride; layout [W][H]
+    long long noise_bstride;
+    const uint8_t* lab;     // [B][H][W]
+    const float* lut;       // [B*19][9][2][C] or null (unstyled)
+    // EPI_NHWC
+    int npix_valid;         // number of valid linear pixels (y*W+x < npix_valid)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// bijective XCD-aware remap: physical block p (XCD p%8) -> logical id so that each XCD owns a contiguous
+// range of logical ids (neighbouring logical ids share the input patch / L2 lines).
+__device__ __forceinline__ int xcd_remap(int p, int n) {
+    const int q = n >> 3, r = n & 7, xcd = p & 7, k = p >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+template <int KS, int WM, int TW, int TH, int TB, int CK, int EPI>
+struct ConvCfg {
+    static constexpr int WN = 4 / WM;
+    static constexpr int HALO = KS / 2;
+    static constexpr int PW = TW + 2 * HALO;
+    static constexpr int PH = TH + 2 * HALO;
+    static constexpr int PLANE = TB * PH * PW;
+    static constexpr int NPIX = TW * TH * TB;
+    static constexpr int KSTEPS = KS * KS * CK / 2;
+    static constexpr int NGROUPS = KSTEPS / 4;
+    static constexpr int STAGE_ELEMS = CK * PLANE;
+    static constexpr int NLOAD = (STAGE_ELEMS + 255) / 256;
+    static constexpr int LDS_BYTES = 2 * STAGE_ELEMS * 4;
+    static_assert(NPIX == 128 * WN, "pixel tile must be 128 px per N-wave");
+    static_assert(KSTEPS % 4 == 0, "k-steps per chunk must be a multiple of 4");
+};
+
+template <int KS, int WM, int TW, int TH, int TB, int CK, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
+    using Cfg = ConvCfg<KS, WM, TW, TH, TB, CK, EPI>;
+    constexpr int WN = Cfg::WN, HALO = Cfg::HALO, PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE;
+    constexpr int NG = Cfg::NGROUPS, NLOAD = Cfg::NLOAD, SE = Cfg::STAGE_ELEMS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L % p.mtiles;
+    int nt = L / p.mtiles;
+    const int txi = nt % p.tiles_x; nt /= p.tiles_x;
+    const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
+    const int x0 = txi * TW, y0 = tyi * TH, b0 = nt * TB;
+    const int mtile64 = mt * WM + wm;
+    const int HW = p.H * p.W;
+
+    // per-lane LDS offsets of the window origin for the 4 N-subtiles
+    int loff[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int idx = wn * 128 + n * 32 + (lane & 31);
+        const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+        loff[n] = (lane >> 5) * PLANE + tb * (PH * PW) + ty * PW + tx;
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // ---- staging: element e of the chunk patch -> (channel, sample-in-tile, row, col).  Done synchronously at
+    // the top of each chunk iteration (registers are transient); the second block on the CU covers the wait.
+    auto stage = [&](int chunk, int buf) {
+        float stg[NLOAD];
+        const float* src = p.in + ((long long)b0 * p.Cin + (long long)chunk * CK) * HW;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            int e = tid + i * 256;
+            asm volatile("" : "+v"(e));     // keep the decode inside the chunk loop (no hoisted address regs)
+            float v = 0.f;
+            if (e < SE) {
+                const int c = e / PLANE, rem = e % PLANE;
+                const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
+                const int y = y0 + py - HALO, x = x0 + px - HALO;
+                if (b0 + tb < p.B && chunk * CK + c < p.Cin && (unsigned)y < (unsigned)p.H &&
+                    (unsigned)x < (unsigned)p.W)
+                    v = src[(tb * p.Cin + c) * HW + y * p.W + x];
+            }
+            stg[i] = v;
+        }
+        float* dst = smem + buf * SE;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int e = tid + i * 256;
+            if (e < SE) dst[e] = stg[i];
+        }
+    };
+
+    const float4* Ap = reinterpret_cast<const float4*>(p.wpk) +
+                       ((long long)mtile64 * p.nchunks) * (NG * 2 * 64) + lane;
+
+    stage(0, 0);
+    __syncthreads();
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        if (ch + 1 < p.nchunks) stage(ch + 1, (ch + 1) & 1);
+        const float* sb = smem + (ch & 1) * SE;
+        const float4* Ac = Ap + (long long)ch * (NG * 2 * 64);
+        float4 a0 = Ac[0], a1 = Ac[64];
+        float bv[4], bn[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bv[n] = sb[loff[n]];          // k-step 0: tap (0,0), channel pair 0
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float4 a0n = a0, a1n = a1;
+            if (g + 1 < NG) {
+                a0n = Ac[(g + 1) * 128];
+                a1n = Ac[(g + 1) * 128 + 64];
+            }
+            const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+            const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                constexpr int HALF = CK / 2;
+                const int s1 = g * 4 + q + 1;                     // prefetch the next k-step's B fragments
+                if (s1 < Cfg::KSTEPS) {
+                    const int t = s1 / HALF, cp = s1 % HALF;
+                    const int koff = 2 * cp * PLANE + (t / KS) * PW + (t % KS);
+                    asm volatile("" ::: "memory");                // no cross-tap CSE of LDS reads (VGPR pressure)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bn[n] = sb[koff + loff[n]];
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (EPI == EPI_NHWC) {
+                        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[n], a0v[q], acc[0][n], 0, 0, 0);
+                        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[n], a1v[q], acc[1][n], 0, 0, 0);
+                    } else {
+                        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[q], bv[n], acc[0][n], 0, 0, 0);
+                        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[q], bv[n], acc[1][n], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bv[n] = bn[n];
+            }
+            a0 = a0n;
+            a1 = a1n;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------
+    const int hi = lane >> 5, col = lane & 31;
+    if (EPI == EPI_PLAIN) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int idx = wn * 128 + n * 32 + col;
+            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+            const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+            if (b >= p.B || y >= p.H || x >= p.W) continue;
+            const long long pix = (long long)y * p.W + x;
+            const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
+            const long long rpix = (long long)(y >> p.res_up) * rW + (x >> p.res_up);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mtile64 * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < p.Mrows) {
+                        float v = acc[m][n][r];
+                        if (p.bias) v += p.bias[row];
+                        if (p.res) v += p.res[((long long)b * p.Mrows + row) * (rW * rH) + rpix];
+                        v = apply_act(v, p.act);
+                        p.out[((long long)b * p.Mrows + row) * HW + pix] = v;
+                    }
+                }
+        }
+    } else if (EPI == EPI_NHWC) {
+        // swapped operands: D[i = pixel in subtile][j = row in M-subtile]; lane col = row, regs = pixels
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int idx = wn * 128 + n * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+                const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+                const long long lin = ((long long)b * p.H + y) * p.W + x;
+                if (b >= p.B || y >= p.H || x >= p.W || lin >= p.npix_valid) continue;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int row = mtile64 * 64 + m * 32 + col;
+                    if (row < p.Mrows) p.out[lin * p.Mrows + row] = acc[m][n][r];
+                }
+            }
+    } else {  // EPI_ACE: wave tile = 32 channels: acc[0] = gamma rows, acc[1] = beta rows
+        const int C = p.C;
+        const int xW = p.W >> p.x_up, xH = p.H >> p.x_up;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int idx = wn * 128 + n * 32 + col;
+            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+            const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+            if (b >= p.B || y >= p.H || x >= p.W) continue;
+            float sg[16], sbt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sg[r] = 0.f; sbt[r] = 0.f; }
+            if (p.lut) {
+                const uint8_t* lb = p.lab + (long long)b * HW;
+#pragma unroll 1
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                        const int j = lb[yy * p.W + xx];
+                        const float* Lp = p.lut + ((long long)(b * 19 + j) * 9 + t) * (2 * C);
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int c4 = mtile64 * 32 + 8 * rq + 4 * hi;
+                            if (c4 < C) {   // C % 4 == 0
+                                const float4 g4 = *reinterpret_cast<const float4*>(Lp + c4);
+                                const float4 b4 = *reinterpret_cast<const float4*>(Lp + C + c4);
+                                sg[rq * 4 + 0] += g4.x; sg[rq * 4 + 1] += g4.y;
+                                sg[rq * 4 + 2] += g4.z; sg[rq * 4 + 3] += g4.w;
+                                sbt[rq * 4 + 0] += b4.x; sbt[rq * 4 + 1] += b4.y;
+                                sbt[rq * 4 + 2] += b4.z; sbt[rq * 4 + 3] += b4.w;
+                            }
+                        }
+                    }
+                }
+            }
+            const float nz = p.noise[(long long)b * p.noise_bstride + (long long)x * p.H + y];
+            const long long xpix = (long long)(y >> p.x_up) * xW + (x >> p.x_up);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = mtile64 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (c < C) {
+                    const float gam = acc[0][n][r] + p.bias_g[c] + sg[r];
+                    const float bet = acc[1][n][r] + p.bias_b[c] + sbt[r];
+                    const float xv = p.x[((long long)b * C + c) * (xW * xH) + xpix];
+                    const float nrm = p.bn_a[c] * xv + p.nv[c] * nz + p.bn_d[c];
+                    float o = nrm * (1.f + gam) + bet;
+                    o = apply_act(o, p.act);
+                    p.out[((long long)b * C + c) * HW + (long long)y * p.W + x] = o;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// host-side launcher for one instantiation
+template <int KS, int WM, int TW, int TH, int TB, int CK, int EPI>
+hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
+    using Cfg = ConvCfg<KS, WM, TW, TH, TB, CK, EPI>;
+    auto kern = conv_mfma_kernel<KS, WM, TW, TH, TB, CK, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.nchunks = (p.Cin + CK - 1) / CK;
+    p.mtiles = (rows + 64 * WM - 1) / (64 * WM);
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.tiles_b = (p.B + TB - 1) / TB;
+    const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+// chunk sizes used by the packer and the launch table
+constexpr int CK_KS3 = 16;
+constexpr int CK_KS1 = 16;
+
+// entry points implemented in conv_inst_*.hip (tile config chosen from W and rows)
+hipError_t conv_plain3(const ConvParams& p, hipStream_t s);          // rows = p.Mrows
+hipError_t conv_plain1(const ConvParams& p, hipStream_t s);          // rows = p.Mrows
+hipError_t conv_ace(const ConvParams& p, hipStream_t s);             // rows = 64-row tiles of 32 ch (gamma|beta)
+hipError_t conv_nhwc1x1(const ConvParams& p, hipStream_t s);         // rows = p.Mrows
+
+}  // namespace chk

@@ -1,0 +1,229 @@
+// sean_kernels.hip -- the small HBM/LDS-bound kernels around the MFMA convs of the SEAN generator path.
+// gfx950 only (wave64).  Every kernel is predicated for arbitrary shapes.
+#include "kernels.h"
+
+namespace chk {
+
+// ---------------------------------------------------------------------------------------------------------
+// F.interpolate(seg, size, mode='nearest') on the label map (generator.py:75, normalization.py:115):
+// src = floor(dst * in/out); in/out is an integer here (S / r).
+__global__ void label_down_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int S, int r) {
+    const long long n = (long long)B * r * r;
+    const int f = S / r;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % r), y = (int)((i / r) % r);
+        const long long b = i / ((long long)r * r);
+        out[i] = in[(b * S + (long long)y * f) * S + (long long)x * f];
+    }
+}
+
+hipError_t label_downsample(const uint8_t* in, uint8_t* out, int B, int S, int r, hipStream_t s) {
+    const long long n = (long long)B * r * r;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(label_down_kernel, dim3(grid), dim3(256), 0, s, in, out, B, S, r);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 conv on a one-hot map == 9-tap table gather (exact):  out[b,k,p] = act(bias[k] + sum_t T[label(p+t)][t][k])
+// Used for SPADE.mlp_shared (normalization.py:239-242,253) and the generator's `fc` conv (generator.py:33,76).
+// Table layout T[(j*9+t)*K + k].  One block = 256 consecutive pixels x KC channels; the table slice for the KC
+// channels sits in LDS.
+constexpr int OH_KC = 32;
+
+__global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __restrict__ lab,
+                                                             const float* __restrict__ table,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int B, int H, int W, int K, int relu) {
+    __shared__ float T[19 * 9 * OH_KC];
+    __shared__ float bs[OH_KC];
+    const int k0 = blockIdx.y * OH_KC;
+    for (int i = threadIdx.x; i < 19 * 9 * OH_KC; i += 256) {
+        const int jt = i / OH_KC, kk = i % OH_KC;
+        T[i] = (k0 + kk < K) ? table[(long long)jt * K + k0 + kk] : 0.f;
+    }
+    if (threadIdx.x < OH_KC) bs[threadIdx.x] = (k0 + threadIdx.x < K) ? bias[k0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const long long pix = blockIdx.x * 256LL + threadIdx.x;
+    if (pix >= B * HW) return;
+    const int b = (int)(pix / HW);
+    const int y = (int)((pix % HW) / W), x = (int)(pix % W);
+    int jt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        jt[t] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    ? (lab[b * HW + (long long)yy * W + xx] * 9 + t) * OH_KC
+                    : -1;
+    }
+    float* o = out + ((long long)b * K + k0) * HW + (pix % HW);
+    const int kmax = (K - k0 < OH_KC) ? (K - k0) : OH_KC;
+    for (int kk = 0; kk < kmax; ++kk) {
+        float v = bs[kk];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (jt[t] >= 0) v += T[jt[t] + kk];
+        if (relu) v = v > 0.f ? v : 0.f;
+        o[(long long)kk * HW] = v;
+    }
+}
+
+hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* bias, float* out, int B, int H, int W,
+                          int K, int relu, hipStream_t s) {
+    const long long npix = (long long)B * H * W;
+    dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
+    hipLaunchKernelGGL(onehot_conv3x3_kernel, grid, dim3(256), 0, s, lab, table, bias, out, B, H, W, K, relu);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-region style projection: mu[b,j,:] = relu(fc_mu_j(code[b,j]))  (normalization.py:134,146 + :191-215).
+// Weight-bandwidth bound (19 x 1 MB per ACE).  One wave per 4 output features; lanes split the 512-long dot
+// product (8 floats each, two float4 loads), wave shuffle reduction, up to FCMU_BT samples per pass.
+// Output is written as the [512][Npad] "image" the LUT GEMM (1x1 conv, NHWC epilogue) consumes: column b*19+j.
+constexpr int FCMU_BT = 8;
+
+__global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ codes, const float* __restrict__ Wt,
+                                                    const float* __restrict__ bias, float* __restrict__ mu_img, int B,
+                                                    int Npad) {
+    const int j = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o0 = (blockIdx.x * 4 + wave) * 4;           // 4 output features per wave
+    const float* Wj = Wt + (long long)j * 512 * 512;
+    float4 w[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4* wr = reinterpret_cast<const float4*>(Wj + (long long)(o0 + i) * 512 + lane * 8);
+        w[i][0] = wr[0];
+        w[i][1] = wr[1];
+    }
+    for (int bb = 0; bb < B; bb += FCMU_BT) {
+        float part[4][FCMU_BT];
+#pragma unroll
+        for (int t = 0; t < FCMU_BT; ++t) {
+            float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;
+            if (bb + t < B) {
+                const float4* cr =
+                    reinterpret_cast<const float4*>(codes + ((long long)(bb + t) * 19 + j) * 512 + lane * 8);
+                c0 = cr[0];
+                c1 = cr[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                part[i][t] = w[i][0].x * c0.x + w[i][0].y * c0.y + w[i][0].z * c0.z + w[i][0].w * c0.w +
+                             w[i][1].x * c1.x + w[i][1].y * c1.y + w[i][1].z * c1.z + w[i][1].w * c1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < FCMU_BT; ++t) {
+                float v = part[i][t];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                part[i][t] = v;
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < FCMU_BT; ++t)
+                    if (bb + t < B) {
+                        const float v = part[i][t] + bias[j * 512 + o0 + i];
+                        mu_img[(long long)(o0 + i) * Npad + (bb + t) * 19 + j] = v > 0.f ? v : 0.f;
+                    }
+        }
+    }
+}
+
+hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_img(leaky_relu(x, 0.2)) then tanh (generator.py:107-108): Cin -> 3, 3x3, zero pad.  Three output rows
+// are far too few for the matrix cores; this is a direct VALU conv, 32x8 pixel tile, input staged through LDS
+// in chunks of 8 channels with the leaky_relu applied on the way in.
+constexpr int CI_TW = 32, CI_TH = 8, CI_CK = 8;
+
+__global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                       int Cin, int H, int W) {
+    __shared__ float patch[CI_CK][CI_TH + 2][CI_TW + 2];
+    __shared__ float ws[3][CI_CK][9];
+    const int tx = threadIdx.x % CI_TW, ty = threadIdx.x / CI_TW;
+    const int x0 = blockIdx.x * CI_TW, y0 = blockIdx.y * CI_TH, b = blockIdx.z;
+    const long long HW = (long long)H * W;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += CI_CK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < CI_CK * (CI_TH + 2) * (CI_TW + 2); e += 256) {
+            const int c = e / ((CI_TH + 2) * (CI_TW + 2)), rem = e % ((CI_TH + 2) * (CI_TW + 2));
+            const int py = rem / (CI_TW + 2), px = rem % (CI_TW + 2);
+            const int yy = y0 + py - 1, xx = x0 + px - 1;
+            float v = 0.f;
+            if (c0 + c < Cin && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                v = x[((long long)b * Cin + c0 + c) * HW + (long long)yy * W + xx];
+                v = v > 0.f ? v : 0.2f * v;
+            }
+            patch[c][py][px] = v;
+        }
+        for (int e = threadIdx.x; e < 3 * CI_CK * 9; e += 256) {
+            const int co = e / (CI_CK * 9), c = (e / 9) % CI_CK, t = e % 9;
+            ws[co][c][t] = (c0 + c < Cin) ? w[((long long)co * Cin + c0 + c) * 9 + t] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CI_CK; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = patch[c][ty + t / 3][tx + t % 3];
+                a0 += ws[0][c][t] * v;
+                a1 += ws[1][c][t] * v;
+                a2 += ws[2][c][t] * v;
+            }
+    }
+    const int xx = x0 + tx, yy = y0 + ty;
+    if (xx < W && yy < H) {
+        float* o = out + (long long)b * 3 * HW + (long long)yy * W + xx;
+        o[0] = tanhf(a0 + bias[0]);
+        o[HW] = tanhf(a1 + bias[1]);
+        o[2 * HW] = tanhf(a2 + bias[2]);
+    }
+}
+
+hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
+                         hipStream_t s) {
+    dim3 grid((W + CI_TW - 1) / CI_TW, (H + CI_TH - 1) / CI_TH, B);
+    hipLaunchKernelGGL(conv_img_kernel, grid, dim3(256), 0, s, x, w, bias, out, B, Cin, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device noise (used only when the caller passes noise == NULL): counter-based, one N(0,1) per element via a
+// 64-bit mix (splitmix64) + Box-Muller.  The reference draws torch.randn (normalization.py:111) from an
+// unseeded global generator, so there is nothing to be bit-compatible with; parity tests pass explicit planes.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void noise_kernel(float* __restrict__ out, long long n, uint64_t seed) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint64_t h = mix64(seed ^ mix64((uint64_t)i));
+        const float u1 = ((uint32_t)(h >> 40) + 1) * (1.0f / 16777217.0f);        // (0,1]
+        const float u2 = (uint32_t)((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);  // [0,1)
+        out[i] = sqrtf(-2.f * __logf(u1)) * __cosf(6.28318530718f * u2);
+    }
+}
+
+hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(noise_kernel, dim3(2048), dim3(256), 0, s, out, n, seed);
+    return hipGetLastError();
+}
+
+}  // namespace chk

@@ -1,0 +1,515 @@
+// sean_model.cpp -- weight folding/packing + forward schedule of the SEAN generator on MI355X.
+//
+// Reference behaviour restated (file:line refer to /root/reference):
+//   generator.py:72-109            SPADEGenerator.forward (fc, 7 ResBlocks, nearest x2 ups, conv_img, tanh)
+//   architecture.py:69-96          SPADEResnetBlock.forward / shortcut / actvn
+//   normalization.py:108-189       ACE.forward (noise, eval-BN, style broadcast, style convs, SPADE, blend, modulate)
+//   normalization.py:249-257       SPADE.forward
+//   torch spectral_norm (eval)     W = W_orig / (u . W_mat v)
+// Exact reformulations used: convs whose input is a one-hot label map or the piecewise-constant
+// style map are evaluated as 9-tap label-table gathers; sigmoid(blending) is folded into weights/biases.
+#include "sean_model.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "conv_mfma.h"
+#include "kernels.h"
+
+namespace chk {
+
+namespace {
+
+constexpr int LABEL_NC = 19, STYLE = 512, HID = 128;
+
+struct Builder {
+    const TensorStore& ts;
+    SeanModel& m;
+    std::string err;
+    Builder(const TensorStore& t, SeanModel& mm) : ts(t), m(mm) {}
+
+    const HostTensor* get(const std::string& n, size_t numel) {
+        auto it = ts.find(n);
+        if (it == ts.end()) {
+            if (err.empty()) err = "missing tensor '" + n + "'";
+            return nullptr;
+        }
+        if (it->second.dtype != 0 || it->second.numel() != numel) {
+            if (err.empty()) err = "tensor '" + n + "' has wrong dtype/size";
+            return nullptr;
+        }
+        return &it->second;
+    }
+    float* upload(const std::vector<float>& v) {
+        void* d = nullptr;
+        if (hipMalloc(&d, v.size() * sizeof(float) + 64) != hipSuccess) {
+            if (err.empty()) err = "hipMalloc failed (weights)";
+            return nullptr;
+        }
+        m.allocs.push_back(d);
+        if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            if (err.empty()) err = "hipMemcpy failed (weights)";
+        return static_cast<float*>(d);
+    }
+    void* dalloc(size_t bytes) {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes + 256) != hipSuccess) {
+            if (err.empty()) err = "hipMalloc failed (workspace, " + std::to_string(bytes >> 20) + " MiB)";
+            return nullptr;
+        }
+        m.allocs.push_back(d);
+        return d;
+    }
+};
+
+// Pack GEMM rows into the per-lane A-fragment order conv_mfma_kernel streams:
+//   [wave tile (64 rows)][chunk][k-group (4 k-steps)][M-subtile (2)][lane (64)][4 floats]
+//   lane l holds row (l&31) of its M-subtile, channel parity (l>>5); k-step s = tap*(CK/2) + channel pair.
+template <class F>
+std::vector<float> pack_A(int rows, int Cin, int KS, int CK, F get) {
+    int mt64 = (rows + 63) / 64;
+    mt64 = (mt64 + 1) & ~1;   // even number of wave tiles so WM=2 blocks never read past the end
+    const int nch = (Cin + CK - 1) / CK;
+    const int ksteps = KS * KS * CK / 2, ng = ksteps / 4, half = CK / 2;
+    std::vector<float> dst((size_t)mt64 * nch * ng * 2 * 64 * 4, 0.f);
+    size_t o = 0;
+    for (int mt = 0; mt < mt64; ++mt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int g = 0; g < ng; ++g)
+                for (int ms = 0; ms < 2; ++ms)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int q = 0; q < 4; ++q, ++o) {
+                            const int s = g * 4 + q, t = s / half, cp = s % half;
+                            const int row = mt * 64 + ms * 32 + (lane & 31);
+                            const int ci = ch * CK + 2 * cp + (lane >> 5);
+                            if (row < rows && ci < Cin) dst[o] = get(row, ci, t);
+                        }
+    return dst;
+}
+
+}  // namespace
+
+size_t SeanModel::noise_floats(int S) const {
+    size_t n = 0;
+    for (const auto& b : blocks) {
+        const size_t r = (size_t)S / b.res_div;
+        n += r * r * (b.learned ? 3 : 2);
+    }
+    return n;
+}
+
+std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
+    Builder B(ts, *this);
+    auto itfc = ts.find("fc.weight");
+    if (itfc == ts.end() || itfc->second.shape.size() != 4) return "missing tensor 'fc.weight'";
+    ngf = (int)itfc->second.shape[0] / 16;
+    if (ngf < 4 || (ngf & 3)) return "unsupported ngf";
+    if (ms % 32 != 0 || ms < 32 || mb < 1) return "max_size must be a multiple of 32 and max_batch >= 1";
+    max_batch = mb;
+    max_size = ms;
+
+    // ---- fc as label table: T[(j*9+t)*K + k] = W[k][j][t] --------------------------------------------------
+    {
+        const int K = 16 * ngf;
+        auto w = B.get("fc.weight", (size_t)K * LABEL_NC * 9);
+        auto b = B.get("fc.bias", K);
+        if (!w || !b) return B.err;
+        std::vector<float> T((size_t)LABEL_NC * 9 * K);
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < LABEL_NC; ++j)
+                for (int t = 0; t < 9; ++t) T[((size_t)j * 9 + t) * K + k] = w->f32()[((size_t)k * LABEL_NC + j) * 9 + t];
+        fc_table = B.upload(T);
+        fc_bias = B.upload(std::vector<float>(b->f32(), b->f32() + K));
+    }
+    {
+        auto w = B.get("conv_img.weight", (size_t)3 * ngf * 9);
+        auto b = B.get("conv_img.bias", 3);
+        if (!w || !b) return B.err;
+        img_w = B.upload(std::vector<float>(w->f32(), w->f32() + 3 * ngf * 9));
+        img_b = B.upload(std::vector<float>(b->f32(), b->f32() + 3));
+    }
+
+    struct BS { const char* name; int fin, fout, res_div; bool up, styled; };
+    const BS specs[7] = {{"head_0", 16, 16, 32, false, true}, {"G_middle_0", 16, 16, 16, true, true},
+                         {"G_middle_1", 16, 16, 16, false, true}, {"up_0", 16, 8, 8, true, true},
+                         {"up_1", 8, 4, 4, true, true}, {"up_2", 4, 2, 2, true, true},
+                         {"up_3", 2, 1, 1, true, false}};
+    int ace_index = 0;
+    blocks.clear();
+    for (const auto& s : specs) {
+        BlockW bw;
+        bw.name = s.name;
+        bw.fin = s.fin * ngf;
+        bw.fout = s.fout * ngf;
+        bw.fmid = bw.fin < bw.fout ? bw.fin : bw.fout;
+        bw.res_div = s.res_div;
+        bw.up_before = s.up;
+        bw.styled = s.styled;
+        bw.learned = bw.fin != bw.fout;
+
+        auto spectral = [&](const std::string& p, int cout, int cin, int ks, bool bias, ConvW& cw) {
+            const size_t kk = (size_t)cin * ks * ks;
+            auto w = B.get(p + ".weight_orig", (size_t)cout * kk);
+            auto u = B.get(p + ".weight_u", cout);
+            auto v = B.get(p + ".weight_v", kk);
+            if (!w || !u || !v) return;
+            double sigma = 0.0;   // u . (W_mat v)
+            for (int o = 0; o < cout; ++o) {
+                double acc = 0.0;
+                const float* wr = w->f32() + (size_t)o * kk;
+                for (size_t i = 0; i < kk; ++i) acc += (double)wr[i] * v->f32()[i];
+                sigma += acc * u->f32()[o];
+            }
+            const float inv = (float)(1.0 / sigma);
+            const float* wp = w->f32();
+            const int ck = ks == 3 ? CK_KS3 : CK_KS1;
+            auto pk = pack_A(cout, cin, ks, ck, [&](int row, int ci, int t) {
+                return wp[((size_t)row * cin + ci) * ks * ks + t] / (float)sigma;
+            });
+            (void)inv;
+            cw.wpk = B.upload(pk);
+            cw.Cout = cout;
+            cw.Cin = cin;
+            cw.KS = ks;
+            if (bias) {
+                auto bb = B.get(p + ".bias", cout);
+                if (bb) cw.bias = B.upload(std::vector<float>(bb->f32(), bb->f32() + cout));
+            }
+        };
+        spectral(bw.name + ".conv_0", bw.fmid, bw.fin, 3, true, bw.conv_0);
+        spectral(bw.name + ".conv_1", bw.fout, bw.fmid, 3, true, bw.conv_1);
+        if (bw.learned) spectral(bw.name + ".conv_s", bw.fout, bw.fin, 1, false, bw.conv_s);
+        if (!B.err.empty()) return B.err;
+
+        auto ace = [&](const std::string& p, int C, AceW& a) {
+            a.name = p;
+            a.C = C;
+            a.res_div = s.res_div;
+            a.styled = s.styled;
+            a.index = ace_index++;
+            auto nvar = B.get(p + ".noise_var", C);
+            auto rm = B.get(p + ".param_free_norm.running_mean", C);
+            auto rv = B.get(p + ".param_free_norm.running_var", C);
+            auto ws = B.get(p + ".Spade.mlp_shared.0.weight", (size_t)HID * LABEL_NC * 9);
+            auto bs = B.get(p + ".Spade.mlp_shared.0.bias", HID);
+            auto wg = B.get(p + ".Spade.mlp_gamma.weight", (size_t)C * HID * 9);
+            auto bg = B.get(p + ".Spade.mlp_gamma.bias", C);
+            auto wb = B.get(p + ".Spade.mlp_beta.weight", (size_t)C * HID * 9);
+            auto bb = B.get(p + ".Spade.mlp_beta.bias", C);
+            auto blg = B.get(p + ".blending_gamma", 1);
+            auto blb = B.get(p + ".blending_beta", 1);
+            if (!nvar || !rm || !rv || !ws || !bs || !wg || !bg || !wb || !bb || !blg || !blb) return;
+            float ag = 0.f, ab = 0.f;   // weight of the style branch
+            if (a.styled) {
+                ag = 1.f / (1.f + std::exp(-blg->f32()[0]));
+                ab = 1.f / (1.f + std::exp(-blb->f32()[0]));
+            }
+            // eval BN (eps 1e-5) + noise scaling as per-channel affine
+            std::vector<float> va(C), vd(C), vn(C), vbg(C), vbb(C);
+            for (int c = 0; c < C; ++c) {
+                const float rstd = 1.f / std::sqrt(rv->f32()[c] + 1e-5f);
+                va[c] = rstd;
+                vd[c] = -rm->f32()[c] * rstd;
+                vn[c] = nvar->f32()[c] * rstd;
+                vbg[c] = (1.f - ag) * bg->f32()[c];
+                vbb[c] = (1.f - ab) * bb->f32()[c];
+            }
+            // mlp_shared as label table
+            std::vector<float> T((size_t)LABEL_NC * 9 * HID);
+            for (int k = 0; k < HID; ++k)
+                for (int j = 0; j < LABEL_NC; ++j)
+                    for (int t = 0; t < 9; ++t)
+                        T[((size_t)j * 9 + t) * HID + k] = ws->f32()[((size_t)k * LABEL_NC + j) * 9 + t];
+            a.actv_table = B.upload(T);
+            a.actv_bias = B.upload(std::vector<float>(bs->f32(), bs->f32() + HID));
+            // SPADE gamma/beta rows: 64-row tiles = (gamma of 32 channels | beta of the same 32 channels)
+            const int tiles = (C + 31) / 32;
+            const float* wgp = wg->f32();
+            const float* wbp = wb->f32();
+            const float sg = 1.f - ag, sb = 1.f - ab;
+            auto pk = pack_A(tiles * 64, HID, 3, CK_KS3, [&](int row, int ci, int t) {
+                const int c = (row / 64) * 32 + (row & 31);
+                if (c >= C) return 0.f;
+                const bool beta = (row & 32) != 0;
+                const float w = (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t];
+                return w * (beta ? sb : sg);
+            });
+            a.spade_wpk = B.upload(pk);
+            if (a.styled) {
+                auto cg = B.get(p + ".conv_gamma.weight", (size_t)C * STYLE * 9);
+                auto cgb = B.get(p + ".conv_gamma.bias", C);
+                auto cb = B.get(p + ".conv_beta.weight", (size_t)C * STYLE * 9);
+                auto cbb = B.get(p + ".conv_beta.bias", C);
+                if (!cg || !cgb || !cb || !cbb) return;
+                for (int c = 0; c < C; ++c) {
+                    vbg[c] += ag * cgb->f32()[c];
+                    vbb[c] += ab * cbb->f32()[c];
+                }
+                std::vector<float> fw((size_t)LABEL_NC * STYLE * STYLE), fb((size_t)LABEL_NC * STYLE);
+                for (int j = 0; j < LABEL_NC; ++j) {
+                    auto w = B.get(p + ".fc_mu" + std::to_string(j) + ".weight", (size_t)STYLE * STYLE);
+                    auto b = B.get(p + ".fc_mu" + std::to_string(j) + ".bias", STYLE);
+                    if (!w || !b) return;
+                    std::memcpy(&fw[(size_t)j * STYLE * STYLE], w->f32(), sizeof(float) * STYLE * STYLE);
+                    std::memcpy(&fb[(size_t)j * STYLE], b->f32(), sizeof(float) * STYLE);
+                }
+                a.fcmu_w = B.upload(fw);
+                a.fcmu_b = B.upload(fb);
+                // LUT GEMM rows (t, gamma|beta, c) <- alpha * W[c][k][t]
+                const float* cgp = cg->f32();
+                const float* cbp = cb->f32();
+                auto lp = pack_A(18 * C, STYLE, 1, CK_KS1, [&](int row, int k, int) {
+                    const int t = row / (2 * C), gb = (row / C) & 1, c = row % C;
+                    return gb ? ab * cbp[((size_t)c * STYLE + k) * 9 + t] : ag * cgp[((size_t)c * STYLE + k) * 9 + t];
+                });
+                a.lut_wpk = B.upload(lp);
+            }
+            a.bn_a = B.upload(va);
+            a.bn_d = B.upload(vd);
+            a.nv = B.upload(vn);
+            a.bias_g = B.upload(vbg);
+            a.bias_b = B.upload(vbb);
+        };
+        if (bw.learned) ace(bw.name + ".ace_s", bw.fin, bw.ace_s);
+        ace(bw.name + ".ace_0", bw.fin, bw.ace_0);
+        ace(bw.name + ".ace_1", bw.fmid, bw.ace_1);
+        if (!B.err.empty()) return B.err;
+        blocks.push_back(bw);
+    }
+
+    // ---- workspace arena --------------------------------------------------------------------------------
+    const size_t MB = mb, S = ms;
+    for (int k = 1; k <= 5; ++k) {   // res_div 2^k
+        const size_t r = S >> k;
+        lab_r[k] = static_cast<uint8_t*>(B.dalloc(MB * r * r));
+    }
+    size_t nf = noise_floats(ms);
+    noise_ws = static_cast<float*>(B.dalloc(MB * nf * 4));
+    const size_t npad = ((MB * LABEL_NC + 31) / 32) * 32;
+    mu_img = static_cast<float*>(B.dalloc((size_t)STYLE * npad * 4));
+    size_t lutmax = 0, h0max = 0, midmax = 0, outmax = 0;
+    for (const auto& b : blocks) {
+        const size_t r = S / b.res_div, px = MB * r * r;
+        if (b.styled) lutmax = std::max(lutmax, (size_t)MB * LABEL_NC * 18 * b.fin);
+        h0max = std::max(h0max, px * b.fin);
+        midmax = std::max(midmax, px * b.fmid);
+        outmax = std::max(outmax, px * b.fout);
+    }
+    outmax = std::max(outmax, (size_t)MB * 16 * ngf * (S / 32) * (S / 32));
+    lut = static_cast<float*>(B.dalloc(lutmax * 4));
+    actv = static_cast<float*>(B.dalloc(MB * S * S * HID * 4));
+    h0 = static_cast<float*>(B.dalloc(h0max * 4));
+    hs = static_cast<float*>(B.dalloc(h0max * 4));
+    dx = static_cast<float*>(B.dalloc(midmax * 4));
+    h1 = static_cast<float*>(B.dalloc(midmax * 4));
+    xs = static_cast<float*>(B.dalloc(outmax * 4));
+    xa = static_cast<float*>(B.dalloc(outmax * 4));
+    xb = static_cast<float*>(B.dalloc(outmax * 4));
+    if (!B.err.empty()) return B.err;
+    if (hipDeviceSynchronize() != hipSuccess) return "hipDeviceSynchronize failed after weight upload";
+    return "";
+}
+
+void SeanModel::destroy() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    for (auto& r : prof) {
+        ev_pool.push_back(r.e0);
+        ev_pool.push_back(r.e1);
+    }
+    prof.clear();
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    ev_pool.clear();
+    blocks.clear();
+}
+
+namespace {
+
+struct Runner {
+    SeanModel& m;
+    hipStream_t st;
+    std::string err;
+    int B, S;
+    Runner(SeanModel& mm, hipStream_t s, int b, int sz) : m(mm), st(s), B(b), S(sz) {}
+
+    void check(hipError_t e, const char* what) {
+        if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    hipEvent_t ev() {
+        if (!m.ev_pool.empty()) {
+            hipEvent_t e = m.ev_pool.back();
+            m.ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        check(hipEventCreate(&e), "hipEventCreate");
+        return e;
+    }
+    template <class F>
+    void timed(int kind, double flops, double bytes, F launch) {
+        if (!m.prof_on) {
+            launch();
+            return;
+        }
+        ProfRec r;
+        r.kind = kind;
+        r.flops = flops;
+        r.bytes = bytes;
+        r.e0 = ev();
+        r.e1 = ev();
+        check(hipEventRecord(r.e0, st), "hipEventRecord");
+        launch();
+        check(hipEventRecord(r.e1, st), "hipEventRecord");
+        m.prof.push_back(r);
+    }
+    void tap(const std::string& name, const float* src, size_t floats) {
+        auto it = m.taps.find(name);
+        if (it != m.taps.end() && it->second)
+            check(hipMemcpyAsync(it->second, src, floats * 4, hipMemcpyDeviceToDevice, st), "tap copy");
+    }
+    const uint8_t* labels_at(const uint8_t* full, int res_div) {
+        if (res_div == 1) return full;
+        int k = 0;
+        while ((1 << k) < res_div) ++k;
+        return m.lab_r[k];
+    }
+
+    // one ACE: SPADE hidden activations (label LUT) -> fused gamma/beta conv + modulation -> h
+    void ace(const AceW& a, const uint8_t* labfull, const float* codes, const float* noise, size_t nf, size_t noff,
+             const float* x, int x_up, int act, float* hout) {
+        const int r = S / a.res_div;
+        const uint8_t* lab = labels_at(labfull, a.res_div);
+        const double npix = (double)B * r * r;
+        if (a.styled) {
+            const int N = B * LABEL_NC, npad = ((N + 31) / 32) * 32;
+            check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st), "fc_mu");
+            ConvParams p{};
+            p.in = m.mu_img;
+            p.wpk = a.lut_wpk;
+            p.out = m.lut;
+            p.B = 1;
+            p.Cin = STYLE;
+            p.H = npad / 32;
+            p.W = 32;
+            p.Mrows = 18 * a.C;
+            p.npix_valid = N;
+            timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
+                  [&] { check(conv_nhwc1x1(p, st), "lut gemm"); });
+        }
+        check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
+        ConvParams p{};
+        p.in = m.actv;
+        p.wpk = a.spade_wpk;
+        p.out = hout;
+        p.B = B;
+        p.Cin = HID;
+        p.H = r;
+        p.W = r;
+        p.Mrows = 2 * a.C;
+        p.x = x;
+        p.x_up = x_up;
+        p.C = a.C;
+        p.bias_g = a.bias_g;
+        p.bias_b = a.bias_b;
+        p.bn_a = a.bn_a;
+        p.bn_d = a.bn_d;
+        p.nv = a.nv;
+        p.noise = noise + noff;
+        p.noise_bstride = (long long)nf;
+        p.lab = lab;
+        p.lut = a.styled ? m.lut : nullptr;
+        p.act = act;
+        const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
+        timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
+              4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(conv_ace(p, st), "spade conv"); });
+    }
+
+    void conv(const ConvW& w, const float* in, float* out, int r, const float* res, int res_up) {
+        ConvParams p{};
+        p.in = in;
+        p.wpk = w.wpk;
+        p.out = out;
+        p.B = B;
+        p.Cin = w.Cin;
+        p.H = r;
+        p.W = r;
+        p.Mrows = w.Cout;
+        p.bias = w.bias;
+        p.res = res;
+        p.res_up = res_up;
+        p.act = ACT_NONE;
+        const double npix = (double)B * r * r, k2 = w.KS * w.KS;
+        timed(0, 2.0 * w.Cout * w.Cin * k2 * npix,
+              4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * k2), [&] {
+                  check(w.KS == 3 ? conv_plain3(p, st) : conv_plain1(p, st), "conv");
+              });
+    }
+};
+
+}  // namespace
+
+std::string SeanModel::generate(const uint8_t* labels, const float* codes, const float* noise, uint64_t seed,
+                                float* out, int Btot, int S, hipStream_t st) {
+    if (blocks.empty()) return "model not finalized";
+    if (S % 32 != 0 || S < 32 || S > max_size) return "S must be a multiple of 32 and <= max_size";
+    if (Btot < 1) return "B must be >= 1";
+    const size_t nf = noise_floats(S);
+    for (int bo = 0; bo < Btot; bo += max_batch) {
+        const int B = std::min(max_batch, Btot - bo);
+        Runner R(*this, st, B, S);
+        const uint8_t* lab = labels + (size_t)bo * S * S;
+        const float* cd = codes + (size_t)bo * LABEL_NC * STYLE;
+        const float* nz;
+        if (noise) {
+            nz = noise + (size_t)bo * nf;
+        } else {
+            R.check(gen_noise(noise_ws, (long long)B * nf, seed + 0x632BE59BD9B4E019ull * (uint64_t)(bo + 1), st),
+                    "gen_noise");
+            nz = noise_ws;
+        }
+        for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");
+
+        const int sw = S / 32;
+        float* x = xa;
+        float* y = xb;
+        R.check(onehot_conv3x3(lab_r[5], fc_table, fc_bias, x, B, sw, sw, 16 * ngf, 0, st), "fc");
+        R.tap("fc", x, (size_t)B * 16 * ngf * sw * sw);
+        size_t noff = 0;
+        for (const auto& b : blocks) {
+            const int r = S / b.res_div;
+            const size_t rr = (size_t)r * r;
+            const int up = b.up_before ? 1 : 0;
+            const float* xsrc = x;   // block input (at r/2 when up_before)
+            const float* shortcut;
+            int sc_up;
+            if (b.learned) {
+                R.ace(b.ace_s, lab, cd, nz, nf, noff, xsrc, up, ACT_NONE, hs);
+                noff += rr;
+                R.tap(b.name + ".hs", hs, (size_t)B * b.fin * rr);
+                R.conv(b.conv_s, hs, xs, r, nullptr, 0);
+                R.tap(b.name + ".xs", xs, (size_t)B * b.fout * rr);
+                shortcut = xs;
+                sc_up = 0;
+            } else {
+                shortcut = xsrc;
+                sc_up = up;
+            }
+            R.ace(b.ace_0, lab, cd, nz, nf, noff, xsrc, up, ACT_LRELU, h0);
+            noff += rr;
+            R.tap(b.name + ".h0", h0, (size_t)B * b.fin * rr);
+            R.conv(b.conv_0, h0, dx, r, nullptr, 0);
+            R.tap(b.name + ".dx", dx, (size_t)B * b.fmid * rr);
+            R.ace(b.ace_1, lab, cd, nz, nf, noff, dx, 0, ACT_LRELU, h1);
+            noff += rr;
+            R.tap(b.name + ".h1", h1, (size_t)B * b.fmid * rr);
+            R.conv(b.conv_1, h1, y, r, shortcut, sc_up);
+            R.tap(b.name, y, (size_t)B * b.fout * rr);
+            std::swap(x, y);
+        }
+        R.check(conv_img_tanh(x, img_w, img_b, out + (size_t)bo * 3 * S * S, B, ngf, S, S, st), "conv_img");
+        if (!R.err.empty()) return R.err;
+    }
+    return "";
+}
+
+}  // namespace chk

@@ -1,0 +1,82 @@
+// sean_model.h -- host side of the SEAN generator path: weight folding/packing at load, workspace arena,
+// and the launch sequence of one batched forward.  No torch types; plain HIP runtime.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace chk {
+
+struct HostTensor {
+    std::vector<char> data;
+    std::vector<int64_t> shape;
+    int dtype = 0;  // 0 f32, 1 i64
+    const float* f32() const { return reinterpret_cast<const float*>(data.data()); }
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        return n;
+    }
+};
+typedef std::map<std::string, HostTensor> TensorStore;
+
+struct ConvW {
+    float* wpk = nullptr;
+    float* bias = nullptr;
+    int Cout = 0, Cin = 0, KS = 0;
+};
+
+struct AceW {
+    std::string name;
+    int C = 0, res_div = 1, index = 0;
+    bool styled = false;
+    float* spade_wpk = nullptr;                 // (gamma|beta) 64-row tiles, K = 128*9
+    float *bias_g = nullptr, *bias_b = nullptr; // blended biases
+    float *bn_a = nullptr, *bn_d = nullptr, *nv = nullptr;
+    float *actv_table = nullptr, *actv_bias = nullptr;   // mlp_shared as label LUT [19*9][128]
+    float *fcmu_w = nullptr, *fcmu_b = nullptr;          // [19][512][512], [19][512]
+    float* lut_wpk = nullptr;                   // rows (tap, gamma|beta, c) x K=512
+};
+
+struct BlockW {
+    std::string name;
+    int fin = 0, fout = 0, fmid = 0, res_div = 1;
+    bool up_before = false, styled = false, learned = false;
+    ConvW conv_0, conv_1, conv_s;
+    AceW ace_0, ace_1, ace_s;
+};
+
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int kind;       // 0 plain conv, 1 ACE conv, 2 LUT gemm
+    double flops, bytes;
+};
+
+struct SeanModel {
+    int ngf = 0, max_batch = 0, max_size = 0;
+    std::vector<BlockW> blocks;
+    float *fc_table = nullptr, *fc_bias = nullptr;     // fc conv as label LUT [19*9][16ngf]
+    float *img_w = nullptr, *img_b = nullptr;          // conv_img raw [3][ngf][3][3]
+    std::vector<void*> allocs;                         // everything to hipFree
+    // workspace
+    uint8_t* lab_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // res_div 32,16,8,4,2 (index by log2) ; [0] unused
+    float *noise_ws = nullptr, *mu_img = nullptr, *lut = nullptr, *actv = nullptr;
+    float *h0 = nullptr, *hs = nullptr, *dx = nullptr, *h1 = nullptr, *xs = nullptr, *xa = nullptr, *xb = nullptr;
+    std::map<std::string, float*> taps;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+
+    size_t noise_floats(int S) const;
+    // returns empty string on success, else error message
+    std::string build(const TensorStore& ts, int max_batch, int max_size);
+    std::string generate(const uint8_t* labels, const float* codes, const float* noise, uint64_t seed, float* out,
+                         int B, int S, hipStream_t stream);
+    void destroy();
+};
+
+}  // namespace chk

@@ -1,0 +1,55 @@
+"""Host-side wrapper of the HIP SEAN generator: the object that stands where the reference keeps
+``Pix2PixModel.netG`` (sean_codes/models/pix2pix_model.py:103-113) for the 'UI_mode' path.
+
+    gen = SeanGenerator(device=0).load_state_dict(sd, max_batch=16, max_size=512)
+    img = gen.generate(labels_u8[B,S,S], codes[B,19,512], noise=None|[B,NF])   # -> cuda float32 [B,3,S,S]
+"""
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import lib as _lib
+
+
+class SeanGenerator:
+    def __init__(self, device: int = 0):
+        self.device_index = device
+        self.device = torch.device('cuda', device)
+        self.handle = _lib.Handle(device)
+        self.max_batch = self.max_size = 0
+
+    def load_state_dict(self, sd: Dict[str, object], max_batch: int = 16, max_size: int = 512):
+        """sd: reference-keyed state dict (torch tensors or numpy arrays), e.g. torch.load('latest_net_G.pth')
+        (util/util.py:202-208) or ctrlhair_amd.procedural.sean_state_dict()."""
+        for k, v in sd.items():
+            if k.startswith('Zencoder.'):
+                continue   # style encoder: separate entry point (not part of the generator forward)
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if a.dtype not in (np.float32, np.int64):
+                a = a.astype(np.float32)
+            self.handle.load_tensor(_lib.MODEL_SEAN, k, a)
+        self.handle.finalize(_lib.MODEL_SEAN, max_batch, max_size)
+        self.max_batch, self.max_size = max_batch, max_size
+        return self
+
+    def noise_floats(self, S: int) -> int:
+        return self.handle.sean_noise_floats(S)
+
+    def generate(self, labels: torch.Tensor, codes: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                 seed: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert labels.is_cuda and labels.dtype == torch.uint8 and labels.dim() == 3, 'labels: cuda uint8 [B,S,S]'
+        B, S = labels.shape[0], labels.shape[-1]
+        assert labels.shape[1] == S
+        assert codes.is_cuda and codes.dtype == torch.float32 and tuple(codes.shape) == (B, 19, 512)
+        labels, codes = labels.contiguous(), codes.contiguous()
+        nptr = None
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.float32 and tuple(noise.shape) == (B, self.noise_floats(S))
+            noise = noise.contiguous()
+            nptr = noise.data_ptr()
+        if out is None:
+            out = torch.empty(B, 3, S, S, dtype=torch.float32, device=labels.device)
+        stream = torch.cuda.current_stream(labels.device).cuda_stream
+        self.handle.sean_generate(labels.data_ptr(), codes.data_ptr(), nptr, seed, out.data_ptr(), B, S, stream)
+        return out

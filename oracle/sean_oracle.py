@@ -113,17 +113,24 @@ def resblock(sd, blk, x, seg, codes, noise_iter, weights_cache, stats_out=None, 
             weights_cache[prefix] = spectral_weight(sd, prefix)
         return weights_cache[prefix]
 
+    def tap(k, v):
+        if taps is not None:
+            taps[name + k] = v
+
     if blk.learned_shortcut:
         x_s = ace(sd, name + '.ace_s', x, seg, codes, next(noise_iter), styled, stats_out)
+        tap('.hs', x_s)
         x_s = F.conv2d(x_s, w(name + '.conv_s'))
+        tap('.xs', x_s)
     else:
         x_s = x
-    dx = ace(sd, name + '.ace_0', x, seg, codes, next(noise_iter), styled, stats_out)
-    if taps is not None:
-        taps[name + '.ace_0'] = dx
-    dx = F.conv2d(F.leaky_relu(dx, 0.2), w(name + '.conv_0'), sd[name + '.conv_0.bias'], padding=1)
-    dx = ace(sd, name + '.ace_1', dx, seg, codes, next(noise_iter), styled, stats_out)
-    dx = F.conv2d(F.leaky_relu(dx, 0.2), w(name + '.conv_1'), sd[name + '.conv_1.bias'], padding=1)
+    dx = F.leaky_relu(ace(sd, name + '.ace_0', x, seg, codes, next(noise_iter), styled, stats_out), 0.2)
+    tap('.h0', dx)
+    dx = F.conv2d(dx, w(name + '.conv_0'), sd[name + '.conv_0.bias'], padding=1)
+    tap('.dx', dx)
+    dx = F.leaky_relu(ace(sd, name + '.ace_1', dx, seg, codes, next(noise_iter), styled, stats_out), 0.2)
+    tap('.h1', dx)
+    dx = F.conv2d(dx, w(name + '.conv_1'), sd[name + '.conv_1.bias'], padding=1)
     return x_s + dx
 
 
