@@ -121,6 +121,20 @@ int ch_sean_generate(ch_handle* h, const uint8_t* labels, const float* codes, co
     return CH_OK;
 }
 
+int ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float* codes, int B, int S,
+                   ch_stream_t stream) {
+    if (!h) return CH_ERR_ARG;
+    if (!h->sean_ready) return fail(h, CH_ERR_STATE, "ch_sean_encode: SEAN weights not finalized");
+    if (!img || !labels || !codes || B < 1) return fail(h, CH_ERR_ARG, "ch_sean_encode: bad argument");
+    try {
+        std::string e = h->sean.encode(img, labels, codes, B, S, static_cast<hipStream_t>(stream));
+        if (!e.empty()) return fail(h, CH_ERR_HIP, "ch_sean_encode: " + e);
+    } catch (const std::exception& e) {
+        return fail(h, CH_ERR_HIP, std::string("ch_sean_encode: ") + e.what());
+    }
+    return CH_OK;
+}
+
 int ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr) {
     if (!h || !name) return CH_ERR_ARG;
     if (dev_ptr) h->sean.taps[name] = dev_ptr;

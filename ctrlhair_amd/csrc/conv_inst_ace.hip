@@ -4,10 +4,10 @@ namespace chk {
 hipError_t conv_ace(const ConvParams& p, hipStream_t s) {
     const int rows = ((p.C + 31) / 32) * 64;   // 64-row wave tiles of 32 channels (gamma | beta)
     if (p.W >= 32) {
-        if (rows <= 64) return launch_conv<3, 1, 32, 16, 1, CK_KS3, EPI_ACE>(p, rows, s);
-        return launch_conv<3, 2, 32, 8, 1, CK_KS3, EPI_ACE>(p, rows, s);
+        if (rows <= 64) return launch_conv<3, 1, 1, 32, 16, 1, CK_KS3, EPI_ACE>(p, rows, s);
+        return launch_conv<3, 1, 2, 32, 8, 1, CK_KS3, EPI_ACE>(p, rows, s);
     }
-    if (p.W > 8) return launch_conv<3, 2, 16, 16, 1, CK_KS3, EPI_ACE>(p, rows, s);
-    return launch_conv<3, 2, 8, 8, 4, CK_KS3, EPI_ACE>(p, rows, s);
+    if (p.W > 8) return launch_conv<3, 1, 2, 16, 16, 1, CK_KS3, EPI_ACE>(p, rows, s);
+    return launch_conv<3, 1, 2, 8, 8, 4, CK_KS3, EPI_ACE>(p, rows, s);
 }
 }  // namespace chk

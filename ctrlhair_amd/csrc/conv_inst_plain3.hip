@@ -4,10 +4,10 @@ namespace chk {
 hipError_t conv_plain3(const ConvParams& p, hipStream_t s) {
     const int rows = p.Mrows;
     if (p.W >= 32) {
-        if (rows <= 64) return launch_conv<3, 1, 32, 16, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
-        return launch_conv<3, 2, 32, 8, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
+        if (rows <= 64) return launch_conv<3, 1, 1, 32, 16, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
+        return launch_conv<3, 1, 2, 32, 8, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
     }
-    if (p.W > 8) return launch_conv<3, 2, 16, 16, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
-    return launch_conv<3, 2, 8, 8, 4, CK_KS3, EPI_PLAIN>(p, rows, s);
+    if (p.W > 8) return launch_conv<3, 1, 2, 16, 16, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
+    return launch_conv<3, 1, 2, 8, 8, 4, CK_KS3, EPI_PLAIN>(p, rows, s);
 }
 }  // namespace chk

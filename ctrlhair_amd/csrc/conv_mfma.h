@@ -1,5 +1,6 @@
 // conv_mfma.h -- implicit-GEMM convolution for gfx950 on the exact-f32 matrix cores
-// (v_mfma_f32_32x32x2_f32), stride 1, "same" zero padding, KS in {1,3}.
+// (v_mfma_f32_32x32x2_f32).  KS in {1,3,4}, stride 1 or 2, zero or reflection padding, optional nearest-x2 or
+// zero-insertion-x2 view of the input (the latter turns ConvTranspose2d(k3,s2,p1,op1) into a plain conv).
 //
 //   GEMM view:  D[row][pixel] = sum_{ci,tap} A[row][(ci,tap)] * X[ci][pixel + tap]
 //     A : weights, pre-packed on the host into per-lane MFMA A-fragments (pack_conv_weights, sean_model.cpp),
@@ -28,13 +29,19 @@ namespace chk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EPI_PLAIN = 0, EPI_ACE = 1, EPI_NHWC = 2 };
-enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3 };
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
+enum { IN_DIRECT = 0, IN_UP2_NEAREST = 1, IN_UP2_ZEROINS = 2 };
 
 struct ConvParams {
-    const float* in;        // [B][Cin][H][W]
+    const float* in;        // [B][Cin][Hin][Win]
     const float* wpk;       // packed A fragments
     float* out;
-    int B, Cin, H, W;
+    int B, Cin, H, W;       // H, W = OUTPUT spatial size
+    int Hin, Win;           // physical input size (0 -> same as H, W)
+    int pad;                // logical padding (top/left); -1 -> KS/2
+    int pad_mode;           // PAD_ZERO / PAD_REFLECT
+    int in_mode;            // IN_DIRECT / IN_UP2_NEAREST / IN_UP2_ZEROINS (logical input = 2x physical)
     int Mrows;              // real GEMM rows (Cout; 2*C for EPI_ACE is NOT used: see C)
     int nchunks;            // ceil(Cin / CK)
     int mtiles;             // ceil(rows / (64*WM)) (block tiles along M)
@@ -43,6 +50,7 @@ struct ConvParams {
     const float* bias;      // [Mrows] or null
     const float* res;       // [B][Mrows][H>>res_up][W>>res_up] or null
     int res_up;
+    int res_after_act;      // 0: act(conv + bias + res) ; 1: act(conv + bias) + res
     int act;
     // EPI_ACE
     const float* x;         // [B][C][H>>x_up][W>>x_up]
@@ -66,6 +74,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ACT_LRELU: return v > 0.f ? v : 0.2f * v;
         case ACT_RELU: return v > 0.f ? v : 0.f;
         case ACT_TANH: return tanhf(v);
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
         default: return v;
     }
 }
@@ -78,12 +87,11 @@ __device__ __forceinline__ int xcd_remap(int p, int n) {
     return base + k;
 }
 
-template <int KS, int WM, int TW, int TH, int TB, int CK, int EPI>
+template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
 struct ConvCfg {
     static constexpr int WN = 4 / WM;
-    static constexpr int HALO = KS / 2;
-    static constexpr int PW = TW + 2 * HALO;
-    static constexpr int PH = TH + 2 * HALO;
+    static constexpr int PW = (TW - 1) * STRIDE + KS;
+    static constexpr int PH = (TH - 1) * STRIDE + KS;
     static constexpr int PLANE = TB * PH * PW;
     static constexpr int NPIX = TW * TH * TB;
     static constexpr int KSTEPS = KS * KS * CK / 2;
@@ -95,10 +103,10 @@ struct ConvCfg {
     static_assert(KSTEPS % 4 == 0, "k-steps per chunk must be a multiple of 4");
 };
 
-template <int KS, int WM, int TW, int TH, int TB, int CK, int EPI>
+template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
-    using Cfg = ConvCfg<KS, WM, TW, TH, TB, CK, EPI>;
-    constexpr int WN = Cfg::WN, HALO = Cfg::HALO, PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE;
+    using Cfg = ConvCfg<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
+    constexpr int WN = Cfg::WN, PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE;
     constexpr int NG = Cfg::NGROUPS, NLOAD = Cfg::NLOAD, SE = Cfg::STAGE_ELEMS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     for (int n = 0; n < 4; ++n) {
         const int idx = wn * 128 + n * 32 + (lane & 31);
         const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-        loff[n] = (lane >> 5) * PLANE + tb * (PH * PW) + ty * PW + tx;
+        loff[n] = (lane >> 5) * PLANE + tb * (PH * PW) + ty * STRIDE * PW + tx * STRIDE;
     }
 
     f32x16 acc[2][4];
@@ -132,9 +140,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
     // ---- staging: element e of the chunk patch -> (channel, sample-in-tile, row, col).  Done synchronously at
     // the top of each chunk iteration (registers are transient); the second block on the CU covers the wait.
+    const int Hl = p.in_mode == IN_DIRECT ? p.Hin : 2 * p.Hin;   // logical input size
+    const int Wl = p.in_mode == IN_DIRECT ? p.Win : 2 * p.Win;
+    const int HWin = p.Hin * p.Win;
     auto stage = [&](int chunk, int buf) {
         float stg[NLOAD];
-        const float* src = p.in + ((long long)b0 * p.Cin + (long long)chunk * CK) * HW;
+        const float* src = p.in + ((long long)b0 * p.Cin + (long long)chunk * CK) * HWin;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             int e = tid + i * 256;
@@ -143,10 +154,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             if (e < SE) {
                 const int c = e / PLANE, rem = e % PLANE;
                 const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
-                const int y = y0 + py - HALO, x = x0 + px - HALO;
-                if (b0 + tb < p.B && chunk * CK + c < p.Cin && (unsigned)y < (unsigned)p.H &&
-                    (unsigned)x < (unsigned)p.W)
-                    v = src[(tb * p.Cin + c) * HW + y * p.W + x];
+                int y = y0 * STRIDE - p.pad + py, x = x0 * STRIDE - p.pad + px;
+                if (p.pad_mode == PAD_REFLECT) {
+                    y = y < 0 ? -y : (y >= Hl ? 2 * (Hl - 1) - y : y);
+                    x = x < 0 ? -x : (x >= Wl ? 2 * (Wl - 1) - x : x);
+                }
+                bool ok = b0 + tb < p.B && chunk * CK + c < p.Cin && (unsigned)y < (unsigned)Hl &&
+                          (unsigned)x < (unsigned)Wl;
+                if (p.in_mode != IN_DIRECT) {
+                    if (p.in_mode == IN_UP2_ZEROINS && ((y | x) & 1)) ok = false;
+                    y >>= 1;
+                    x >>= 1;
+                }
+                if (ok) v = src[(tb * p.Cin + c) * HWin + y * p.Win + x];
             }
             stg[i] = v;
         }
@@ -231,8 +251,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                     if (row < p.Mrows) {
                         float v = acc[m][n][r];
                         if (p.bias) v += p.bias[row];
-                        if (p.res) v += p.res[((long long)b * p.Mrows + row) * (rW * rH) + rpix];
-                        v = apply_act(v, p.act);
+                        float rv = 0.f;
+                        if (p.res) rv = p.res[((long long)b * p.Mrows + row) * (rW * rH) + rpix];
+                        v = p.res_after_act ? apply_act(v, p.act) + rv : apply_act(v + rv, p.act);
                         p.out[((long long)b * p.Mrows + row) * HW + pix] = v;
                     }
                 }
@@ -310,10 +331,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 }
 
 // host-side launcher for one instantiation
-template <int KS, int WM, int TW, int TH, int TB, int CK, int EPI>
+template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
 hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
-    using Cfg = ConvCfg<KS, WM, TW, TH, TB, CK, EPI>;
-    auto kern = conv_mfma_kernel<KS, WM, TW, TH, TB, CK, EPI>;
+    using Cfg = ConvCfg<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
+    auto kern = conv_mfma_kernel<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -322,6 +343,8 @@ hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
         attr_set = true;
     }
     p.nchunks = (p.Cin + CK - 1) / CK;
+    if (p.Hin == 0) { p.Hin = p.H; p.Win = p.W; }
+    if (p.pad < 0) p.pad = KS / 2;
     p.mtiles = (rows + 64 * WM - 1) / (64 * WM);
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
@@ -334,11 +357,14 @@ hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
 // chunk sizes used by the packer and the launch table
 constexpr int CK_KS3 = 16;
 constexpr int CK_KS1 = 16;
+constexpr int CK_S2 = 8;     // stride-2 variants (larger input patch per output tile)
+inline int conv_ck(int ks, int stride) { return stride == 2 ? CK_S2 : 16; }
 
 // entry points implemented in conv_inst_*.hip (tile config chosen from W and rows)
 hipError_t conv_plain3(const ConvParams& p, hipStream_t s);          // rows = p.Mrows
 hipError_t conv_plain1(const ConvParams& p, hipStream_t s);          // rows = p.Mrows
 hipError_t conv_ace(const ConvParams& p, hipStream_t s);             // rows = 64-row tiles of 32 ch (gamma|beta)
 hipError_t conv_nhwc1x1(const ConvParams& p, hipStream_t s);         // rows = p.Mrows
+hipError_t conv_plain_s2(const ConvParams& p, int KS, hipStream_t s); // stride 2, KS in {1,3,4}
 
 }  // namespace chk

@@ -11,4 +11,24 @@ hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* 
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                          hipStream_t s);
 hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s);
+// misc_kernels.hip
+hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s);
+hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
+                         int act, hipStream_t s);
+hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B, int F, int h, int w, int S,
+                       hipStream_t s);
+hipError_t maxpool3x3s2(const float* in, float* out, long long planes, int H, int W, hipStream_t s);
+hipError_t global_avg_pool(const float* in, float* out, int planes, int HW, hipStream_t s);
+hipError_t chan_affine(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,
+                       long long planes, int HW, hipStream_t s);
+hipError_t stem7x7(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+hipError_t bilinear_argmax(const float* lg, uint8_t* out, float* logits_out, const uint8_t* remap, int B, int h, int w,
+                           int H, int W, hipStream_t s);
+hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW, hipStream_t s);
+hipError_t shape_inputs(const uint8_t* lab, const float* pos, float* hair_in, float* face_in, int B, int HW,
+                        hipStream_t s);
+hipError_t linear(const float* x, const float* W, const float* bias, const float* scale, const float* shift, float* out,
+                  int B, int K, int O, int ldx, int ldo, int act, hipStream_t s);
+hipError_t subspace_add(float* h, const float* z, int zld, const float* U, const float* L, const float* mu, int B, int D,
+                        int Z, hipStream_t s);
 }  // namespace chk

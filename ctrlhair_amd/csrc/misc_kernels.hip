@@ -1,0 +1,459 @@
+// misc_kernels.hip -- HBM/latency-bound kernels of the Zencoder, shape branch, BiSeNet and colour MLPs:
+// wave64 shuffle reductions for the normalisation statistics, pooling, up-sampling/argmax epilogues, GEMV.
+#include "kernels.h"
+
+namespace chk {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// block (256 threads) sum, result broadcast to all threads; `red` = 4 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float act_fn(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.2f * v;
+        case 2: return v > 0.f ? v : 0.f;
+        case 3: return tanhf(v);
+        case 4: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// nn.InstanceNorm2d(affine=False, eps=1e-5) + activation, in place (architecture.py:158-172).  One block per
+// (b,c) plane, two-pass statistics (mean, then biased variance), third pass writes.
+__global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x, int HW, float eps, int act) {
+    __shared__ float red[4];
+    float* p = x + (long long)blockIdx.x * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    const float mean = block_sum(s, red) / HW;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float d = p[i] - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, red) / HW;
+    const float rstd = 1.f / sqrtf(var + eps);
+    for (int i = threadIdx.x; i < HW; i += 256) p[i] = act_fn((p[i] - mean) * rstd, act);
+}
+hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s) {
+    hipLaunchKernelGGL(instnorm_act_kernel, dim3(planes), dim3(256), 0, s, x, HW, eps, act);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The custom LayerNorm of my_torchlib/module.py:189-205: per-sample mean and *unbiased* std over C*H*W,
+// y = (x-mean)/(std+eps) * gamma[c] + beta[c]; then activation.  Two kernels: (1) per-block partial
+// (count, mean, M2) with a block-local two-pass; (2) every block merges the partials (Chan et al.) and
+// normalises its slice.  part: [B][nblk][3].
+__global__ __launch_bounds__(256) void ln_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                         long long N, int nblk) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, k = blockIdx.x;
+    const long long per = (N + nblk - 1) / nblk, lo = k * per, hi = (lo + per < N) ? lo + per : N;
+    const float* p = x + (long long)b * N;
+    float s = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+    const float cnt = (float)(hi > lo ? hi - lo : 0);
+    const float mean = cnt > 0 ? block_sum(s, red) / cnt : 0.f;
+    float q = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float d = p[i] - mean;
+        q += d * d;
+    }
+    const float m2 = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        float* o = part + ((long long)b * nblk + k) * 3;
+        o[0] = cnt;
+        o[1] = mean;
+        o[2] = m2;
+    }
+}
+__global__ __launch_bounds__(256) void ln_apply_kernel(float* __restrict__ x, const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       long long N, int HW, int nblk, float eps, int act) {
+    const int b = blockIdx.y;
+    // merge partials (every thread redundantly; nblk <= 256)
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        const float* o = part + ((long long)b * nblk + k) * 3;
+        const float nb = o[0], mb = o[1], qb = o[2];
+        if (nb > 0.f) {
+            const float nn = n + nb, d = mb - mean;
+            mean += d * nb / nn;
+            m2 += qb + d * d * n * nb / nn;
+            n = nn;
+        }
+    }
+    const float stdv = sqrtf(m2 / (n - 1.f));
+    const float inv = 1.f / (stdv + eps);
+    float* p = x + (long long)b * N;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i / HW);
+        p[i] = act_fn((p[i] - mean) * inv * gamma[c] + beta[c], act);
+    }
+}
+hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
+                         int act, hipStream_t s) {
+    const long long N = (long long)C * HW;
+    int nblk = (int)((N + 16383) / 16384);
+    if (nblk > 128) nblk = 128;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(ln_partial_kernel, dim3(nblk, B), dim3(256), 0, s, x, part, N, nblk);
+    int gx = (int)((N + 2047) / 2048);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3(gx, B), dim3(256), 0, s, x, part, gamma, beta, N, HW, nblk, eps, act);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Zencoder region average pooling (architecture.py:179-205): codes [B,F,h,w], labels nearest-down-sampled to
+// (h,w) from the full-res label map [B,S,S]; out[b,j,f] = mean of codes[b,f,p] over pixels with label j
+// (0 if the region is absent).  One block per (f, b); 19 register accumulators per thread.
+__global__ __launch_bounds__(256) void region_mean_kernel(const float* __restrict__ codes,
+                                                          const uint8_t* __restrict__ lab, float* __restrict__ out,
+                                                          int F, int h, int w, int S) {
+    __shared__ float red[4];
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int fy = S / h, fx = S / w;
+    const float* p = codes + ((long long)b * F + f) * h * w;
+    const uint8_t* lb = lab + (long long)b * S * S;
+    float acc[19], cnt[19];
+#pragma unroll
+    for (int j = 0; j < 19; ++j) { acc[j] = 0.f; cnt[j] = 0.f; }
+    for (int i = threadIdx.x; i < h * w; i += 256) {
+        const int y = i / w, x = i % w;
+        const int l = lb[(long long)(y * fy) * S + x * fx];
+        const float v = p[i];
+#pragma unroll
+        for (int j = 0; j < 19; ++j)
+            if (l == j) { acc[j] += v; cnt[j] += 1.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 19; ++j) {
+        const float sv = block_sum(acc[j], red);
+        const float cv = block_sum(cnt[j], red);
+        if (threadIdx.x == 0) out[((long long)b * 19 + j) * F + f] = cv > 0.f ? sv / cv : 0.f;
+    }
+}
+hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B, int F, int h, int w, int S,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(region_mean_kernel, dim3(F, B), dim3(256), 0, s, codes, lab, out, F, h, w, S);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// nn.MaxPool2d(3, stride 2, padding 1) (resnet.py:63)
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes, int H,
+                                    int W, int Ho, int Wo) {
+    const long long n = planes * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+        const long long pl = i / ((long long)Wo * Ho);
+        const float* p = in + pl * H * W;
+        float m = -3.4e38f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = 2 * y + dy, xx = 2 * x + dx;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) m = fmaxf(m, p[yy * W + xx]);
+            }
+        out[i] = m;
+    }
+}
+hipError_t maxpool3x3s2(const float* in, float* out, long long planes, int H, int W, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long n = planes * Ho * Wo;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, s, in, out, planes, H, W, Ho, Wo);
+    return hipGetLastError();
+}
+
+// F.avg_pool2d(x, x.size()[2:]) : one wave per plane
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ in, float* __restrict__ out, int planes,
+                                                  int HW) {
+    const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pl >= planes) return;
+    const float* p = in + (long long)pl * HW;
+    float s = 0.f;
+    for (int i = lane; i < HW; i += 64) s += p[i];
+    s = wave_sum(s);
+    if (lane == 0) out[pl] = s / HW;
+}
+hipError_t global_avg_pool(const float* in, float* out, int planes, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(gap_kernel, dim3((planes + 3) / 4), dim3(256), 0, s, in, out, planes, HW);
+    return hipGetLastError();
+}
+
+// out[pl,p] = in[pl,p] * (sc[pl] + sc_add) + (sh ? sh[pl] : 0) + (other ? other[pl,p] : 0)
+__global__ void chan_affine_kernel(const float* __restrict__ in, const float* __restrict__ sc, float sc_add,
+                                   const float* __restrict__ sh, const float* __restrict__ other,
+                                   float* __restrict__ out, long long planes, int HW) {
+    const long long n = planes * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long pl = i / HW;
+        float v = in[i] * (sc[pl] + sc_add);
+        if (sh) v += sh[pl];
+        if (other) v += other[i];
+        out[i] = v;
+    }
+}
+hipError_t chan_affine(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,
+                       long long planes, int HW, hipStream_t s) {
+    const long long n = planes * HW;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(chan_affine_kernel, dim3(grid), dim3(256), 0, s, in, sc, sc_add, sh, other, out, planes, HW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ResNet-18 stem (resnet.py:61,72-73): conv 7x7 s2 p3, 3 -> 64, eval-BN folded into (w, bias), ReLU.
+// Direct VALU conv (K = 147 only): block = 16x16 output pixels; input patch 37x37x3 and all weights in LDS;
+// each thread computes 64 outputs for one pixel in 4 passes of 16 channels.
+__global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                      int W, int Ho, int Wo) {
+    __shared__ float patch[3][37][38];
+    __shared__ float ws[64 * 147];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16, b = blockIdx.z;
+    for (int e = threadIdx.x; e < 64 * 147; e += 256) ws[e] = w[e];
+    for (int e = threadIdx.x; e < 3 * 37 * 37; e += 256) {
+        const int c = e / (37 * 37), r = e % (37 * 37), py = r / 37, px = r % 37;
+        const int y = oy0 * 2 - 3 + py, x = ox0 * 2 - 3 + px;
+        patch[c][py][px] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                               ? in[((long long)b * 3 + c) * H * W + (long long)y * W + x]
+                               : 0.f;
+    }
+    __syncthreads();
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    for (int co0 = 0; co0 < 64; co0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int c = 0; c < 3; ++c)
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const float v = patch[c][ty * 2 + ky][tx * 2 + kx];
+                    const int wi = (c * 7 + ky) * 7 + kx;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[k] += ws[(co0 + k) * 147 + wi] * v;
+                }
+        if (ox < Wo && oy < Ho) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float v = acc[k] + bias[co0 + k];
+                out[(((long long)b * 64 + co0 + k) * Ho + oy) * Wo + ox] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+hipError_t stem7x7(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    hipLaunchKernelGGL(stem7x7_kernel, dim3((Wo + 15) / 16, (Ho + 15) / 16, B), dim3(256), 0, s, in, w, bias, out, H, W,
+                       Ho, Wo);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BiSeNet tail (model.py:250 + my_parsing_util.py:45-54): bilinear align_corners=True up-sampling of the 19
+// logit planes to (H,W), argmax over classes, remap BiSeNet ids -> CelebAMask-HQ ids with a 19-entry LUT.
+// logits_out (optional) receives the up-sampled logits [B,19,H,W] for tests.
+__global__ void bilinear_argmax_kernel(const float* __restrict__ lg, uint8_t* __restrict__ out,
+                                       float* __restrict__ logits_out, const uint8_t* __restrict__ remap, int B, int h,
+                                       int w, int H, int W) {
+    const long long n = (long long)B * H * W;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int b = (int)(i / ((long long)W * H));
+        const float fy = sy * y, fx = sx * x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+        const float ly = fy - y0, lx = fx - x0;
+        float best = -3.4e38f;
+        int bi = 0;
+        for (int c = 0; c < 19; ++c) {
+            const float* p = lg + ((long long)b * 19 + c) * h * w;
+            // same association as ATen's upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+            const float v = (1.f - ly) * ((1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1]) +
+                            ly * ((1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+            if (logits_out) logits_out[(((long long)b * 19 + c) * H + y) * W + x] = v;
+            if (v > best) { best = v; bi = c; }
+        }
+        out[i] = remap ? remap[bi] : (uint8_t)bi;
+    }
+}
+hipError_t bilinear_argmax(const float* lg, uint8_t* out, float* logits_out, const uint8_t* remap, int B, int h, int w,
+                           int H, int W, hipStream_t s) {
+    const long long n = (long long)B * H * W;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bilinear_argmax_kernel, dim3(grid), dim3(256), 0, s, lg, out, logits_out, remap, B, h, w, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shape decoder tail (shape_branch/model.py:184-187 + shape_util.py:17-20): insert the hair logit at class 13,
+// softmax over 19, argmax -> uint8 label.  probs (optional) receives the softmax [B,19,H,W].
+__global__ void shape_softmax_kernel(const float* __restrict__ hair, const float* __restrict__ face,
+                                     uint8_t* __restrict__ lab, float* __restrict__ probs, int B, int HW) {
+    const long long n = (long long)B * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW), p = (int)(i % HW);
+        float v[19];
+#pragma unroll
+        for (int c = 0; c < 19; ++c)
+            v[c] = c == 13 ? hair[(long long)b * HW + p]
+                           : face[((long long)b * 18 + (c < 13 ? c : c - 1)) * HW + p];
+        float m = v[0];
+        int bi = 0;
+#pragma unroll
+        for (int c = 1; c < 19; ++c)
+            if (v[c] > m) { m = v[c]; bi = c; }
+        lab[i] = (uint8_t)bi;
+        if (probs) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 19; ++c) { v[c] = __expf(v[c] - m); s += v[c]; }
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int c = 0; c < 19; ++c) probs[((long long)b * 19 + c) * HW + p] = v[c] * inv;
+        }
+    }
+}
+hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW,
+                         hipStream_t s) {
+    const long long n = (long long)B * HW;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(shape_softmax_kernel, dim3(grid), dim3(256), 0, s, hair, face, lab, probs, B, HW);
+    return hipGetLastError();
+}
+
+// Shape encoder inputs (ui/backend.py:81-83, shape_util.py:6-26, shape_branch/model.py:96-100):
+// label map uint8 [B,HW] (255 = no class) -> hair_in [B,1+40,HW] (one-hot of class 13 + positional channels) and
+// face_in [B,18+40,HW] (one-hot of the other 18 classes + positional channels).  pos: [40][HW].
+__global__ void shape_inputs_kernel(const uint8_t* __restrict__ lab, const float* __restrict__ pos,
+                                    float* __restrict__ hair_in, float* __restrict__ face_in, int B, int HW) {
+    const long long n = (long long)B * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW), p = (int)(i % HW);
+        const int l = lab[i];
+        float* h = hair_in + (long long)b * 41 * HW + p;
+        float* f = face_in + (long long)b * 58 * HW + p;
+        h[0] = l == 13 ? 1.f : 0.f;
+        for (int c = 0; c < 18; ++c) f[(long long)c * HW] = (l == (c < 13 ? c : c + 1)) ? 1.f : 0.f;
+        for (int k = 0; k < 40; ++k) {
+            const float v = pos[(long long)k * HW + p];
+            h[(long long)(1 + k) * HW] = v;
+            f[(long long)(18 + k) * HW] = v;
+        }
+    }
+}
+hipError_t shape_inputs(const uint8_t* lab, const float* pos, float* hair_in, float* face_in, int B, int HW,
+                        hipStream_t s) {
+    const long long n = (long long)B * HW;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(shape_inputs_kernel, dim3(grid), dim3(256), 0, s, lab, pos, hair_in, face_in, B, HW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// nn.Linear as a batched GEMV (weight-bandwidth bound at B <= 16): out[b][o] = act(scale[o]*(bias[o] + W[o,:].x[b,:]) + shift[o])
+// One wave per 2 output rows; lanes stride K (float4 when K % 4 == 0); up to LIN_BT samples per pass.
+// x row stride = ldx (allows reading a slice / concatenation handled by the caller), out row stride = ldo.
+constexpr int LIN_BT = 8;
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ out, int B,
+                                                     int K, int O, int ldx, int ldo, int act) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o0 = (blockIdx.x * 4 + wave) * 2;
+    if (o0 >= O) return;
+    const bool two = o0 + 1 < O;
+    const float* w0 = W + (long long)o0 * K;
+    const float* w1 = W + (long long)(two ? o0 + 1 : o0) * K;
+    for (int bb = 0; bb < B; bb += LIN_BT) {
+        float a0[LIN_BT], a1[LIN_BT];
+#pragma unroll
+        for (int t = 0; t < LIN_BT; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+        if ((K & 3) == 0) {
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4 u0 = *reinterpret_cast<const float4*>(w0 + k);
+                const float4 u1 = *reinterpret_cast<const float4*>(w1 + k);
+#pragma unroll
+                for (int t = 0; t < LIN_BT; ++t)
+                    if (bb + t < B) {
+                        const float4 v = *reinterpret_cast<const float4*>(x + (long long)(bb + t) * ldx + k);
+                        a0[t] += u0.x * v.x + u0.y * v.y + u0.z * v.z + u0.w * v.w;
+                        a1[t] += u1.x * v.x + u1.y * v.y + u1.z * v.z + u1.w * v.w;
+                    }
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) {
+                const float u0 = w0[k], u1 = w1[k];
+#pragma unroll
+                for (int t = 0; t < LIN_BT; ++t)
+                    if (bb + t < B) {
+                        const float v = x[(long long)(bb + t) * ldx + k];
+                        a0[t] += u0 * v;
+                        a1[t] += u1 * v;
+                    }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < LIN_BT; ++t) {
+            a0[t] = wave_sum(a0[t]);
+            a1[t] = wave_sum(a1[t]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < LIN_BT; ++t)
+                if (bb + t < B) {
+                    float v = a0[t] + (bias ? bias[o0] : 0.f);
+                    if (scale) v = v * scale[o0] + shift[o0];
+                    out[(long long)(bb + t) * ldo + o0] = act_fn(v, act);
+                    if (two) {
+                        float u = a1[t] + (bias ? bias[o0 + 1] : 0.f);
+                        if (scale) u = u * scale[o0 + 1] + shift[o0 + 1];
+                        out[(long long)(bb + t) * ldo + o0 + 1] = act_fn(u, act);
+                    }
+                }
+        }
+    }
+}
+hipError_t linear(const float* x, const float* W, const float* bias, const float* scale, const float* shift, float* out,
+                  int B, int K, int O, int ldx, int ldo, int act, hipStream_t s) {
+    hipLaunchKernelGGL(linear_kernel, dim3((O + 7) / 8), dim3(256), 0, s, x, W, bias, scale, shift, out, B, K, O, ldx, ldo,
+                       act);
+    return hipGetLastError();
+}
+
+// EigenGAN subspace injection (model_eigengan.py:27-31,76-81): h[b,:] = lrelu(h[b,:] + U (L * z[b,:]) + mu), z 2-d
+__global__ void subspace_add_kernel(float* __restrict__ h, const float* __restrict__ z, int zld, const float* __restrict__ U,
+                                    const float* __restrict__ L, const float* __restrict__ mu, int B, int D, int Z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i % D;
+    float v = h[i] + mu[d];
+    for (int k = 0; k < Z; ++k) v += U[k * D + d] * L[k] * z[b * zld + k];   // U: [Z][D]
+    h[i] = v > 0.f ? v : 0.2f * v;
+}
+hipError_t subspace_add(float* h, const float* z, int zld, const float* U, const float* L, const float* mu, int B, int D,
+                        int Z, hipStream_t s) {
+    hipLaunchKernelGGL(subspace_add_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, h, z, zld, U, L, mu, B, D, Z);
+    return hipGetLastError();
+}
+
+}  // namespace chk

@@ -1,0 +1,173 @@
+// net_common.h -- shared host-side helpers of the model files: host tensor store, weight upload, MFMA operand
+// packing, a generic conv layer (conv_mfma_kernel launcher wrapper) and small-op launch helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv_mfma.h"
+
+namespace chk {
+
+struct HostTensor {
+    std::vector<char> data;
+    std::vector<int64_t> shape;
+    int dtype = 0;  // 0 f32, 1 i64
+    const float* f32() const { return reinterpret_cast<const float*>(data.data()); }
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        return n;
+    }
+};
+typedef std::map<std::string, HostTensor> TensorStore;
+
+struct Builder {
+    const TensorStore& ts;
+    std::vector<void*>& allocs;
+    std::string err;
+    std::string prefix;   // prepended to every tensor name looked up
+    Builder(const TensorStore& t, std::vector<void*>& a) : ts(t), allocs(a) {}
+
+    bool has(const std::string& n) const { return ts.find(prefix + n) != ts.end(); }
+    const HostTensor* get(const std::string& n0, size_t numel) {
+        const std::string n = prefix + n0;
+        auto it = ts.find(n);
+        if (it == ts.end()) {
+            if (err.empty()) err = "missing tensor '" + n + "'";
+            return nullptr;
+        }
+        if (it->second.dtype != 0 || it->second.numel() != numel) {
+            if (err.empty())
+                err = "tensor '" + n + "' has wrong dtype/size (" + std::to_string(it->second.numel()) + " vs " +
+                      std::to_string(numel) + ")";
+            return nullptr;
+        }
+        return &it->second;
+    }
+    std::vector<float> vec(const std::string& n, size_t numel) {
+        auto t = get(n, numel);
+        return t ? std::vector<float>(t->f32(), t->f32() + numel) : std::vector<float>(numel, 0.f);
+    }
+    float* upload(const std::vector<float>& v) {
+        void* d = nullptr;
+        if (hipMalloc(&d, v.size() * sizeof(float) + 64) != hipSuccess) {
+            if (err.empty()) err = "hipMalloc failed (weights)";
+            return nullptr;
+        }
+        allocs.push_back(d);
+        if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            if (err.empty()) err = "hipMemcpy failed (weights)";
+        return static_cast<float*>(d);
+    }
+    void* dalloc(size_t bytes) {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes + 256) != hipSuccess) {
+            if (err.empty()) err = "hipMalloc failed (workspace, " + std::to_string(bytes >> 20) + " MiB)";
+            return nullptr;
+        }
+        allocs.push_back(d);
+        return d;
+    }
+    float* falloc(size_t floats) { return static_cast<float*>(dalloc(floats * 4)); }
+};
+
+// Pack GEMM rows into the per-lane A-fragment order conv_mfma_kernel streams:
+//   [wave tile (64 rows)][chunk][k-group (4 k-steps)][M-subtile (2)][lane (64)][4 floats]
+//   lane l holds row (l&31) of its M-subtile, channel parity (l>>5); k-step s = tap*(CK/2) + channel pair.
+template <class F>
+std::vector<float> pack_A(int rows, int Cin, int KS, int CK, F get) {
+    int mt64 = (rows + 63) / 64;
+    mt64 = (mt64 + 1) & ~1;   // even number of wave tiles so WM=2 blocks never read past the end
+    const int nch = (Cin + CK - 1) / CK;
+    const int ksteps = KS * KS * CK / 2, ng = ksteps / 4, half = CK / 2;
+    std::vector<float> dst((size_t)mt64 * nch * ng * 2 * 64 * 4, 0.f);
+    size_t o = 0;
+    for (int mt = 0; mt < mt64; ++mt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int g = 0; g < ng; ++g)
+                for (int ms = 0; ms < 2; ++ms)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int q = 0; q < 4; ++q, ++o) {
+                            const int s = g * 4 + q, t = s / half, cp = s % half;
+                            const int row = mt * 64 + ms * 32 + (lane & 31);
+                            const int ci = ch * CK + 2 * cp + (lane >> 5);
+                            if (row < rows && ci < Cin) dst[o] = get(row, ci, t);
+                        }
+    return dst;
+}
+
+// ---- generic conv layer on the MFMA kernel ------------------------------------------------------------------
+struct ConvLayer {
+    float* wpk = nullptr;
+    float* bias = nullptr;
+    int Cout = 0, Cin = 0, KS = 0, stride = 1, pad = 0;
+};
+
+// w: [Cout][Cin][KS][KS] (already folded: BN / spectral norm / flips), bias may be empty
+inline ConvLayer make_conv(Builder& B, const std::vector<float>& w, const std::vector<float>& bias, int cout, int cin,
+                           int ks, int stride, int pad) {
+    ConvLayer L;
+    L.Cout = cout;
+    L.Cin = cin;
+    L.KS = ks;
+    L.stride = stride;
+    L.pad = pad;
+    const int ck = conv_ck(ks, stride);
+    const float* wp = w.data();
+    L.wpk = B.upload(pack_A(cout, cin, ks, ck, [&](int row, int ci, int t) {
+        return wp[((size_t)row * cin + ci) * ks * ks + t];
+    }));
+    if (!bias.empty()) L.bias = B.upload(bias);
+    return L;
+}
+
+struct ConvOpts {
+    int pad_mode = PAD_ZERO;
+    int in_mode = IN_DIRECT;
+    int act = ACT_NONE;
+    const float* res = nullptr;
+    int res_up = 0;
+    int res_after_act = 0;
+};
+
+inline int conv_out_size(const ConvLayer& L, int in, int in_mode) {
+    const int l = in_mode == IN_DIRECT ? in : 2 * in;
+    return (l + 2 * L.pad - L.KS) / L.stride + 1;
+}
+
+// in: [B][Cin][Hin][Win] -> out: [B][Cout][Ho][Wo]
+inline hipError_t run_conv(const ConvLayer& L, const float* in, float* out, int B, int Hin, int Win,
+                           const ConvOpts& o, hipStream_t st) {
+    ConvParams p{};
+    p.in = in;
+    p.wpk = L.wpk;
+    p.out = out;
+    p.B = B;
+    p.Cin = L.Cin;
+    p.Hin = Hin;
+    p.Win = Win;
+    p.H = conv_out_size(L, Hin, o.in_mode);
+    p.W = conv_out_size(L, Win, o.in_mode);
+    p.pad = L.pad;
+    p.pad_mode = o.pad_mode;
+    p.in_mode = o.in_mode;
+    p.Mrows = L.Cout;
+    p.bias = L.bias;
+    p.res = o.res;
+    p.res_up = o.res_up;
+    p.res_after_act = o.res_after_act;
+    p.act = o.act;
+    if (L.stride == 2) return conv_plain_s2(p, L.KS, st);
+    if (L.KS == 3) return conv_plain3(p, st);
+    if (L.KS == 1) return conv_plain1(p, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace chk

@@ -22,71 +22,6 @@ namespace {
 
 constexpr int LABEL_NC = 19, STYLE = 512, HID = 128;
 
-struct Builder {
-    const TensorStore& ts;
-    SeanModel& m;
-    std::string err;
-    Builder(const TensorStore& t, SeanModel& mm) : ts(t), m(mm) {}
-
-    const HostTensor* get(const std::string& n, size_t numel) {
-        auto it = ts.find(n);
-        if (it == ts.end()) {
-            if (err.empty()) err = "missing tensor '" + n + "'";
-            return nullptr;
-        }
-        if (it->second.dtype != 0 || it->second.numel() != numel) {
-            if (err.empty()) err = "tensor '" + n + "' has wrong dtype/size";
-            return nullptr;
-        }
-        return &it->second;
-    }
-    float* upload(const std::vector<float>& v) {
-        void* d = nullptr;
-        if (hipMalloc(&d, v.size() * sizeof(float) + 64) != hipSuccess) {
-            if (err.empty()) err = "hipMalloc failed (weights)";
-            return nullptr;
-        }
-        m.allocs.push_back(d);
-        if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-            if (err.empty()) err = "hipMemcpy failed (weights)";
-        return static_cast<float*>(d);
-    }
-    void* dalloc(size_t bytes) {
-        void* d = nullptr;
-        if (hipMalloc(&d, bytes + 256) != hipSuccess) {
-            if (err.empty()) err = "hipMalloc failed (workspace, " + std::to_string(bytes >> 20) + " MiB)";
-            return nullptr;
-        }
-        m.allocs.push_back(d);
-        return d;
-    }
-};
-
-// Pack GEMM rows into the per-lane A-fragment order conv_mfma_kernel streams:
-//   [wave tile (64 rows)][chunk][k-group (4 k-steps)][M-subtile (2)][lane (64)][4 floats]
-//   lane l holds row (l&31) of its M-subtile, channel parity (l>>5); k-step s = tap*(CK/2) + channel pair.
-template <class F>
-std::vector<float> pack_A(int rows, int Cin, int KS, int CK, F get) {
-    int mt64 = (rows + 63) / 64;
-    mt64 = (mt64 + 1) & ~1;   // even number of wave tiles so WM=2 blocks never read past the end
-    const int nch = (Cin + CK - 1) / CK;
-    const int ksteps = KS * KS * CK / 2, ng = ksteps / 4, half = CK / 2;
-    std::vector<float> dst((size_t)mt64 * nch * ng * 2 * 64 * 4, 0.f);
-    size_t o = 0;
-    for (int mt = 0; mt < mt64; ++mt)
-        for (int ch = 0; ch < nch; ++ch)
-            for (int g = 0; g < ng; ++g)
-                for (int ms = 0; ms < 2; ++ms)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int q = 0; q < 4; ++q, ++o) {
-                            const int s = g * 4 + q, t = s / half, cp = s % half;
-                            const int row = mt * 64 + ms * 32 + (lane & 31);
-                            const int ci = ch * CK + 2 * cp + (lane >> 5);
-                            if (row < rows && ci < Cin) dst[o] = get(row, ci, t);
-                        }
-    return dst;
-}
-
 }  // namespace
 
 size_t SeanModel::noise_floats(int S) const {
@@ -99,7 +34,7 @@ size_t SeanModel::noise_floats(int S) const {
 }
 
 std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
-    Builder B(ts, *this);
+    Builder B(ts, allocs);
     auto itfc = ts.find("fc.weight");
     if (itfc == ts.end() || itfc->second.shape.size() != 4) return "missing tensor 'fc.weight'";
     ngf = (int)itfc->second.shape[0] / 16;
@@ -277,6 +212,29 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         blocks.push_back(bw);
     }
 
+    // ---- Zencoder (optional: only when its tensors were loaded) ----------------------------------------------
+    has_zencoder = false;
+    if (ts.find("Zencoder.model.1.weight") != ts.end()) {
+        auto plain = [&](const std::string& p, int cout, int cin, int stride, ConvLayer& L) {
+            L = make_conv(B, B.vec(p + ".weight", (size_t)cout * cin * 9), B.vec(p + ".bias", cout), cout, cin, 3, stride, 1);
+        };
+        plain("Zencoder.model.1", 32, 3, 1, z1);
+        plain("Zencoder.model.4", 64, 32, 2, z4);
+        plain("Zencoder.model.7", 128, 64, 2, z7);
+        {   // ConvTranspose2d(128,256,k3,s2,p1,op1): weight [in=128][out=256][3][3] -> plain conv over the
+            // zero-inserted input with flipped taps: W'[co][ci][ky][kx] = Wt[ci][co][2-ky][2-kx]
+            auto wt = B.vec("Zencoder.model.10.weight", (size_t)128 * 256 * 9);
+            std::vector<float> w((size_t)256 * 128 * 9);
+            for (int co = 0; co < 256; ++co)
+                for (int ci = 0; ci < 128; ++ci)
+                    for (int t = 0; t < 9; ++t) w[((size_t)co * 128 + ci) * 9 + t] = wt[((size_t)ci * 256 + co) * 9 + (8 - t)];
+            z10 = make_conv(B, w, B.vec("Zencoder.model.10.bias", 256), 256, 128, 3, 1, 1);
+        }
+        plain("Zencoder.model.14", 512, 256, 1, z14);
+        if (!B.err.empty()) return B.err;
+        has_zencoder = true;
+    }
+
     // ---- workspace arena --------------------------------------------------------------------------------
     const size_t MB = mb, S = ms;
     for (int k = 1; k <= 5; ++k) {   // res_div 2^k
@@ -296,6 +254,10 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         outmax = std::max(outmax, px * b.fout);
     }
     outmax = std::max(outmax, (size_t)MB * 16 * ngf * (S / 32) * (S / 32));
+    if (has_zencoder) {   // Zencoder activations live in h0/hs (<= 512 ch at S/2) and dx/h1 (<= 64 ch at S/2)
+        h0max = std::max(h0max, MB * S * S * 128);
+        midmax = std::max(midmax, MB * S * S * 16);
+    }
     lut = static_cast<float*>(B.dalloc(lutmax * 4));
     actv = static_cast<float*>(B.dalloc(MB * S * S * HID * 4));
     h0 = static_cast<float*>(B.dalloc(h0max * 4));
@@ -393,6 +355,7 @@ struct Runner {
             p.W = 32;
             p.Mrows = 18 * a.C;
             p.npix_valid = N;
+            p.pad = -1;
             timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
                   [&] { check(conv_nhwc1x1(p, st), "lut gemm"); });
         }
@@ -419,6 +382,7 @@ struct Runner {
         p.lab = lab;
         p.lut = a.styled ? m.lut : nullptr;
         p.act = act;
+        p.pad = -1;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
               4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(conv_ace(p, st), "spade conv"); });
@@ -438,6 +402,7 @@ struct Runner {
         p.res = res;
         p.res_up = res_up;
         p.act = ACT_NONE;
+        p.pad = -1;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS;
         timed(0, 2.0 * w.Cout * w.Cin * k2 * npix,
               4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * k2), [&] {
@@ -508,6 +473,44 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         }
         R.check(conv_img_tanh(x, img_w, img_b, out + (size_t)bo * 3 * S * S, B, ngf, S, S, st), "conv_img");
         if (!R.err.empty()) return R.err;
+    }
+    return "";
+}
+
+std::string SeanModel::encode(const float* img, const uint8_t* labels, float* codes_out, int Btot, int S,
+                              hipStream_t st) {
+    if (blocks.empty() || !has_zencoder) return "Zencoder weights not loaded/finalized";
+    if (S % 32 != 0 || S < 32 || S > max_size) return "S must be a multiple of 32 and <= max_size";
+    for (int bo = 0; bo < Btot; bo += max_batch) {
+        const int B = std::min(max_batch, Btot - bo);
+        std::string err;
+        auto ck = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e);
+        };
+        const float* x = img + (size_t)bo * 3 * S * S;
+        ConvOpts refl;
+        refl.pad_mode = PAD_REFLECT;
+        ConvOpts zero;
+        ConvOpts zins;
+        zins.in_mode = IN_UP2_ZEROINS;
+        ConvOpts last = refl;
+        last.act = ACT_TANH;
+        const int h2 = S / 2, h4 = S / 4;
+        ck(run_conv(z1, x, hs, B, S, S, refl, st), "zenc conv1");
+        ck(instnorm_act(hs, B * 32, S * S, 1e-5f, ACT_LRELU, st), "zenc in1");
+        ck(run_conv(z4, hs, dx, B, S, S, zero, st), "zenc conv2");
+        ck(instnorm_act(dx, B * 64, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in2");
+        ck(run_conv(z7, dx, h1, B, h2, h2, zero, st), "zenc conv3");
+        ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
+        ck(run_conv(z10, h1, hs, B, h4, h4, zins, st), "zenc convT");
+        ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
+        ck(run_conv(z14, hs, h0, B, h2, h2, last, st), "zenc conv5");
+        ck(region_mean(h0, labels + (size_t)bo * S * S, codes_out + (size_t)bo * LABEL_NC * STYLE, B, STYLE, h2, h2, S, st),
+           "region_mean");
+        auto it = taps.find("zenc.feat");
+        if (it != taps.end() && it->second)
+            ck(hipMemcpyAsync(it->second, h0, (size_t)B * STYLE * h2 * h2 * 4, hipMemcpyDeviceToDevice, st), "tap");
+        if (!err.empty()) return err;
     }
     return "";
 }

@@ -8,20 +8,9 @@
 #include <string>
 #include <vector>
 
-namespace chk {
+#include "net_common.h"
 
-struct HostTensor {
-    std::vector<char> data;
-    std::vector<int64_t> shape;
-    int dtype = 0;  // 0 f32, 1 i64
-    const float* f32() const { return reinterpret_cast<const float*>(data.data()); }
-    size_t numel() const {
-        size_t n = 1;
-        for (auto d : shape) n *= (size_t)d;
-        return n;
-    }
-};
-typedef std::map<std::string, HostTensor> TensorStore;
+namespace chk {
 
 struct ConvW {
     float* wpk = nullptr;
@@ -60,6 +49,8 @@ struct SeanModel {
     std::vector<BlockW> blocks;
     float *fc_table = nullptr, *fc_bias = nullptr;     // fc conv as label LUT [19*9][16ngf]
     float *img_w = nullptr, *img_b = nullptr;          // conv_img raw [3][ngf][3][3]
+    bool has_zencoder = false;
+    ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
     std::vector<void*> allocs;                         // everything to hipFree
     // workspace
     uint8_t* lab_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // res_div 32,16,8,4,2 (index by log2) ; [0] unused
@@ -76,6 +67,8 @@ struct SeanModel {
     std::string build(const TensorStore& ts, int max_batch, int max_size);
     std::string generate(const uint8_t* labels, const float* codes, const float* noise, uint64_t seed, float* out,
                          int B, int S, hipStream_t stream);
+    // Zencoder (style encoder + region average pooling), architecture.py:177-207
+    std::string encode(const float* img, const uint8_t* labels, float* codes_out, int B, int S, hipStream_t stream);
     void destroy();
 };
 

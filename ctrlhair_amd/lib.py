@@ -23,6 +23,7 @@ SYMBOLS = {
     'ch_finalize': (_I, [_VP, _I, _I, _I]),
     'ch_sean_noise_floats': (C.c_size_t, [_VP, _I]),
     'ch_sean_generate': (_I, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _I, _I, _VP]),
+    'ch_sean_encode': (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
     'ch_sean_set_tap': (_I, [_VP, C.c_char_p, _VP]),
     'ch_profile_enable': (_I, [_VP, _I]),
     'ch_profile_read': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
@@ -88,6 +89,10 @@ class Handle:
     def sean_generate(self, labels_ptr, codes_ptr, noise_ptr, seed, out_ptr, B, S, stream_ptr):
         self._check(self.lib.ch_sean_generate(self._h, labels_ptr, codes_ptr, noise_ptr, seed, out_ptr, B, S,
                                               stream_ptr), 'ch_sean_generate')
+
+    def sean_encode(self, img_ptr, labels_ptr, codes_ptr, B, S, stream_ptr):
+        self._check(self.lib.ch_sean_encode(self._h, img_ptr, labels_ptr, codes_ptr, B, S, stream_ptr),
+                    'ch_sean_encode')
 
     def sean_set_tap(self, name: str, ptr):
         self._check(self.lib.ch_sean_set_tap(self._h, name.encode(), ptr), 'ch_sean_set_tap')

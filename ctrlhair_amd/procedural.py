@@ -172,3 +172,20 @@ def noise_planes(B: int, S: int, ngf: int = 64, seed: int = 7, first: int = 0) -
     for b in range(B):
         out[b] = _rng(seed + first + b, 'noise').standard_normal((n,), dtype=np.float32)
     return out
+
+
+def synthetic_images(B: int, S: int, seed: int = 31, first: int = 0) -> np.ndarray:
+    """float32 [B,3,S,S] in (-1,1): smooth colour blobs (bilinear-upsampled 8x8 grid) + fine noise -- a stand-in for
+    portraits (no dataset ships)."""
+    out = np.empty((B, 3, S, S), np.float32)
+    t = (np.arange(S, dtype=np.float32) + 0.5) / S * 7.0
+    i0 = np.clip(np.floor(t).astype(np.int64), 0, 6)
+    f = (t - i0).astype(np.float32)
+    for b in range(B):
+        r = _rng(seed + first + b, 'image')
+        g = r.standard_normal((3, 8, 8), dtype=np.float32)
+        rows = g[:, i0, :] * (1 - f)[None, :, None] + g[:, i0 + 1, :] * f[None, :, None]
+        img = rows[:, :, i0] * (1 - f)[None, None, :] + rows[:, :, i0 + 1] * f[None, None, :]
+        img = img + 0.15 * r.standard_normal((3, S, S), dtype=np.float32)
+        out[b] = np.tanh(img)
+    return out

@@ -23,8 +23,6 @@ class SeanGenerator:
         """sd: reference-keyed state dict (torch tensors or numpy arrays), e.g. torch.load('latest_net_G.pth')
         (util/util.py:202-208) or ctrlhair_amd.procedural.sean_state_dict()."""
         for k, v in sd.items():
-            if k.startswith('Zencoder.'):
-                continue   # style encoder: separate entry point (not part of the generator forward)
             a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             if a.dtype not in (np.float32, np.int64):
                 a = a.astype(np.float32)
@@ -52,4 +50,17 @@ class SeanGenerator:
             out = torch.empty(B, 3, S, S, dtype=torch.float32, device=labels.device)
         stream = torch.cuda.current_stream(labels.device).cuda_stream
         self.handle.sean_generate(labels.data_ptr(), codes.data_ptr(), nptr, seed, out.data_ptr(), B, S, stream)
+        return out
+
+    def encode(self, img: torch.Tensor, labels: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Zencoder: img cuda float32 [B,3,S,S] in [-1,1], labels cuda uint8 [B,S,S] -> codes [B,19,512]
+        (Pix2PixModel.forward(mode='style_code'), pix2pix_model.py:69-72)."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3
+        B, S = img.shape[0], img.shape[-1]
+        assert labels.is_cuda and labels.dtype == torch.uint8 and tuple(labels.shape) == (B, S, S)
+        img, labels = img.contiguous(), labels.contiguous()
+        if out is None:
+            out = torch.empty(B, 19, 512, dtype=torch.float32, device=img.device)
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        self.handle.sean_encode(img.data_ptr(), labels.data_ptr(), out.data_ptr(), B, S, stream)
         return out

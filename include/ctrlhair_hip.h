@@ -74,6 +74,16 @@ size_t ch_sean_noise_floats(const ch_handle* h, int S);
 int  ch_sean_generate(ch_handle* h, const uint8_t* labels, const float* codes, const float* noise, uint64_t seed,
                       float* out, int B, int S, ch_stream_t stream);
 
+/* Replaces Pix2PixModel.forward(data, mode='style_code') -> Zencoder.forward
+ * (pix2pix_model.py:69-72; architecture.py:177-207; callers hair_editor.py:149-157 get_code, :208-231):
+ * conv stack (reflection-padded 3x3, two stride-2 convs, ConvTranspose2d, InstanceNorm + LeakyReLU, tanh) at
+ * S/2 resolution, then per-region average pooling with the label map nearest-down-sampled to S/2.
+ *   img    : device float [B,3,S,S] in [-1,1]        labels : device uint8 [B,S,S]
+ *   codes  : device float [B,19,512] (rows of absent regions are 0)
+ * Requires the Zencoder.* tensors to have been loaded before ch_finalize. */
+int  ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float* codes, int B, int S,
+                    ch_stream_t stream);
+
 /* Test hook: after the next ch_sean_generate calls, the activation produced at stage `name` ("fc", "<block>",
  * "<block>.ace_0" = tensor before leaky_relu, "<block>.conv_0", "<block>.shortcut") is also copied
  * (device-to-device, same stream) to `dev_ptr` (caller-sized: [B,C,r,r] floats).  dev_ptr NULL removes the tap. */

@@ -134,6 +134,35 @@ def resblock(sd, blk, x, seg, codes, noise_iter, weights_cache, stats_out=None, 
     return x_s + dx
 
 
+@torch.no_grad()
+def zencoder_forward(sd: Dict[str, torch.Tensor], img, labels, taps: Optional[dict] = None) -> torch.Tensor:
+    """architecture.py:155-207 (Zencoder.__init__ layer list + forward), fed like
+    Pix2PixModel.forward(mode='style_code') (pix2pix_model.py:69-72).
+    img f32 [B,3,S,S]; labels uint8 [B,S,S] -> codes [B,19,512]."""
+    img, labels = _t(img).float(), _t(labels)
+    p = 'Zencoder.model.'
+    x = F.conv2d(F.pad(img, (1, 1, 1, 1), mode='reflect'), sd[p + '1.weight'], sd[p + '1.bias'])      # :158-159
+    x = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.2)
+    for i in (4, 7):                                                                                  # :161-164
+        x = F.conv2d(x, sd[f'{p}{i}.weight'], sd[f'{p}{i}.bias'], stride=2, padding=1)
+        x = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.2)
+    x = F.conv_transpose2d(x, sd[p + '10.weight'], sd[p + '10.bias'], stride=2, padding=1, output_padding=1)  # :169-172
+    x = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.2)
+    codes = torch.tanh(F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), sd[p + '14.weight'], sd[p + '14.bias']))  # :174
+    if taps is not None:
+        taps['zenc.feat'] = codes
+    seg = F.interpolate(one_hot(labels), size=codes.shape[2:], mode='nearest')                        # :181
+    B, Fd = codes.shape[:2]
+    out = torch.zeros(B, LABEL_NC, Fd)
+    for b in range(B):                                                                                # :195-203
+        for j in range(LABEL_NC):
+            m = seg[b, j].bool()
+            n = int(m.sum())
+            if n > 0:
+                out[b, j] = codes[b].masked_select(m).reshape(Fd, n).mean(1)
+    return out
+
+
 def split_noise(noise: torch.Tensor, S: int, ngf: int) -> List[torch.Tensor]:
     """[B, NF] flat noise (ctrlhair_amd.procedural.noise_planes layout) -> 18 planes [B, W, H]."""
     from ctrlhair_amd.sean import arch

@@ -84,7 +84,24 @@ def case(name, ngf, S, B, ui, wseed=0, lseed=1234, cseed=2024, nseed=7, grid=16,
     print(name, 'std', img.std(), 'bytes', os.path.getsize(path))
 
 
+def zenc_case(name, S, B, labels='blocky', lseed=1234, iseed=31, grid=16):
+    sd = P.sean_state_dict(0, 16)     # Zencoder weights do not depend on ngf
+    lab = P.blocky_labels(B, S, seed=lseed, grid=grid) if labels == 'blocky' else \
+        np.stack([face_like_labels(S, lseed + b) for b in range(B)])
+    img = P.synthetic_images(B, S, seed=iseed)
+    codes = R.run_zencoder(sd, img, lab)
+    path = os.path.join(HERE, f'sean_zenc_{name}.npz')
+    np.savez_compressed(path, labels=lab, codes=codes, meta_S=np.array(S), meta_B=np.array(B), meta_iseed=np.array(iseed))
+    print('zenc', name, 'absent rows', int((np.abs(codes).sum(-1) == 0).sum()), 'bytes', os.path.getsize(path))
+
+
 def main():
+    if 'zenc' in sys.argv[1:] or len(sys.argv) == 1:
+        zenc_case('S64_B2', 64, 2, grid=8)
+        zenc_case('S256_face', 256, 1, labels='face', lseed=41, iseed=42)
+        zenc_case('S512_B1', 512, 1, lseed=51, iseed=52)
+    if len(sys.argv) > 1 and 'gen' not in sys.argv[1:]:
+        return
     case('ngf16_S64_B3', 16, 64, 3, False, grid=8)
     case('ngf16_S64_ui', 16, 64, 1, True, grid=8, lseed=5, cseed=6, nseed=8)
     case('ngf16_S128_face', 16, 128, 2, False, labels='face', codes='median', lseed=11, nseed=12)

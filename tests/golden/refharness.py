@@ -104,3 +104,14 @@ def run_generator(sd_np, labels, codes, noise, ngf, ui_mode=False):
             out = G(seg, torch.zeros(B, 3, S, S))
         assert nf.i == 18
     return out.numpy()
+
+
+def run_zencoder(sd_np, img, labels):
+    """Reference Zencoder (architecture.py:155-207) on CPU; sd_np: full generator state dict."""
+    import torch
+    from oracle import sean_oracle as O
+    G = make_generator(16, img.shape[-1])        # Zencoder is independent of ngf; tiny G keeps construction cheap
+    zsd = {k[len('Zencoder.'):]: torch.from_numpy(v) for k, v in sd_np.items() if k.startswith('Zencoder.')}
+    G.Zencoder.load_state_dict(zsd, strict=True)
+    with torch.no_grad():
+        return G.Zencoder(torch.from_numpy(img), O.one_hot(torch.from_numpy(labels))).numpy()

@@ -47,3 +47,17 @@ class Case:
             i += 1
         mean_err = np.abs(img.astype(np.float64).sum(axis=(2, 3)) - z['sums']).max() / (self.S * self.S)
         return max(d, float(mean_err))
+
+
+ZENC_CASES = ['S64_B2', 'S256_face', 'S512_B1']
+
+
+class ZencCase:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, f'sean_zenc_{name}.npz'))
+        self.S, self.B = int(z['meta_S']), int(z['meta_B'])
+        self.labels, self.codes = z['labels'], z['codes']
+        self.img = P.synthetic_images(self.B, self.S, seed=int(z['meta_iseed']))
+
+    def state_dict(self):
+        return P.sean_state_dict(0, 16)

@@ -1,0 +1,50 @@
+"""GPU parity of the HIP Zencoder (ch_sean_encode) vs oracle and reference-made golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import ZENC_CASES, ZencCase
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+_gen = {}
+
+
+def gen():
+    if 'g' not in _gen:
+        from ctrlhair_amd import procedural as P
+        from ctrlhair_amd.sean.generator import SeanGenerator
+        _gen['g'] = SeanGenerator(0).load_state_dict(P.sean_state_dict(0, 16), max_batch=2, max_size=512)
+    return _gen['g']
+
+
+def test_feature_map_and_codes_vs_oracle(hip_lib):
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    g = gen()
+    B, S = 3, 128     # B > max_batch exercises chunking
+    lab, img = P.blocky_labels(B, S, grid=8, seed=9), P.synthetic_images(B, S, seed=10)
+    taps = {}
+    ref = O.zencoder_forward(O.to_torch(P.sean_state_dict(0, 16)), img, lab, taps=taps).numpy()
+    feat = torch.zeros(2, 512, S // 2, S // 2, device=g.device)
+    g.handle.sean_set_tap('zenc.feat', feat.data_ptr())
+    codes = g.encode(torch.from_numpy(img).to(g.device), torch.from_numpy(lab).to(g.device))
+    torch.cuda.synchronize()
+    g.handle.sean_set_tap('zenc.feat', None)
+    # tap holds the last chunk (sample 2 -> slot 0)
+    assert float((feat[0].cpu() - taps['zenc.feat'][2]).abs().max()) <= TOL
+    assert np.abs(codes.cpu().numpy() - ref).max() <= TOL
+
+
+@pytest.mark.parametrize('name', ZENC_CASES)
+def test_golden(hip_lib, name):
+    c = ZencCase(name)
+    g = gen()
+    codes = g.encode(torch.from_numpy(c.img).to(g.device), torch.from_numpy(c.labels).to(g.device))
+    torch.cuda.synchronize()
+    out = codes.cpu().numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out - c.codes).max() <= TOL
+    # absent regions are exactly zero rows (architecture.py:199)
+    absent = np.abs(c.codes).sum(-1) == 0
+    assert (out[absent] == 0).all()

@@ -35,3 +35,14 @@ def test_noise_matters():
         off += r * r
     t = O.generator_forward(sd, c.labels, c.codes, nz, c.ngf).numpy()
     assert np.abs(a - t).max() > 5e-2
+
+
+from tests.golden_util import ZENC_CASES, ZencCase  # noqa: E402
+
+
+@pytest.mark.parametrize('name', ZENC_CASES)
+def test_zencoder_oracle_matches_reference_golden(name):
+    import numpy as np
+    c = ZencCase(name)
+    codes = O.zencoder_forward(O.to_torch(c.state_dict()), c.img, c.labels).numpy()
+    assert np.abs(codes - c.codes).max() <= 1e-5
