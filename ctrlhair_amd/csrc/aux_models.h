@@ -1,0 +1,80 @@
+// aux_models.h -- the three smaller networks either side of the SEAN generator on the CtrlHair path:
+// colour/texture MLPs (A14-A15), shape VAE encoder/decoder (A11-A13), BiSeNet face parser (A16-A17).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "net_common.h"
+
+namespace chk {
+
+// ---- colour / texture branch (color_texture_branch/model_eigengan.py, model.py:86-130, predictor_model.py) ----
+struct ColorModel {
+    bool ready = false;
+    int max_batch = 0;
+    std::vector<void*> allocs;
+    float *g_in_w = nullptr, *g_in_b = nullptr;
+    float *g_mid_w[4] = {}, *g_mid_b[4] = {};
+    float *sub_U[4] = {}, *sub_L[4] = {}, *sub_mu[4] = {};
+    float *d_w[5] = {}, *d_b[5] = {};
+    float *p_w[4] = {}, *p_b[4] = {}, *p_scale[3] = {}, *p_shift[3] = {};
+    float *wa = nullptr, *wb = nullptr;   // [max_batch][512] scratch
+    std::string build(const TensorStore& ts, int max_batch);
+    std::string generate(const float* noise, const float* cond, float* code, int B, hipStream_t st);
+    std::string encode(const float* code, float* out11, int B, hipStream_t st);
+    std::string predict(const float* code, float* out4, int B, hipStream_t st);
+    void destroy();
+};
+
+// ---- shape branch (shape_branch/model.py, my_torchlib/module.py) ----------------------------------------------
+struct LnW { float *gamma = nullptr, *beta = nullptr; };
+struct ShapeModel {
+    bool ready = false;
+    int max_batch = 0;
+    static constexpr int S = 256, HAIR_DIM = 16, FACE_DIM = 1024;
+    std::vector<void*> allocs;
+    ConvLayer enc[2][7];      // [0]=hair, [1]=face
+    LnW enc_ln[2][7];
+    float *enc_fc_w[2] = {}, *enc_fc_b[2] = {};
+    float *dec_in_w[2] = {}, *dec_in_b[2] = {};
+    ConvLayer dec[2][7], dec_out[2];
+    LnW dec_ln[2][7];
+    float* pos = nullptr;      // [40][S*S]
+    float *in_hair = nullptr, *in_face = nullptr, *bufa = nullptr, *bufb = nullptr, *bufc = nullptr, *lnpart = nullptr,
+          *codecat = nullptr;
+    std::string build(const TensorStore& ts, int max_batch);
+    std::string encode(const uint8_t* labels, float* hair_code, float* face_code, int B, hipStream_t st);
+    // decode: any of hair_logit/face_logit/labels/probs may be null; hair_code may be null when only the face is wanted
+    std::string decode(const float* hair_code, const float* face_code, float* hair_logit, float* face_logit,
+                       uint8_t* labels, float* probs, int B, hipStream_t st);
+    std::string combine(const float* hair_logit, const float* face_logit, uint8_t* labels, float* probs, int B,
+                        hipStream_t st);
+    void destroy();
+  private:
+    std::string run_encoder(int which, const float* in, float* code, int B, hipStream_t st);
+    std::string run_decoder(int which, const float* code, int code_dim, float* logit, int B, hipStream_t st);
+};
+
+// ---- BiSeNet (external_code/face_parsing/model.py, resnet.py, my_parsing_util.py) ------------------------------
+struct BasicBlockW { ConvLayer c1, c2, down; bool has_down = false; };
+struct BiSeNetModel {
+    bool ready = false;
+    int max_batch = 0, max_size = 0;
+    std::vector<void*> allocs;
+    float *stem_w = nullptr, *stem_b = nullptr;
+    BasicBlockW blk[8];
+    ConvLayer arm16_conv, arm32_conv, head32, head16, ffm_a, ffm_b, out_conv, out_cls;
+    // 1x1 convs on pooled vectors as GEMV (+ folded BN)
+    float *avg_w = nullptr, *avg_scale = nullptr, *avg_shift = nullptr;
+    float *att16_w = nullptr, *att16_scale = nullptr, *att16_shift = nullptr;
+    float *att32_w = nullptr, *att32_scale = nullptr, *att32_shift = nullptr;
+    float *ffm1_w = nullptr, *ffm2_w = nullptr;
+    uint8_t* remap = nullptr;
+    float *b0 = nullptr, *b1 = nullptr, *b2 = nullptr, *f8 = nullptr, *f16 = nullptr, *f32 = nullptr, *vec0 = nullptr,
+          *vec1 = nullptr, *vec2 = nullptr;
+    std::string build(const TensorStore& ts, int max_batch, int max_size);
+    std::string parse(const float* img, uint8_t* labels, float* logits, int B, int H, int W, hipStream_t st);
+    void destroy();
+};
+
+}  // namespace chk

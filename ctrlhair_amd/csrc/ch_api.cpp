@@ -7,14 +7,18 @@
 #include <new>
 #include <string>
 
+#include "aux_models.h"
 #include "sean_model.h"
 
 struct ch_handle {
     int device = 0;
     std::string err;
-    chk::TensorStore tensors[1];
+    chk::TensorStore tensors[4];
     chk::SeanModel sean;
     bool sean_ready = false;
+    chk::ShapeModel shape;
+    chk::ColorModel color;
+    chk::BiSeNetModel bisenet;
 };
 
 namespace {
@@ -54,6 +58,9 @@ void ch_destroy(ch_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->sean.destroy();
+    h->shape.destroy();
+    h->color.destroy();
+    h->bisenet.destroy();
     delete h;
 }
 
@@ -62,7 +69,7 @@ const char* ch_last_error(const ch_handle* h) { return h ? h->err.c_str() : "nul
 int ch_load_tensor(ch_handle* h, int model, const char* name, const void* host, int dtype, const int64_t* shape,
                    int ndim) {
     if (!h || !name || !host || ndim < 0 || ndim > 8 || (ndim > 0 && !shape)) return fail(h, CH_ERR_ARG, "bad argument");
-    if (model != CH_MODEL_SEAN) return fail(h, CH_ERR_ARG, "unknown model id");
+    if (model < 0 || model > CH_MODEL_BISENET) return fail(h, CH_ERR_ARG, "unknown model id");
     if (dtype != CH_F32 && dtype != CH_I64) return fail(h, CH_ERR_ARG, "unsupported dtype");
     try {
         chk::HostTensor t;
@@ -84,8 +91,21 @@ int ch_load_tensor(ch_handle* h, int model, const char* name, const void* host, 
 
 int ch_finalize(ch_handle* h, int model, int max_batch, int max_size) {
     if (!h) return CH_ERR_ARG;
-    if (model != CH_MODEL_SEAN) return fail(h, CH_ERR_ARG, "unknown model id");
+    if (model < 0 || model > CH_MODEL_BISENET) return fail(h, CH_ERR_ARG, "unknown model id");
     if (hipSetDevice(h->device) != hipSuccess) return fail(h, CH_ERR_HIP, "hipSetDevice failed");
+    if (model != CH_MODEL_SEAN) {
+        try {
+            std::string e;
+            if (model == CH_MODEL_SHAPE) { h->shape.destroy(); e = h->shape.build(h->tensors[model], max_batch); if (!e.empty()) h->shape.destroy(); }
+            if (model == CH_MODEL_COLOR) { h->color.destroy(); e = h->color.build(h->tensors[model], max_batch); if (!e.empty()) h->color.destroy(); }
+            if (model == CH_MODEL_BISENET) { h->bisenet.destroy(); e = h->bisenet.build(h->tensors[model], max_batch, max_size); if (!e.empty()) h->bisenet.destroy(); }
+            if (!e.empty()) return fail(h, CH_ERR_WEIGHTS, "ch_finalize: " + e);
+            h->tensors[model].clear();
+        } catch (const std::exception& e) {
+            return fail(h, CH_ERR_WEIGHTS, std::string("ch_finalize: ") + e.what());
+        }
+        return CH_OK;
+    }
     try {
         h->sean.destroy();
         h->sean_ready = false;
@@ -133,6 +153,51 @@ int ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float*
         return fail(h, CH_ERR_HIP, std::string("ch_sean_encode: ") + e.what());
     }
     return CH_OK;
+}
+
+#define CH_CALL(name, expr)                                                             \
+    if (!h) return CH_ERR_ARG;                                                          \
+    try {                                                                               \
+        std::string e = (expr);                                                         \
+        if (!e.empty()) return fail(h, e.find("not finalized") != std::string::npos ? CH_ERR_STATE : CH_ERR_HIP, \
+                                    std::string(name) + ": " + e);                      \
+    } catch (const std::exception& ex) {                                                \
+        return fail(h, CH_ERR_HIP, std::string(name) + ": " + ex.what());               \
+    }                                                                                   \
+    return CH_OK;
+
+int ch_color_generate(ch_handle* h, const float* noise, const float* cond, float* code, int B, ch_stream_t stream) {
+    if (h && (!noise || !cond || !code || B < 1)) return fail(h, CH_ERR_ARG, "ch_color_generate: bad argument");
+    CH_CALL("ch_color_generate", h->color.generate(noise, cond, code, B, static_cast<hipStream_t>(stream)))
+}
+int ch_color_encode(ch_handle* h, const float* code, float* out11, int B, ch_stream_t stream) {
+    if (h && (!code || !out11 || B < 1)) return fail(h, CH_ERR_ARG, "ch_color_encode: bad argument");
+    CH_CALL("ch_color_encode", h->color.encode(code, out11, B, static_cast<hipStream_t>(stream)))
+}
+int ch_color_predict(ch_handle* h, const float* code, float* out4, int B, ch_stream_t stream) {
+    if (h && (!code || !out4 || B < 1)) return fail(h, CH_ERR_ARG, "ch_color_predict: bad argument");
+    CH_CALL("ch_color_predict", h->color.predict(code, out4, B, static_cast<hipStream_t>(stream)))
+}
+int ch_shape_encode(ch_handle* h, const uint8_t* labels, float* hair_code, float* face_code, int B, ch_stream_t stream) {
+    if (h && (!labels || (!hair_code && !face_code) || B < 1)) return fail(h, CH_ERR_ARG, "ch_shape_encode: bad argument");
+    CH_CALL("ch_shape_encode", h->shape.encode(labels, hair_code, face_code, B, static_cast<hipStream_t>(stream)))
+}
+int ch_shape_decode(ch_handle* h, const float* hair_code, const float* face_code, float* hair_logit, float* face_logit,
+                    uint8_t* labels, float* probs, int B, ch_stream_t stream) {
+    if (h && (!face_code || B < 1 || ((labels || probs || hair_logit) && !hair_code)))
+        return fail(h, CH_ERR_ARG, "ch_shape_decode: bad argument");
+    CH_CALL("ch_shape_decode", h->shape.decode(hair_code, face_code, hair_logit, face_logit, labels, probs, B,
+                                               static_cast<hipStream_t>(stream)))
+}
+int ch_shape_combine(ch_handle* h, const float* hair_logit, const float* face_logit, uint8_t* labels, float* probs, int B,
+                     ch_stream_t stream) {
+    if (h && (!hair_logit || !face_logit || !labels || B < 1)) return fail(h, CH_ERR_ARG, "ch_shape_combine: bad argument");
+    CH_CALL("ch_shape_combine", h->shape.combine(hair_logit, face_logit, labels, probs, B, static_cast<hipStream_t>(stream)))
+}
+int ch_bisenet_parse(ch_handle* h, const float* img, uint8_t* labels, float* logits, int B, int H, int W,
+                     ch_stream_t stream) {
+    if (h && (!img || !labels || B < 1)) return fail(h, CH_ERR_ARG, "ch_bisenet_parse: bad argument");
+    CH_CALL("ch_bisenet_parse", h->bisenet.parse(img, labels, logits, B, H, W, static_cast<hipStream_t>(stream)))
 }
 
 int ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr) {

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libctrlhair_hip.so')
 
-MODEL_SEAN = 0
+MODEL_SEAN, MODEL_SHAPE, MODEL_COLOR, MODEL_BISENET = 0, 1, 2, 3
 F32, I64 = 0, 1
 
 # every symbol include/ctrlhair_hip.h declares: name -> (restype, argtypes)
@@ -24,6 +24,13 @@ SYMBOLS = {
     'ch_sean_noise_floats': (C.c_size_t, [_VP, _I]),
     'ch_sean_generate': (_I, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _I, _I, _VP]),
     'ch_sean_encode': (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
+    'ch_color_generate': (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
+    'ch_color_encode': (_I, [_VP, _VP, _VP, _I, _VP]),
+    'ch_color_predict': (_I, [_VP, _VP, _VP, _I, _VP]),
+    'ch_shape_encode': (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
+    'ch_shape_decode': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    'ch_shape_combine': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    'ch_bisenet_parse': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     'ch_sean_set_tap': (_I, [_VP, C.c_char_p, _VP]),
     'ch_profile_enable': (_I, [_VP, _I]),
     'ch_profile_read': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
@@ -93,6 +100,10 @@ class Handle:
     def sean_encode(self, img_ptr, labels_ptr, codes_ptr, B, S, stream_ptr):
         self._check(self.lib.ch_sean_encode(self._h, img_ptr, labels_ptr, codes_ptr, B, S, stream_ptr),
                     'ch_sean_encode')
+
+    def call(self, fn: str, *args):
+        """Generic checked call of a ch_* entry point taking (handle, *args)."""
+        self._check(getattr(self.lib, fn)(self._h, *args), fn)
 
     def sean_set_tap(self, name: str, ptr):
         self._check(self.lib.ch_sean_set_tap(self._h, name.encode(), ptr), 'ch_sean_set_tap')

@@ -189,3 +189,128 @@ def synthetic_images(B: int, S: int, seed: int = 31, first: int = 0) -> np.ndarr
         img = img + 0.15 * r.standard_normal((3, S, S), dtype=np.float32)
         out[b] = np.tanh(img)
     return out
+
+
+# ---- procedural weights of the other networks on the path (same key names / shapes as the reference modules) ----
+
+def _bn(sd, seed, p, C):
+    sd[p + '.weight'] = (0.5 + _rng(seed, p + '.weight').random(C, dtype=np.float32)).astype(np.float32)
+    sd[p + '.bias'] = _normal(seed, p + '.bias', (C,), 0.1)
+    sd[p + '.running_mean'] = _normal(seed, p + '.running_mean', (C,), 0.1)
+    sd[p + '.running_var'] = (0.5 + _rng(seed, p + '.running_var').random(C, dtype=np.float32)).astype(np.float32)
+    sd[p + '.num_batches_tracked'] = np.zeros((), np.int64)
+
+
+def shape_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
+    """shape_branch/model.py Generator(cfg 054): hair/face MaskEncoder (7 x conv4x4 s2 + custom LayerNorm) and
+    MaskDecoder (Linear -> 7 x [up, conv3x3, LayerNorm] -> conv3x3).  241.0 M parameters."""
+    sd: Dict[str, np.ndarray] = {}
+
+    def he(name, shape):   # fan-in scaled normal: LayerNorm follows every conv, so only the ratio to the bias matters
+        fan_in = int(np.prod(shape[1:]))
+        sd[name] = _normal(seed, name, shape, np.sqrt(2.0 / fan_in))
+
+    for side, cin0, odim in (('hair', 41, 16), ('face', 58, 1024)):
+        cin = cin0
+        for l in range(7):
+            cout = min(2048, 32 << l)
+            p = f'{side}_encoder.layers.{l}'
+            he(p + '.conv.weight', (cout, cin, 4, 4))
+            sd[p + '.conv.bias'] = _normal(seed, p + '.conv.bias', (cout,), 0.05)
+            sd[p + '.norm.gamma'] = (0.25 + 0.75 * _rng(seed, p + '.norm.gamma').random(cout, dtype=np.float32)).astype(np.float32)
+            sd[p + '.norm.beta'] = _normal(seed, p + '.norm.beta', (cout,), 0.1)
+            cin = cout
+        heads = ['out_layer'] + (['std_out_layer'] if side == 'hair' else [])
+        for hd in heads:
+            sd[f'{side}_encoder.{hd}.fc.weight'] = _normal(seed, f'{side}_encoder.{hd}.fc.weight', (odim, 8192), 1.0 / 64)
+            sd[f'{side}_encoder.{hd}.fc.bias'] = _normal(seed, f'{side}_encoder.{hd}.fc.bias', (odim,), 0.05)
+    for side, idim, oc in (('hair', 1040, 1), ('face', 1024, 18)):
+        d = f'{side}_decoder'
+        sd[d + '.in_layer.fc.weight'] = _normal(seed, d + '.in_layer.fc.weight', (8192, idim), 1.0 / 32)
+        sd[d + '.in_layer.fc.bias'] = _normal(seed, d + '.in_layer.fc.bias', (8192,), 0.1)
+        ci = 2048
+        for l in range(7):
+            co = min(32 << (6 - l), 2048)
+            p = f'{d}.layers.{2 * l + 1}'
+            he(p + '.conv.weight', (co, ci, 3, 3))
+            sd[p + '.conv.bias'] = _normal(seed, p + '.conv.bias', (co,), 0.05)
+            sd[p + '.norm.gamma'] = (0.25 + 0.75 * _rng(seed, p + '.norm.gamma').random(co, dtype=np.float32)).astype(np.float32)
+            sd[p + '.norm.beta'] = _normal(seed, p + '.norm.beta', (co,), 0.1)
+            ci = co
+        sd[d + '.out_layer.conv.weight'] = _normal(seed, d + '.out_layer.conv.weight', (oc, 32, 3, 3), 0.25)
+        sd[d + '.out_layer.conv.bias'] = _normal(seed, d + '.out_layer.conv.bias', (oc,), 0.5)
+    return sd
+
+
+def color_state_dicts(seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:
+    """color_texture_branch cfg 045: {'gen': EigenGenerator, 'dis': Discriminator (encoder), 'rgb': Predictor p004}."""
+    gen: Dict[str, np.ndarray] = {}
+    gen['main_layer_in.weight'] = _normal(seed, 'ct.gen.in.w', (256, 5), 0.01)     # inputs are 0..255 colours / pca_std ~ 20..120
+    gen['main_layer_in.bias'] = _normal(seed, 'ct.gen.in.b', (256,), 0.1)
+    for k in range(4):
+        o = 512 if k == 3 else 256
+        gen[f'main_layer_mid.{k}.1.weight'] = _xavier(seed, f'ct.gen.mid{k}.w', (o, 256))
+        gen[f'main_layer_mid.{k}.1.bias'] = _normal(seed, f'ct.gen.mid{k}.b', (o,), 0.05)
+        q, _ = np.linalg.qr(_rng(seed, f'ct.gen.U{k}').standard_normal((256, 2)))
+        gen[f'subspaces.{k}.U'] = np.ascontiguousarray(q.T).astype(np.float32)     # orthonormal rows (model_eigengan.py:18)
+        gen[f'subspaces.{k}.L'] = np.array([6.0, 3.0], np.float32) * np.float32(0.2 + 0.1 * k)
+        gen[f'subspaces.{k}.mu'] = _normal(seed, f'ct.gen.mu{k}', (256,), 0.05)
+    dis: Dict[str, np.ndarray] = {}
+    for k in range(5):
+        i, o = (512 if k == 0 else 256), (11 if k == 4 else 256)
+        dis[f'net.{k}.fc.weight'] = _xavier(seed, f'ct.dis{k}.w', (o, i))
+        dis[f'net.{k}.fc.bias'] = _normal(seed, f'ct.dis{k}.b', (o,), 0.05)
+    rgb: Dict[str, np.ndarray] = {}
+    for k in range(4):
+        i, o = (512 if k == 0 else 256), (4 if k == 3 else 256)
+        rgb[f'net.{k}.fc.weight'] = _xavier(seed, f'ct.rgb{k}.w', (o, i))
+        rgb[f'net.{k}.fc.bias'] = _normal(seed, f'ct.rgb{k}.b', (o,), 0.05)
+        if k < 3:
+            _bn(rgb, seed + 17, f'net.{k}.norm', 256)
+    # make the predictor emit plausible colours: rgb ~ 128 +- 60, pca_std ~ 60 +- 20
+    rgb['net.3.fc.weight'] = (rgb['net.3.fc.weight'] * np.array([[60.0], [60.0], [60.0], [25.0]], np.float32)).astype(np.float32)
+    rgb['net.3.fc.bias'] = np.array([128.0, 110.0, 90.0, 60.0], np.float32)
+    return {'gen': gen, 'dis': dis, 'rgb': rgb}
+
+
+def bisenet_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
+    """external_code/face_parsing/model.py BiSeNet(19) (+ resnet.py Resnet18): 13.3 M parameters, convs without bias,
+    BatchNorm with random affine/running statistics so that BN folding is exercised."""
+    sd: Dict[str, np.ndarray] = {}
+
+    def conv(name, cout, cin, k, gain=2.0):
+        sd[name + '.weight'] = _normal(seed, 'bise.' + name, (cout, cin, k, k), np.sqrt(gain / (cin * k * k)))
+
+    conv('cp.resnet.conv1', 64, 3, 7)
+    _bn(sd, seed, 'cp.resnet.bn1', 64)
+    chans = [64, 64, 128, 256, 512]
+    for L in range(1, 5):
+        for i in range(2):
+            cin, cout = (chans[L - 1] if i == 0 else chans[L]), chans[L]
+            p = f'cp.resnet.layer{L}.{i}'
+            conv(p + '.conv1', cout, cin, 3)
+            _bn(sd, seed, p + '.bn1', cout)
+            conv(p + '.conv2', cout, cout, 3, gain=1.0)
+            _bn(sd, seed, p + '.bn2', cout)
+            if i == 0 and L > 1:
+                conv(p + '.downsample.0', cout, cin, 1, gain=1.0)
+                _bn(sd, seed, p + '.downsample.1', cout)
+    for arm, cin in (('cp.arm16', 256), ('cp.arm32', 512)):
+        conv(arm + '.conv.conv', 128, cin, 3)
+        _bn(sd, seed, arm + '.conv.bn', 128)
+        conv(arm + '.conv_atten', 128, 128, 1)
+        _bn(sd, seed, arm + '.bn_atten', 128)
+    for hd in ('cp.conv_head32', 'cp.conv_head16'):
+        conv(hd + '.conv', 128, 128, 3)
+        _bn(sd, seed, hd + '.bn', 128)
+    conv('cp.conv_avg.conv', 128, 512, 1)
+    _bn(sd, seed, 'cp.conv_avg.bn', 128)
+    conv('ffm.convblk.conv', 256, 256, 1)
+    _bn(sd, seed, 'ffm.convblk.bn', 256)
+    conv('ffm.conv1', 64, 256, 1)
+    conv('ffm.conv2', 256, 64, 1)
+    for out, cin, mid in (('conv_out', 256, 256), ('conv_out16', 128, 64), ('conv_out32', 128, 64)):
+        conv(out + '.conv.conv', mid, cin, 3)
+        _bn(sd, seed, out + '.conv.bn', mid)
+        conv(out + '.conv_out', 19, mid, 1, gain=0.05)
+    return sd

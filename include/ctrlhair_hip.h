@@ -30,7 +30,10 @@ enum ch_status { CH_OK = 0, CH_ERR_ARG = 1, CH_ERR_HIP = 2, CH_ERR_STATE = 3, CH
 
 /* which network a tensor belongs to (one handle can hold all of them) */
 enum ch_model {
-    CH_MODEL_SEAN = 0          /* sean_codes/models/networks/generator.py: SPADEGenerator (+Zencoder) */
+    CH_MODEL_SEAN = 0,         /* sean_codes/models/networks/generator.py: SPADEGenerator (+Zencoder) */
+    CH_MODEL_SHAPE = 1,        /* shape_branch/model.py: Generator (hair/face MaskEncoder + MaskDecoder), cfg 054 */
+    CH_MODEL_COLOR = 2,        /* color_texture_branch: EigenGenerator "gen.*", Discriminator "dis.*", rgb Predictor "rgb.*" */
+    CH_MODEL_BISENET = 3       /* external_code/face_parsing/model.py: BiSeNet(19) */
 };
 
 enum ch_dtype { CH_F32 = 0, CH_I64 = 1 };
@@ -54,7 +57,8 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  * architecture.py:42-46), eval-BN running stats -> per-channel affine (sync_batchnorm/batchnorm.py:52-55),
  * sigmoid(blending) folded into the SPADE / style weights (normalization.py:177-181), one-hot convs -> label
  * LUTs, MFMA operand layouts.  Sizes the workspace arena for images up to max_size x max_size in chunks of
- * max_batch.  ngf is inferred from the tensors.  Synchronises the device. */
+ * max_batch.  ngf is inferred from the tensors.  For CH_MODEL_SHAPE / CH_MODEL_COLOR max_size is ignored.
+ * Synchronises the device. */
 int  ch_finalize(ch_handle* h, int model, int max_batch, int max_size);
 
 /* Floats of noise per sample at image side S: sum over the 18 ACE layers (execution order: ace_s, ace_0, ace_1
@@ -83,6 +87,43 @@ int  ch_sean_generate(ch_handle* h, const uint8_t* labels, const float* codes, c
  * Requires the Zencoder.* tensors to have been loaded before ch_finalize. */
 int  ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float* codes, int B, int S,
                     ch_stream_t stream);
+
+/* ---- colour / texture branch (three MLPs on 512-d hair style codes) -------------------------------------------
+ * Tensor names: the reference state-dict keys prefixed "gen." (EigenGenerator, model_eigengan.py:34-84), "dis."
+ * (Discriminator used as encoder, model.py:86-130) and "rgb." (Predictor p004, predictor_model.py:14-41).
+ * ch_color_generate replaces feature_generator(data)['code'] (ui/backend.py:166-169, solver.py:78-83):
+ *   noise [B,8], cond [B,5] = cat(noise_curliness[1], rgb_mean[3], pca_std[1]) (model_eigengan.py:66-74) -> code [B,512]
+ * ch_color_encode replaces feature_encoder({'code'}) (ui/backend.py:103-105): raw net output [B,11]; columns
+ *   0 = adv, 1..8 = noise, 9 = noise_curliness, 10 unused (model.py:112-127 slices them on the host).
+ * ch_color_predict replaces feature_rgb_predictor({'code'}) (ui/backend.py:96): [B,4] = rgb_mean[3], pca_std[1]. */
+int  ch_color_generate(ch_handle* h, const float* noise, const float* cond, float* code, int B, ch_stream_t stream);
+int  ch_color_encode(ch_handle* h, const float* code, float* out11, int B, ch_stream_t stream);
+int  ch_color_predict(ch_handle* h, const float* code, float* out4, int B, ch_stream_t stream);
+
+/* ---- shape branch (256x256 only: the Linear sizes fix it, shape_branch/model.py:85-89,120-122) ---------------
+ * ch_shape_encode replaces mask_label_to_one_hot + split_hair_face + forward_hair_encoder(testing=True) +
+ *   forward_face_encoder (ui/backend.py:81-86; shape_util.py:6-26; model.py:96-108,164-173):
+ *   labels uint8 [B,256,256] (255 = no class) -> hair_code [B,16] (VAE mean), face_code [B,1024]; either output
+ *   may be NULL to skip that encoder.
+ * ch_shape_decode replaces forward_decode_by_code / forward_hair_decoder / forward_face_decoder / forward_decoder
+ *   + mask_one_hot_to_label (model.py:175-199; shape_util.py:17-20; ui/backend.py:87-90,304-315):
+ *   any of hair_logit [B,1,256,256], face_logit [B,18,256,256], labels uint8 [B,256,256], probs [B,19,256,256]
+ *   may be NULL; hair_code NULL = face decoder only (ui/backend.py:420).
+ * ch_shape_combine replaces Generator.forward_decoder on caller-made logits (ui/backend.py:421-424). */
+int  ch_shape_encode(ch_handle* h, const uint8_t* labels, float* hair_code, float* face_code, int B, ch_stream_t stream);
+int  ch_shape_decode(ch_handle* h, const float* hair_code, const float* face_code, float* hair_logit, float* face_logit,
+                     uint8_t* labels, float* probs, int B, ch_stream_t stream);
+int  ch_shape_combine(ch_handle* h, const float* hair_logit, const float* face_logit, uint8_t* labels, float* probs,
+                      int B, ch_stream_t stream);
+
+/* ---- BiSeNet face parser ---------------------------------------------------------------------------------------
+ * Replaces FaceParsing.parsing_img's network part + swap_parsing_label_to_celeba_mask
+ * (my_parsing_util.py:37-54; model.py:241-254 output [0] only; resnet.py:71-80):
+ *   img float [B,3,H,W], already ImageNet-normalised (my_parsing_util.py:25-28); H, W multiples of 32
+ *   labels uint8 [B,H,W] in CelebAMask-HQ ids;  logits (optional) float [B,19,H,W] = bilinear(align_corners) logits
+ * The reference runs this network on CPU (the .cuda() calls are commented out, :37,41). */
+int  ch_bisenet_parse(ch_handle* h, const float* img, uint8_t* labels, float* logits, int B, int H, int W,
+                      ch_stream_t stream);
 
 /* Test hook: after the next ch_sean_generate calls, the activation produced at stage `name` ("fc", "<block>",
  * "<block>.ace_0" = tensor before leaky_relu, "<block>.conv_0", "<block>.shortcut") is also copied

@@ -95,7 +95,66 @@ def zenc_case(name, S, B, labels='blocky', lseed=1234, iseed=31, grid=16):
     print('zenc', name, 'absent rows', int((np.abs(codes).sum(-1) == 0).sum()), 'bytes', os.path.getsize(path))
 
 
+def aux_cases():
+    import torch
+    from oracle import aux_oracle as A
+    from oracle import sean_oracle as O
+    # ---- shape branch: encode + decode on blocky and face-like label maps (incl. 255 'no class' pixels)
+    G = R.make_shape_generator()
+    sd = P.shape_state_dict(0)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    lab = np.stack([P.blocky_labels(1, 256, seed=61)[0], face_like_labels(256, 62), face_like_labels(256, 63)])
+    lab[0, :32, :48] = 255
+    with torch.no_grad():
+        hair, face = A.split_hair_face(A.label_to_onehot19(lab))
+        hc = G.forward_hair_encoder(hair, testing=True)
+        fc = G.forward_face_encoder(face)
+        hl = G.forward_hair_decoder(hc, fc)
+        fl = G.forward_face_decoder(fc)
+        probs = G.forward_decoder(hl, fl)
+        out = torch.argmax(probs, dim=1).to(torch.uint8)
+        top2 = torch.topk(probs, 2, dim=1).values
+    np.savez_compressed(os.path.join(HERE, 'shape_054.npz'), labels=lab, hair_code=hc.numpy(), face_code=fc.numpy(),
+                        hair_logit_sub4=hl.numpy()[:, :, ::4, ::4], face_logit_sub4=fl.numpy()[:, :, ::4, ::4],
+                        face_logit_crop=fl.numpy()[:, :, 96:160, 96:160], out_labels=out.numpy(),
+                        margin=(top2[:, 0] - top2[:, 1]).numpy().astype(np.float16))
+    print('shape classes', np.unique(out.numpy()), 'min margin', float((top2[:, 0] - top2[:, 1]).min()))
+    # ---- colour MLPs
+    S = R.make_color_solver()
+    cs = P.color_state_dicts(0)
+    for nm, mod in (('gen', S.gen), ('dis', S.dis), ('rgb', S.rgb_model)):
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in cs[nm].items()})
+    code = torch.from_numpy(P.style_codes(5, seed=71)[:, 13])
+    with torch.no_grad():
+        d = S.dis({'code': code})
+        r = S.rgb_model({'code': code})
+        data = {'noise': d['noise'], 'noise_curliness': d['noise_curliness'], 'rgb_mean': r['rgb_mean'], 'pca_std': r['pca_std']}
+        g = S.gen(data)['code']
+        ei = S.edit_infer(code, {'noise_curliness': torch.full((5, 1), 1.0), 'rgb_mean': r['rgb_mean'], 'pca_std': r['pca_std']})
+    np.savez_compressed(os.path.join(HERE, 'color_045.npz'), code=code.numpy(), noise=d['noise'].numpy(),
+                        noise_curliness=d['noise_curliness'].numpy(), adv=d['adv'].numpy(), rgb_mean=r['rgb_mean'].numpy(),
+                        pca_std=r['pca_std'].numpy(), gen_code=g.numpy(), edit_infer=ei.numpy())
+    print('color rgb', r['rgb_mean'][0].numpy(), 'gen std', float(g.std()))
+    # ---- BiSeNet
+    N = R.make_bisenet()
+    bs = P.bisenet_state_dict(0)
+    N.load_state_dict({k: torch.from_numpy(v) for k, v in bs.items()})
+    for name, Bn, Hn, seed in (('256', 2, 256, 81), ('512', 1, 512, 82)):
+        img = P.synthetic_images(Bn, Hn, seed=seed)
+        with torch.no_grad():
+            lg = N(torch.from_numpy(img))[0]
+        lut = np.array(A.BISENET_TO_CELEBA, np.uint8)
+        top2 = torch.topk(lg, 2, dim=1).values
+        np.savez_compressed(os.path.join(HERE, f'bisenet_{name}.npz'), meta_B=np.array(Bn), meta_S=np.array(Hn),
+                            meta_seed=np.array(seed), logits_sub8=lg.numpy()[:, :, ::8, ::8],
+                            logits_crop=lg.numpy()[:, :, 100:164, 60:124], labels=lut[lg.argmax(1).numpy()],
+                            margin=(top2[:, 0] - top2[:, 1]).numpy().astype(np.float16))
+        print('bisenet', name, 'classes', np.unique(lg.argmax(1).numpy()), 'logit std', float(lg.std()))
+
+
 def main():
+    if 'aux' in sys.argv[1:] or len(sys.argv) == 1:
+        aux_cases()
     if 'zenc' in sys.argv[1:] or len(sys.argv) == 1:
         zenc_case('S64_B2', 64, 2, grid=8)
         zenc_case('S256_face', 256, 1, labels='face', lseed=41, iseed=42)

@@ -115,3 +115,69 @@ def run_zencoder(sd_np, img, labels):
     G.Zencoder.load_state_dict(zsd, strict=True)
     with torch.no_grad():
         return G.Zencoder(torch.from_numpy(img), O.one_hot(torch.from_numpy(labels))).numpy()
+
+
+class _Dict(dict):
+    """Stand-in for addict.Dict (not installed): attribute access, missing key -> empty falsy _Dict, nested dicts
+    wrapped (needed by shape_branch/config.py:10 and color_texture_branch/config.py:10)."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        for key, v in dict(*a, **k).items():
+            self[key] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, _Dict):
+            v = _Dict(v)
+        super().__setitem__(k, v)
+
+    def __getattr__(self, k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        if k not in self:
+            return _Dict()
+        return self[k]
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __missing__(self, k):
+        return _Dict()
+
+
+def boot_cfg():
+    boot()
+    if 'addict' not in sys.modules:
+        m = types.ModuleType('addict')
+        m.Dict = _Dict
+        sys.modules['addict'] = m
+    tv = sys.modules['torchvision.transforms']
+    for n in ('Compose', 'ToTensor', 'Normalize', 'Resize'):
+        if not hasattr(tv, n):
+            setattr(tv, n, lambda *a, **k: (lambda x: x))
+    sys.modules['torchvision'].transforms = tv
+
+
+def make_shape_generator():
+    boot_cfg()
+    import warnings
+    warnings.filterwarnings('ignore')
+    from shape_branch.config import cfg
+    from shape_branch.model import Generator
+    return Generator(cfg).eval()
+
+
+def make_color_solver():
+    boot_cfg()
+    import warnings
+    warnings.filterwarnings('ignore')
+    import torch
+    from color_texture_branch.config import cfg
+    from color_texture_branch.solver import Solver
+    return Solver(cfg, torch.device('cpu'), -1, training=False)
+
+
+def make_bisenet():
+    boot_cfg()
+    from external_code.face_parsing.model import BiSeNet
+    return BiSeNet(19).eval()

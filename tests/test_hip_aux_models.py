@@ -1,0 +1,139 @@
+"""GPU parity of the HIP shape branch, colour MLPs and BiSeNet (through the C ABI and the reference-shaped host
+shims) vs the oracle and the reference-made golden vectors.  Float outputs: |delta| <= 1e-3.  Label maps: identical
+except where the reference's own top-2 margin is below 1e-3 (an fp32 tie)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+_c = {}
+
+
+def env():
+    if not _c:
+        from ctrlhair_amd import lib, models
+        from ctrlhair_amd import procedural as P
+        h = lib.Handle(0)
+        dev = torch.device('cuda', 0)
+        _c['h'] = h
+        _c['dev'] = dev
+        _c['shape'] = models.ShapeGenerator(h, dev).load_state_dict(P.shape_state_dict(0), max_batch=2)
+        cs = P.color_state_dicts(0)
+        _c['color'] = models.ColorTextureModels(h, dev).load_state_dicts(cs['gen'], cs['dis'], cs['rgb'], max_batch=4)
+        _c['bise'] = models.FaceParsing(h, dev).load_state_dict(P.bisenet_state_dict(0), max_batch=2, max_size=512)
+    return _c
+
+
+def test_color_mlps(hip_lib):
+    e = env()
+    z = np.load(os.path.join(GOLDEN, 'color_045.npz'))
+    code = torch.from_numpy(z['code']).to(e['dev'])       # B=5 > max_batch=4 -> chunked
+    d = e['color'].dis({'code': code})
+    r = e['color'].rgb_model({'code': code})
+    g = e['color'].gen({'noise': d['noise'], 'noise_curliness': d['noise_curliness'], 'rgb_mean': r['rgb_mean'],
+                        'pca_std': r['pca_std']})['code']
+    ei = e['color'].edit_infer(code, {'noise_curliness': torch.full((5, 1), 1.0, device=e['dev']),
+                                      'rgb_mean': r['rgb_mean'], 'pca_std': r['pca_std']})
+    torch.cuda.synchronize()
+    assert np.abs(d['noise'].cpu().numpy() - z['noise']).max() <= TOL
+    assert np.abs(d['noise_curliness'].cpu().numpy() - z['noise_curliness']).max() <= TOL
+    assert np.abs(d['adv'].cpu().numpy() - z['adv']).max() <= TOL
+    assert np.abs(r['rgb_mean'].cpu().numpy() - z['rgb_mean']).max() <= TOL * 10   # values ~1e2: 1e-5 relative
+    assert np.abs(r['pca_std'].cpu().numpy() - z['pca_std']).max() <= TOL * 10
+    assert np.abs(g.cpu().numpy() - z['gen_code']).max() <= TOL
+    assert np.abs(ei.cpu().numpy() - z['edit_infer']).max() <= TOL
+
+
+def test_shape_branch_golden(hip_lib):
+    e = env()
+    z = np.load(os.path.join(GOLDEN, 'shape_054.npz'))
+    sg = e['shape']
+    lab = torch.from_numpy(z['labels']).to(e['dev'])
+    hc, fc = sg.encode_labels(lab)
+    torch.cuda.synchronize()
+    assert np.abs(hc.cpu().numpy() - z['hair_code']).max() <= TOL
+    assert np.abs(fc.cpu().numpy() - z['face_code']).max() <= TOL
+    # reference-shaped API on one-hot tensors gives the same codes
+    from ctrlhair_amd.models import mask_label_to_one_hot, mask_one_hot_to_label, split_hair_face
+    hair, face = split_hair_face(mask_label_to_one_hot(lab[:, None]))
+    assert torch.equal(sg.forward_hair_encoder(hair, testing=True), hc)
+    assert torch.equal(sg.forward_face_encoder(face), fc)
+    # decode from the golden codes
+    ghc, gfc = torch.from_numpy(z['hair_code']).to(e['dev']), torch.from_numpy(z['face_code']).to(e['dev'])
+    hl = sg.forward_hair_decoder(ghc, gfc)
+    fl = sg.forward_face_decoder(gfc)
+    probs = sg.forward_decode_by_code(ghc, gfc)
+    out = sg.decode_labels(ghc, gfc)
+    torch.cuda.synchronize()
+    assert np.abs(hl.cpu().numpy()[:, :, ::4, ::4] - z['hair_logit_sub4']).max() <= TOL
+    assert np.abs(fl.cpu().numpy()[:, :, ::4, ::4] - z['face_logit_sub4']).max() <= TOL
+    assert np.abs(fl.cpu().numpy()[:, :, 96:160, 96:160] - z['face_logit_crop']).max() <= TOL
+    bad = out.cpu().numpy() != z['out_labels']
+    assert not (bad & (z['margin'].astype(np.float32) > 1e-3)).any(), int(bad.sum())
+    assert torch.equal(mask_one_hot_to_label(probs).to(torch.uint8), out)
+    assert torch.equal(mask_one_hot_to_label(sg.forward_decoder(hl, fl)).to(torch.uint8), out)
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-4
+
+
+def test_shape_branch_vs_oracle_fresh(hip_lib):
+    from ctrlhair_amd import procedural as P
+    from oracle import aux_oracle as A
+    from oracle import sean_oracle as O
+    e = env()
+    lab = P.blocky_labels(1, 256, seed=777, grid=8)
+    sd = O.to_torch(P.shape_state_dict(0))
+    rh, rf = A.shape_encode(sd, lab)
+    hc, fc = e['shape'].encode_labels(torch.from_numpy(lab).to(e['dev']))
+    torch.cuda.synchronize()
+    assert float((hc.cpu() - rh).abs().max()) <= TOL and float((fc.cpu() - rf).abs().max()) <= TOL
+    rhl, rfl, rprobs, rlab = A.shape_decode(sd, rh, rf)
+    probs = e['shape'].forward_decode_by_code(rh.to(e['dev']), rf.to(e['dev']))
+    torch.cuda.synchronize()
+    assert float((probs.cpu() - rprobs).abs().max()) <= TOL
+
+
+@pytest.mark.parametrize('name', ['256', '512'])
+def test_bisenet_golden(hip_lib, name):
+    from ctrlhair_amd import procedural as P
+    e = env()
+    z = np.load(os.path.join(GOLDEN, f'bisenet_{name}.npz'))
+    img = torch.from_numpy(P.synthetic_images(int(z['meta_B']), int(z['meta_S']), seed=int(z['meta_seed']))).to(e['dev'])
+    lab, lg = e['bise'].parse_tensor(img, want_logits=True)
+    torch.cuda.synchronize()
+    lg = lg.cpu().numpy()
+    assert np.abs(lg[:, :, ::8, ::8] - z['logits_sub8']).max() <= TOL
+    assert np.abs(lg[:, :, 100:164, 60:124] - z['logits_crop']).max() <= TOL
+    bad = lab.cpu().numpy() != z['labels']
+    assert not (bad & (z['margin'].astype(np.float32) > 1e-3)).any(), int(bad.sum())
+    lab2, _ = e['bise'].parse_tensor(img)
+    assert torch.equal(lab, lab2)
+
+
+def test_bisenet_stagewise_vs_oracle(hip_lib):
+    from ctrlhair_amd import procedural as P
+    from oracle import aux_oracle as A
+    from oracle import sean_oracle as O
+    e = env()
+    img = P.synthetic_images(3, 128, seed=99)      # B=3 > max_batch=2, non-512 size
+    rl, rlab = A.bisenet_forward(O.to_torch(P.bisenet_state_dict(0)), img)
+    lab, lg = e['bise'].parse_tensor(torch.from_numpy(img).to(e['dev']), want_logits=True)
+    torch.cuda.synchronize()
+    assert float((lg.cpu() - rl).abs().max()) <= TOL
+    top2 = torch.topk(rl, 2, dim=1).values
+    bad = lab.cpu() != rlab
+    assert not (bad & ((top2[:, 0] - top2[:, 1]) > 1e-3)).any()
+
+
+def test_parsing_img_surface(hip_lib):
+    from ctrlhair_amd import procedural as P
+    e = env()
+    img = ((P.synthetic_images(1, 256, seed=5)[0].transpose(1, 2, 0) * 0.5 + 0.5) * 255).astype(np.uint8)
+    parsing, pil = e['bise'].parsing_img(img)
+    assert parsing.shape == (512, 512) and pil.size == (512, 512) and parsing.max() <= 18
+    celeba = e['bise'].swap_parsing_label_to_celeba_mask(parsing)
+    assert celeba.shape == (512, 512) and celeba.dtype == np.uint8

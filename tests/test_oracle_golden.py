@@ -46,3 +46,55 @@ def test_zencoder_oracle_matches_reference_golden(name):
     c = ZencCase(name)
     codes = O.zencoder_forward(O.to_torch(c.state_dict()), c.img, c.labels).numpy()
     assert np.abs(codes - c.codes).max() <= 1e-5
+
+
+def _g(name):
+    import os
+    import numpy as np
+    from tests.golden_util import GOLDEN
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_shape_oracle_matches_reference_golden():
+    import numpy as np
+    from ctrlhair_amd import procedural as P
+    from oracle import aux_oracle as A
+    z = _g('shape_054.npz')
+    sd = O.to_torch(P.shape_state_dict(0))
+    hc, fc = A.shape_encode(sd, z['labels'])
+    assert np.abs(hc.numpy() - z['hair_code']).max() <= 1e-5 and np.abs(fc.numpy() - z['face_code']).max() <= 1e-5
+    hl, fl, probs, lab = A.shape_decode(sd, z['hair_code'], z['face_code'])
+    assert np.abs(hl.numpy()[:, :, ::4, ::4] - z['hair_logit_sub4']).max() <= 1e-4
+    assert np.abs(fl.numpy()[:, :, ::4, ::4] - z['face_logit_sub4']).max() <= 1e-4
+    bad = lab.numpy() != z['out_labels']
+    assert not (bad & (z['margin'].astype(np.float32) > 1e-3)).any()
+
+
+def test_color_oracle_matches_reference_golden():
+    import numpy as np
+    import torch
+    from ctrlhair_amd import procedural as P
+    from oracle import aux_oracle as A
+    z = _g('color_045.npz')
+    cs = {k: O.to_torch(v) for k, v in P.color_state_dicts(0).items()}
+    e = A.color_encode(cs['dis'], z['code']).numpy()
+    assert np.abs(e[:, 1:9] - z['noise']).max() <= 1e-5 and np.abs(e[:, 9:10] - z['noise_curliness']).max() <= 1e-5
+    p = A.color_predict(cs['rgb'], z['code']).numpy()
+    assert np.abs(p[:, :3] - z['rgb_mean']).max() <= 1e-3 and np.abs(p[:, 3:] - z['pca_std']).max() <= 1e-3
+    cond = np.concatenate([z['noise_curliness'], z['rgb_mean'], z['pca_std']], 1)
+    g = A.color_generate(cs['gen'], z['noise'], cond).numpy()
+    assert np.abs(g - z['gen_code']).max() <= 1e-5
+
+
+@pytest.mark.parametrize('name', ['256', '512'])
+def test_bisenet_oracle_matches_reference_golden(name):
+    import numpy as np
+    from ctrlhair_amd import procedural as P
+    from oracle import aux_oracle as A
+    z = _g(f'bisenet_{name}.npz')
+    img = P.synthetic_images(int(z['meta_B']), int(z['meta_S']), seed=int(z['meta_seed']))
+    lg, lab = A.bisenet_forward(O.to_torch(P.bisenet_state_dict(0)), img)
+    assert np.abs(lg.numpy()[:, :, ::8, ::8] - z['logits_sub8']).max() <= 1e-4
+    assert np.abs(lg.numpy()[:, :, 100:164, 60:124] - z['logits_crop']).max() <= 1e-4
+    bad = lab.numpy() != z['labels']
+    assert not (bad & (z['margin'].astype(np.float32) > 1e-3)).any()
