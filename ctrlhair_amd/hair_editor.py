@@ -1,0 +1,230 @@
+"""Mirror of /root/reference/hair_editor.py::HairEditor on the MI355X library: same method names, argument meaning
+and return types (hair_editor.py:40-335), the networks replaced by C-ABI shims.
+
+Differences that are deliberate and documented (SURVEY.md 7 'host-side dependencies'):
+  * no argv parsing / checkpoint globbing in the constructor: weights come in as state dicts (`weights=`), either real
+    checkpoints in the reference's formats or ctrlhair_amd.procedural ones;
+  * cv2 / dlib / scipy are imported lazily and only by the CPU pre/post-processing helpers that need them;
+  * `load_average_feature` reads the 19 median codes once (packed copy of
+    sean_codes/styles_test/mean_style_code/median/*/ACE.npy) instead of re-globbing .npy files on every call.
+"""
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import hostutil as U
+from . import lib as _lib
+from .hostutil import HAIR_IDX, PARSING_LABEL_LIST
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+
+
+def change_status(model, new_status):
+    """hair_editor.py:33-36 (a no-op for the HIP generator, which has no per-module status)."""
+    for m in model.modules():
+        if hasattr(m, 'status'):
+            m.status = new_status
+
+
+def procedural_weights(seed: int = 0, ngf: int = 64) -> Dict[str, dict]:
+    from . import procedural as P
+    cs = P.color_state_dicts(seed)
+    return {'sean': P.sean_state_dict(seed, ngf), 'shape': P.shape_state_dict(seed), 'color_gen': cs['gen'],
+            'color_dis': cs['dis'], 'color_rgb': cs['rgb'], 'bisenet': P.bisenet_state_dict(seed)}
+
+
+def reference_checkpoints(root: str = '.') -> Dict[str, dict]:
+    """Load the reference's own checkpoint files (hair_editor.py:45-108, util/util.py:202-208,
+    my_torchlib/utils.py:25-36, my_parsing_util.py:42-43) when a user has them."""
+    def latest(d):
+        with open(os.path.join(d, 'latest_checkpoint')) as f:
+            return torch.load(os.path.join(d, f.read().strip()), map_location='cpu')
+    strip = lambda sd: {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+    ct = latest(os.path.join(root, 'model_trained/color_texture/045__color_texture_final/checkpoints'))
+    sh = latest(os.path.join(root, 'model_trained/shape/054__shape_final/checkpoints'))
+    rgb = latest(os.path.join(root, 'model_trained/color_encoder/p004___pca_std/checkpoints'))
+    return {'sean': torch.load(os.path.join(root, 'external_model_params/sean_checkpoints/CelebA-HQ_pretrained/latest_net_G.pth'),
+                               map_location='cpu'),
+            'shape': strip(sh['Model_G']), 'color_gen': strip(ct['Model_G']), 'color_dis': strip(ct['Model_D']),
+            'color_rgb': strip(rgb['Predictor']),
+            'bisenet': torch.load(os.path.join(root, 'external_model_params/face_parsing_79999_iter.pth'), map_location='cpu')}
+
+
+class HipModels:
+    """Builds every network of the path on one ch_handle (one GPU)."""
+
+    def __init__(self, weights: Dict[str, dict], device: int = 0, img_size: int = 256, max_batch: int = 1):
+        from .models import ColorTextureModels, FaceParsing, ShapeGenerator
+        from .sean.generator import SeanGenerator
+        from .sean.pix2pix_model import Pix2PixModel
+        self.generator = SeanGenerator(device).load_state_dict(weights['sean'], max_batch=max_batch, max_size=img_size)
+        h, dev = self.generator.handle, self.generator.device
+        self.device = dev
+        self.sean_model = Pix2PixModel(self.generator)
+        self.solver_feature = ColorTextureModels(h, dev).load_state_dicts(weights['color_gen'], weights['color_dis'],
+                                                                          weights['color_rgb'], max_batch=max(max_batch, 16))
+        self.mask_generator = ShapeGenerator(h, dev).load_state_dict(weights['shape'], max_batch=max(max_batch, 1))
+        self.face_parsing = FaceParsing(h, dev).load_state_dict(weights['bisenet'], max_batch=max(max_batch, 1), max_size=512)
+
+
+class HairEditor:
+    """This is the basic module (hair_editor.py:40-43); ctrlhair_amd.ui.backend.Backend succeeds this class."""
+
+    def __init__(self, load_feature_model=True, load_mask_model=True, *, weights='procedural', device: int = 0,
+                 img_size: int = 256, models=None, texture_dirs=None, shape_dirs=None, max_batch: int = 1):
+        if models is None:
+            if weights == 'procedural':
+                weights = procedural_weights()
+            elif weights == 'reference':
+                weights = reference_checkpoints()
+            models = HipModels(weights, device=device, img_size=img_size, max_batch=max_batch)
+        self.models = models
+        self.sean_model = models.sean_model
+        self.img_size = img_size                     # hair_editor.py:50 (256 in the reference)
+        self.device = models.device
+        self.face_parsing = models.face_parsing
+        if load_feature_model:
+            self.solver_feature = models.solver_feature
+            self.feature_encoder = self.solver_feature.dis
+            self.feature_generator = self.solver_feature.gen
+            self.feature_rgb_predictor = self.solver_feature.rgb_model
+            dirs = texture_dirs if texture_dirs is not None else U.seeded_directions(2, 8, seed=45)
+            self.texture_dirs = [torch.as_tensor(d).float().to(self.device) for d in dirs]
+        if load_mask_model:
+            self.mask_generator = models.mask_generator
+            dirs = shape_dirs if shape_dirs is not None else U.seeded_directions(4, 16, seed=54)
+            self.shape_dirs = [torch.as_tensor(d).float().to(self.device) for d in dirs]
+        self._median = None
+
+    # ---- pre-processing (hair_editor.py:121-128) --------------------------------------------------------------
+    def preprocess_img(self, img):
+        img = U.resize_bilinear(np.asarray(img).astype('uint8'), (self.img_size, self.img_size))
+        return (np.transpose(img, [2, 0, 1]) / 127.5 - 1.0)[None, ...]
+
+    def preprocess_mask(self, mask_img):
+        mask_img = U.resize_nearest(np.asarray(mask_img).astype('uint8'), (self.img_size, self.img_size))
+        return mask_img[None, None, :, :]
+
+    def load_average_feature(self):
+        """hair_editor.py:130-147: {str(i): {'ACE': tensor[512]}} of the per-category median style codes."""
+        if self._median is None:
+            self._median = torch.from_numpy(np.load(os.path.join(_DATA, 'mean_style_code.npz'))['median']).to(self.device)
+        return {str(i): {'ACE': self._median[i]} for i in range(19)}
+
+    # ---- networks --------------------------------------------------------------------------------------------
+    def get_code(self, hair_img, hair_parsing):
+        """hair_editor.py:149-157 -> style codes [1,19,512]."""
+        data = {'label': torch.as_tensor(np.asarray(hair_parsing), dtype=torch.float32), 'instance': torch.tensor(0),
+                'image': torch.as_tensor(np.asarray(hair_img), dtype=torch.float32), 'path': ['temp/temp_npy']}
+        change_status(self.sean_model, 'test')
+        return self.sean_model(data, mode='style_code')
+
+    def _obj_dic(self, code):
+        obj_dic = self.load_average_feature()
+        for idx in range(19):
+            cur_code = code[0, idx]
+            if not torch.all(cur_code == 0):          # all-zero row (absent region) -> keep the median code, :165-168
+                obj_dic[str(idx)]['ACE'] = cur_code
+        return obj_dic
+
+    def gen_img(self, code, parsing, noise=None):
+        """hair_editor.py:159-179 -> generated image [3,S,S] in [-1,1]."""
+        if not isinstance(code, torch.Tensor):
+            code = torch.tensor(code)
+        code = code.to(self.device)
+        data = {'label': torch.as_tensor(np.asarray(parsing) if not isinstance(parsing, torch.Tensor) else parsing,
+                                         dtype=torch.float32),
+                'instance': torch.tensor(0), 'image': None, 'obj_dic': self._obj_dic(code)}
+        if noise is not None:
+            data['noise'] = noise
+        change_status(self.sean_model, 'UI_mode')
+        return self.sean_model(data, mode='UI_mode')[0]
+
+    def generate_by_sean(self, face_img_code, hair_code, target_seg, noise=None):
+        """hair_editor.py:181-206 (face_img_code [19,512], hair_code [512])."""
+        obj_dic = self.load_average_feature()
+        for idx in range(19):
+            cur_code = hair_code if idx == HAIR_IDX else face_img_code[idx]
+            if not torch.all(face_img_code == 0):
+                obj_dic[str(idx)]['ACE'] = cur_code
+        data = {'label': torch.as_tensor(np.asarray(target_seg), dtype=torch.float32), 'instance': torch.tensor(0),
+                'obj_dic': obj_dic, 'image': None}
+        if noise is not None:
+            data['noise'] = noise
+        change_status(self.sean_model, 'UI_mode')
+        return self.sean_model(data, mode='UI_mode')[0]
+
+    def generate_instance_transfer_img(self, face_img, face_parsing, hair_img, hair_parsing, target_seg, edit_data=None,
+                                       temp_path='temp'):
+        """hair_editor.py:208-231."""
+        face_img_code = self.get_code(face_img, face_parsing)
+        hair_img_code = face_img_code if hair_img is None else self.get_code(hair_img, hair_parsing)
+        hair_code = hair_img_code[0, HAIR_IDX]
+        if edit_data is not None:
+            hair_code = self.solver_feature.edit_infer(hair_code[None, ...], edit_data)[0]
+        return self.generate_by_sean(face_img_code[0], hair_code, target_seg)
+
+    def get_mask(self, img_rgb):
+        """hair_editor.py:331-335: BiSeNet parse @512 -> CelebAMask ids -> nearest resize to img_size."""
+        parsing, _ = self.face_parsing.parsing_img(img_rgb)
+        parsing = self.face_parsing.swap_parsing_label_to_celeba_mask(parsing)
+        return U.resize_nearest(parsing.astype('uint8'), (self.img_size, self.img_size))
+
+    def get_hair_color(self, img):
+        """hair_editor.py:233-243 (needs cv2 for the 19x19 elliptical erosion)."""
+        cv2 = U._cv2()
+        if cv2 is None:
+            raise RuntimeError('get_hair_color needs cv2 (elliptical erosion), which is not installed')
+        parsing = self.get_mask_fullres(img, 1024)
+        img = cv2.resize(np.asarray(img).astype('uint8'), (1024, 1024))
+        hair_mask = cv2.erode((parsing == HAIR_IDX).astype('uint8'),
+                              cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ksize=(19, 19)), iterations=1)
+        return img[hair_mask.astype('bool')].mean(axis=0)
+
+    def get_mask_fullres(self, img_rgb, size):
+        parsing, _ = self.face_parsing.parsing_img(img_rgb)
+        return U.resize_nearest(self.face_parsing.swap_parsing_label_to_celeba_mask(parsing).astype('uint8'), (size, size))
+
+    # ---- post-processing (hair_editor.py:257-310) --------------------------------------------------------------
+    def postprocess_blending(self, face_img, res_img, face_parsing, target_parsing, verbose_print=False, blending=True,
+                             blender=None):
+        def from_tensor_order_to_cv2(tensor_img, is_mask=False):
+            if isinstance(tensor_img, torch.Tensor):
+                tensor_img = tensor_img.detach().cpu().numpy()
+            if len(tensor_img.shape) == 4:
+                tensor_img = tensor_img[0]
+            if len(tensor_img.shape) == 2:
+                tensor_img = tensor_img[None, ...]
+            if tensor_img.shape[2] <= 3:
+                return tensor_img
+            res = np.transpose(tensor_img, [1, 2, 0])
+            if not is_mask:
+                res = res * 127.5 + 127.5
+            return res
+
+        res_img = from_tensor_order_to_cv2(res_img).astype('uint8')
+        if not blending:
+            return res_img, None
+        # Poisson blending (poisson_blending.py:29-87) is a CPU post-process outside the GPU path; a
+        # caller that wants it injects the reference function (`blender=poisson_blending`) and needs cv2 for the dilations.
+        cv2 = U._cv2()
+        if blender is None or cv2 is None:
+            raise RuntimeError('blending=True needs cv2 and a Poisson blender (poisson_blending.poisson_blending); '
+                               'construct Backend(..., blending=False) or pass blender=')
+        target_parsing = from_tensor_order_to_cv2(target_parsing, is_mask=True)
+        face_img = from_tensor_order_to_cv2(face_img).astype('uint8')
+        face_parsing = from_tensor_order_to_cv2(face_parsing, is_mask=True)
+        res_mask = np.logical_or(target_parsing == HAIR_IDX, face_parsing == HAIR_IDX).astype('uint8')
+        k13 = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ksize=(13, 13))
+        k5 = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ksize=(5, 5))
+        d13 = cv2.dilate(res_mask, k13, iterations=1)[..., None]
+        d5 = cv2.dilate(res_mask, k5, iterations=1)[..., None]
+        bg_mask = (target_parsing == PARSING_LABEL_LIST.index('background'))
+        res_mask_dilated = d13 * (1 - bg_mask) + d5 * bg_mask
+        return blender(face_img, res_img, 1 - res_mask_dilated, with_gamma=True), res_mask_dilated
+
+    def crop_face(self, img_rgb, save_path=None):
+        """hair_editor.py:312-329: dlib landmark alignment -- CPU pre-processing, out of scope."""
+        raise NotImplementedError('crop_face needs dlib landmark models (external_code/crop.py); crop offline')

@@ -228,7 +228,7 @@ class FaceParsing:
 
     def normalise(self, img_u8_hwc: np.ndarray) -> torch.Tensor:
         """ToTensor + Normalize (my_parsing_util.py:25-28) on device."""
-        t = torch.from_numpy(np.ascontiguousarray(img_u8_hwc)).to(self.device).permute(2, 0, 1).float() / 255.0
+        t = torch.from_numpy(np.array(img_u8_hwc, copy=True)).to(self.device).permute(2, 0, 1).float() / 255.0
         mean = torch.tensor(_MEAN, device=self.device).view(3, 1, 1)
         std = torch.tensor(_STD, device=self.device).view(3, 1, 1)
         return ((t - mean) / std)[None]

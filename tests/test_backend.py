@@ -1,0 +1,111 @@
+"""The editing API (ctrlhair_amd.ui.backend.Backend, mirror of ui/backend.py) end to end.
+
+CPU (not gpu): BASELINE config 1 -- one portrait through set_input_img -> sliders -> output() with every network
+replaced by the CPU oracle (the reference plumbing, no GPU).
+GPU: the same script on the HIP library must give the same masks / latents / image."""
+import numpy as np
+import pytest
+import torch
+
+from ctrlhair_amd import procedural as P
+from ctrlhair_amd.hair_editor import procedural_weights
+from ctrlhair_amd.sean import arch
+from ctrlhair_amd.ui.backend import Backend
+
+NGF = 16      # tiny SEAN generator keeps the CPU leg fast; the other three networks are full size
+
+
+def weights():
+    w = procedural_weights(0, 64)
+    w['sean'] = P.sean_state_dict(0, NGF)
+    return w
+
+
+def portrait(seed=3):
+    return ((P.synthetic_images(1, 256, seed=seed)[0].transpose(1, 2, 0) * 0.5 + 0.5) * 255).astype(np.uint8)
+
+
+def script(be, noise):
+    """The usage example of ui/backend.py:468-504 minus the warping-based shape transfer."""
+    be.noise = noise
+    inp, mask_show = be.set_input_img(portrait(3))
+    be.set_target_img(portrait(4))
+    be.transfer_latent_representation('texture')
+    be.transfer_latent_representation('color')
+    be.change_color(1.0, 2)
+    be.change_color(0.5, 3)
+    be.change_curliness(1.0)
+    be.change_texture(1.5, 0)
+    be.change_shape(-1.0, 0)
+    out = be.output()
+    return dict(inp=inp, mask_show=mask_show, out=out, cur_mask=be.cur_mask.copy(), shape=be.cur_latent.shape.cpu().numpy(),
+                texture=be.cur_latent.texture.cpu().numpy(), hsv=be.cur_latent.color['hsv'].cpu().numpy(),
+                code=be.input_sean_code.cpu().numpy(), sliders=[float(v) for v in be.get_shape_be2fe()])
+
+
+@pytest.fixture(scope='module')
+def cpu_run():
+    from tests.oracle_models import OracleModels
+    torch.manual_seed(0)
+    be = Backend(2.5, blending=False, models=OracleModels(weights(), NGF))
+    noise = torch.from_numpy(P.noise_planes(1, 256, NGF, seed=77))
+    return script(be, noise)
+
+
+def test_config1_cpu_plumbing(cpu_run):
+    r = cpu_run
+    assert r['out'].shape == (256, 256, 3) and r['out'].dtype == np.uint8
+    assert r['inp'].shape == (256, 256, 3) and r['mask_show'].shape == (256, 256, 3)
+    assert r['cur_mask'].shape == (256, 256) and r['cur_mask'].max() <= 18
+    assert abs(r['sliders'][0] - (-1.0)) < 1e-4           # continue_change_with_direction pins the projection
+    assert r['out'].std() > 5                              # a real image, not a constant
+
+
+def test_api_surface_matches_reference_names():
+    """Every public method of the reference's Backend / HairEditor exists on the mirror (names from ui/backend.py and
+    hair_editor.py)."""
+    names = ['parse_img', 'tensor_hsv_to_rgb', 'tensor_rgb_to_hsv', 'set_input_img', 'set_target_img', 'output',
+             'change_curliness', 'change_color', 'change_shape', 'change_texture', 'get_curliness_be2fe', 'get_color_be2fe',
+             'get_shape_be2fe', 'get_texture_be2fe', 'transfer_latent_representation', 'refresh_cur_mask', 'get_cur_mask',
+             'interpolate_hsv', 'interpolate_triple', 'interpolate', 'interpolate_each_att', 'show_hair_region',
+             'directly_change_hair_mask', 'get_random_texture', 'get_random_shape', 'get_random_curliness',
+             'continue_change_with_direction', 'preprocess_img', 'preprocess_mask', 'load_average_feature', 'get_code',
+             'gen_img', 'generate_by_sean', 'generate_instance_transfer_img', 'get_hair_color', 'postprocess_blending',
+             'crop_face', 'get_mask']
+    for n in names:
+        assert callable(getattr(Backend, n)), n
+
+
+def test_gen_img_median_fallback_and_interpolate(cpu_run):
+    from tests.oracle_models import OracleModels
+    be = Backend(2.5, blending=False, models=OracleModels(weights(), NGF))
+    be.set_input_img(portrait(5))
+    code = be.input_sean_code.clone()
+    absent = [j for j in range(19) if torch.all(code[0, j] == 0)]
+    obj = be._obj_dic(code)
+    med = be.load_average_feature()
+    for j in range(19):
+        want = med[str(j)]['ACE'] if j in absent else code[0, j]
+        assert torch.equal(obj[str(j)]['ACE'], want)           # hair_editor.py:165-168
+    lat = be.interpolate(be.cur_latent, be.cur_latent, 0.3)
+    assert torch.allclose(lat.shape, be.cur_latent.shape, atol=1e-6)
+    be.get_random_shape()
+    assert be.cur_mask.shape == (256, 256)
+    be.directly_change_hair_mask(np.full((256, 256), 13, np.uint8))
+    assert (be.cur_mask == 13).all()
+
+
+@pytest.mark.gpu
+def test_hip_backend_matches_cpu_plumbing(hip_lib, cpu_run):
+    torch.manual_seed(0)
+    be = Backend(2.5, blending=False, weights=weights(), device=0)
+    noise = torch.from_numpy(P.noise_planes(1, 256, NGF, seed=77)).cuda()
+    g = script(be, noise)
+    c = cpu_run
+    assert np.array_equal(g['inp'], c['inp'])
+    assert np.abs(g['shape'] - c['shape']).max() <= 1e-3 and np.abs(g['texture'] - c['texture']).max() <= 1e-3
+    assert np.array_equal(g['hsv'], c['hsv'])
+    assert np.abs(g['code'] - c['code']).max() <= 1e-3
+    assert (g['cur_mask'] != c['cur_mask']).mean() < 1e-3          # label flips only at fp32 ties
+    d = np.abs(g['out'].astype(np.int32) - c['out'].astype(np.int32))
+    assert d.max() <= 1 or (d > 1).mean() < 1e-3, (d.max(), (d > 1).mean())   # uint8 truncation of |delta|<=1e-3 floats
