@@ -59,6 +59,8 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ngf', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--path', choices=('f32', 'f16x3'), default='f32',
+                    help='conv arithmetic: exact-f32 MFMA, or 3-term split-operand f16 MFMA (f32-class)')
     args = ap.parse_args()
 
     import torch
@@ -81,7 +83,7 @@ def main():
     from ctrlhair_amd.sean.generator import SeanGenerator
     B, S, ngf = args.batch, args.size, args.ngf
     sd = P.sean_state_dict(0, ngf)
-    gen = SeanGenerator(local_rank).load_state_dict(sd, max_batch=B, max_size=S)
+    gen = SeanGenerator(local_rank, f16x3=(args.path == 'f16x3')).load_state_dict(sd, max_batch=B, max_size=S)
     first = rank * B     # global sample index offset (SURVEY.md 8d Config 4)
     labels = torch.from_numpy(P.blocky_labels(B, S, first=first)).to(dev)
     codes = torch.from_numpy(P.style_codes(B, first=first)).to(dev)

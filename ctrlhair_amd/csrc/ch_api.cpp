@@ -207,6 +207,16 @@ int ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr) {
     return CH_OK;
 }
 
+int ch_set_option(ch_handle* h, const char* key, int value) {
+    if (!h || !key) return CH_ERR_ARG;
+    if (std::strcmp(key, "sean.f16x3") == 0) {
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.f16x3) must precede ch_finalize");
+        h->sean.use_sh16 = value != 0;
+        return CH_OK;
+    }
+    return fail(h, CH_ERR_ARG, std::string("unknown option '") + key + "'");
+}
+
 int ch_profile_enable(ch_handle* h, int on) {
     if (!h) return CH_ERR_ARG;
     h->sean.prof_on = on != 0;

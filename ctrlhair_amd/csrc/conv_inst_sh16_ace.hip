@@ -1,0 +1,10 @@
+// f16x3 split-operand SPADE conv with fused ACE epilogue (see conv_sh16.h)
+#include "conv_sh16.h"
+namespace chk {
+hipError_t conv_sh16_ace(const ConvParams& p, hipStream_t s) {
+    const int rows = ((p.C + 31) / 32) * 64;
+    if (p.W >= 32) return launch_sh16<3, 32, 16, 1, EPI_ACE>(p, rows, s);
+    if (p.W > 8) return launch_sh16<3, 16, 16, 2, EPI_ACE>(p, rows, s);
+    return launch_sh16<3, 8, 8, 8, EPI_ACE>(p, rows, s);
+}
+}  // namespace chk

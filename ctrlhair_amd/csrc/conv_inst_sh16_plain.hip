@@ -1,0 +1,13 @@
+// f16x3 split-operand plain convs (3x3 and 1x1), SH16 input -> f32 NCHW output (see conv_sh16.h)
+#include "conv_sh16.h"
+namespace chk {
+template <int KS>
+static hipError_t go(const ConvParams& p, hipStream_t s) {
+    if (p.W >= 32) return launch_sh16<KS, 32, 16, 1, EPI_PLAIN>(p, p.Mrows, s);
+    if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN>(p, p.Mrows, s);
+    return launch_sh16<KS, 8, 8, 8, EPI_PLAIN>(p, p.Mrows, s);
+}
+hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s) {
+    return KS == 3 ? go<3>(p, s) : (KS == 1 ? go<1>(p, s) : hipErrorInvalidValue);
+}
+}  // namespace chk

@@ -103,6 +103,34 @@ std::vector<float> pack_A(int rows, int Cin, int KS, int CK, F get) {
     return dst;
 }
 
+// f16x3 split-operand packing for conv_sh16_kernel:
+//   [wave tile 64 rows][chunk 16 ch][tap][M-subtile][hi|lo][lane][8 halfs]; lane l: row (l&31), channels 8*(l>>5)+e
+template <class F>
+std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get) {
+    const int mt64 = (rows + 63) / 64, nch = (Cin + 15) / 16, nt = KS * KS;
+    std::vector<_Float16> dst((size_t)mt64 * nch * nt * 2 * 2 * 64 * 8, (_Float16)0.f);
+    size_t o = 0;
+    for (int mt = 0; mt < mt64; ++mt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int t = 0; t < nt; ++t)
+                for (int ms = 0; ms < 2; ++ms) {
+                    for (int hl = 0; hl < 2; ++hl)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e, ++o) {
+                                const int row = mt * 64 + ms * 32 + (lane & 31);
+                                const int ci = ch * 16 + (lane >> 5) * 8 + e;
+                                if (row < rows && ci < Cin) {
+                                    const float w = get(row, ci, t);
+                                    const _Float16 h = (_Float16)w;
+                                    dst[o] = hl == 0 ? h : (_Float16)(w - (float)h);
+                                }
+                            }
+                }
+    std::vector<float> out(dst.size() / 2);
+    std::memcpy(out.data(), dst.data(), dst.size() * 2);
+    return out;
+}
+
 // ---- generic conv layer on the MFMA kernel ------------------------------------------------------------------
 struct ConvLayer {
     float* wpk = nullptr;

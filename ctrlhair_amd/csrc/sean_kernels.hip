@@ -77,6 +77,86 @@ hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* b
     return hipGetLastError();
 }
 
+// Same computation, output in the SH16 layout of conv_sh16.h: [B][K/8][2][H*W][8] _Float16 (hi plane, lo plane).
+// One thread = one pixel x 32 channels = 4 groups; every store is one aligned 16-byte unit, lanes on consecutive
+// pixels -> 1 KiB contiguous per wave store.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t* __restrict__ lab,
+                                                                  const float* __restrict__ table,
+                                                                  const float* __restrict__ bias, uint4* __restrict__ out,
+                                                                  int B, int H, int W, int K, int relu) {
+    __shared__ float T[19 * 9 * OH_KC];
+    __shared__ float bs[OH_KC];
+    const int k0 = blockIdx.y * OH_KC;
+    for (int i = threadIdx.x; i < 19 * 9 * OH_KC; i += 256) {
+        const int jt = i / OH_KC, kk = i % OH_KC;
+        T[i] = (k0 + kk < K) ? table[(long long)jt * K + k0 + kk] : 0.f;
+    }
+    if (threadIdx.x < OH_KC) bs[threadIdx.x] = (k0 + threadIdx.x < K) ? bias[k0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const long long pix = blockIdx.x * 256LL + threadIdx.x;
+    if (pix >= B * HW) return;
+    const int b = (int)(pix / HW);
+    const int y = (int)((pix % HW) / W), x = (int)(pix % W);
+    int jt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        jt[t] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    ? (lab[b * HW + (long long)yy * W + xx] * 9 + t) * OH_KC
+                    : -1;
+    }
+    const int G = (K + 7) / 8;
+#pragma unroll
+    for (int gq = 0; gq < OH_KC / 8; ++gq) {
+        const int g = k0 / 8 + gq;
+        if (g >= G) break;
+        h8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = gq * 8 + e;
+            float v = bs[kk];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (jt[t] >= 0) v += T[jt[t] + kk];
+            if (relu) v = v > 0.f ? v : 0.f;
+            if (k0 + kk >= K) v = 0.f;
+            const _Float16 h = (_Float16)v;
+            vh[e] = h;
+            vl[e] = (_Float16)(v - (float)h);
+        }
+        const long long unit = (((long long)b * G + g) * 2) * HW + (pix % HW);
+        out[unit] = __builtin_bit_cast(uint4, vh);
+        out[unit + HW] = __builtin_bit_cast(uint4, vl);
+    }
+}
+
+hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
+                               int K, int relu, hipStream_t s) {
+    const long long npix = (long long)B * H * W;
+    dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
+    hipLaunchKernelGGL(onehot_conv3x3_sh16_kernel, grid, dim3(256), 0, s, lab, table, bias, static_cast<uint4*>(out), B, H,
+                       W, K, relu);
+    return hipGetLastError();
+}
+
+// SH16 -> f32 NCHW (test taps only)
+__global__ void sh16_decode_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int B, int C, long long HW) {
+    const long long n = (long long)B * C * HW;
+    const int G = (C + 7) / 8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i % HW;
+        const int c = (int)((i / HW) % C), b = (int)(i / (HW * C));
+        const long long unit = (((long long)b * G + c / 8) * 2) * HW + p;
+        out[i] = (float)in[unit * 8 + (c & 7)] + (float)in[(unit + HW) * 8 + (c & 7)];
+    }
+}
+hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, hipStream_t s) {
+    hipLaunchKernelGGL(sh16_decode_kernel, dim3(4096), dim3(256), 0, s, static_cast<const _Float16*>(in), out, B, C, HW);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Per-region style projection: mu[b,j,:] = relu(fc_mu_j(code[b,j]))  (normalization.py:134,146 + :191-215).
 // Weight-bandwidth bound (19 x 1 MB per ACE).  One wave per 4 output features; lanes split the 512-long dot

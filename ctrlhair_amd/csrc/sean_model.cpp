@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "conv_mfma.h"
+#include "conv_sh16.h"
 #include "kernels.h"
 
 namespace chk {
@@ -98,9 +99,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             const float inv = (float)(1.0 / sigma);
             const float* wp = w->f32();
             const int ck = ks == 3 ? CK_KS3 : CK_KS1;
-            auto pk = pack_A(cout, cin, ks, ck, [&](int row, int ci, int t) {
-                return wp[((size_t)row * cin + ci) * ks * ks + t] / (float)sigma;
-            });
+            auto getw = [&](int row, int ci, int t) { return wp[((size_t)row * cin + ci) * ks * ks + t] / (float)sigma; };
+            auto pk = use_sh16 ? pack_A_sh16(cout, cin, ks, getw) : pack_A(cout, cin, ks, ck, getw);
             (void)inv;
             cw.wpk = B.upload(pk);
             cw.Cout = cout;
@@ -162,13 +162,14 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             const float* wgp = wg->f32();
             const float* wbp = wb->f32();
             const float sg = 1.f - ag, sb = 1.f - ab;
-            auto pk = pack_A(tiles * 64, HID, 3, CK_KS3, [&](int row, int ci, int t) {
+            auto getsp = [&](int row, int ci, int t) {
                 const int c = (row / 64) * 32 + (row & 31);
                 if (c >= C) return 0.f;
                 const bool beta = (row & 32) != 0;
                 const float w = (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t];
                 return w * (beta ? sb : sg);
-            });
+            };
+            auto pk = use_sh16 ? pack_A_sh16(tiles * 64, HID, 3, getsp) : pack_A(tiles * 64, HID, 3, CK_KS3, getsp);
             a.spade_wpk = B.upload(pk);
             if (a.styled) {
                 auto cg = B.get(p + ".conv_gamma.weight", (size_t)C * STYLE * 9);
@@ -324,6 +325,12 @@ struct Runner {
         check(hipEventRecord(r.e1, st), "hipEventRecord");
         m.prof.push_back(r);
     }
+    void tap_sh16(const std::string& name, const float* src, int C, size_t hw) {
+        auto it = m.taps.find(name);
+        if (it == m.taps.end() || !it->second) return;
+        if (m.use_sh16) check(sh16_decode(src, it->second, B, C, (long long)hw, st), "tap decode");
+        else check(hipMemcpyAsync(it->second, src, (size_t)B * C * hw * 4, hipMemcpyDeviceToDevice, st), "tap copy");
+    }
     void tap(const std::string& name, const float* src, size_t floats) {
         auto it = m.taps.find(name);
         if (it != m.taps.end() && it->second)
@@ -359,7 +366,10 @@ struct Runner {
             timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
                   [&] { check(conv_nhwc1x1(p, st), "lut gemm"); });
         }
-        check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
+        if (m.use_sh16)
+            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
+        else
+            check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
         ConvParams p{};
         p.in = m.actv;
         p.wpk = a.spade_wpk;
@@ -385,7 +395,7 @@ struct Runner {
         p.pad = -1;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
-              4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(conv_ace(p, st), "spade conv"); });
+              4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
     }
 
     void conv(const ConvW& w, const float* in, float* out, int r, const float* res, int res_up) {
@@ -406,7 +416,8 @@ struct Runner {
         const double npix = (double)B * r * r, k2 = w.KS * w.KS;
         timed(0, 2.0 * w.Cout * w.Cin * k2 * npix,
               4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * k2), [&] {
-                  check(w.KS == 3 ? conv_plain3(p, st) : conv_plain1(p, st), "conv");
+                  if (m.use_sh16) check(conv_sh16_plain(p, w.KS, st), "conv");
+                  else check(w.KS == 3 ? conv_plain3(p, st) : conv_plain1(p, st), "conv");
               });
     }
 };
@@ -450,7 +461,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             if (b.learned) {
                 R.ace(b.ace_s, lab, cd, nz, nf, noff, xsrc, up, ACT_NONE, hs);
                 noff += rr;
-                R.tap(b.name + ".hs", hs, (size_t)B * b.fin * rr);
+                R.tap_sh16(b.name + ".hs", hs, b.fin, rr);
                 R.conv(b.conv_s, hs, xs, r, nullptr, 0);
                 R.tap(b.name + ".xs", xs, (size_t)B * b.fout * rr);
                 shortcut = xs;
@@ -461,12 +472,12 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             }
             R.ace(b.ace_0, lab, cd, nz, nf, noff, xsrc, up, ACT_LRELU, h0);
             noff += rr;
-            R.tap(b.name + ".h0", h0, (size_t)B * b.fin * rr);
+            R.tap_sh16(b.name + ".h0", h0, b.fin, rr);
             R.conv(b.conv_0, h0, dx, r, nullptr, 0);
             R.tap(b.name + ".dx", dx, (size_t)B * b.fmid * rr);
             R.ace(b.ace_1, lab, cd, nz, nf, noff, dx, 0, ACT_LRELU, h1);
             noff += rr;
-            R.tap(b.name + ".h1", h1, (size_t)B * b.fmid * rr);
+            R.tap_sh16(b.name + ".h1", h1, b.fmid, rr);
             R.conv(b.conv_1, h1, y, r, shortcut, sc_up);
             R.tap(b.name, y, (size_t)B * b.fout * rr);
             std::swap(x, y);

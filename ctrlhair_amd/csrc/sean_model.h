@@ -46,6 +46,7 @@ struct ProfRec {
 
 struct SeanModel {
     int ngf = 0, max_batch = 0, max_size = 0;
+    bool use_sh16 = false;     // generator convs on the f16x3 split-operand MFMA path (conv_sh16.h)
     std::vector<BlockW> blocks;
     float *fc_table = nullptr, *fc_bias = nullptr;     // fc conv as label LUT [19*9][16ngf]
     float *img_w = nullptr, *img_b = nullptr;          // conv_img raw [3][ngf][3][3]

@@ -20,6 +20,7 @@ SYMBOLS = {
     'ch_destroy': (None, [_VP]),
     'ch_last_error': (C.c_char_p, [_VP]),
     'ch_load_tensor': (_I, [_VP, _I, C.c_char_p, _VP, _I, C.POINTER(C.c_int64), _I]),
+    'ch_set_option': (_I, [_VP, C.c_char_p, _I]),
     'ch_finalize': (_I, [_VP, _I, _I, _I]),
     'ch_sean_noise_floats': (C.c_size_t, [_VP, _I]),
     'ch_sean_generate': (_I, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _I, _I, _VP]),
@@ -86,6 +87,9 @@ class Handle:
         shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
         self._check(self.lib.ch_load_tensor(self._h, model, name.encode(), a.ctypes.data_as(_VP), dt, shape, a.ndim),
                     f'ch_load_tensor({name})')
+
+    def set_option(self, key: str, value: int):
+        self._check(self.lib.ch_set_option(self._h, key.encode(), int(value)), f'ch_set_option({key})')
 
     def finalize(self, model: int, max_batch: int, max_size: int):
         self._check(self.lib.ch_finalize(self._h, model, max_batch, max_size), 'ch_finalize')

@@ -13,7 +13,8 @@ from .. import lib as _lib
 
 
 class SeanGenerator:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, f16x3: bool = False):
+        self.f16x3 = f16x3
         self.device_index = device
         self.device = torch.device('cuda', device)
         self.handle = _lib.Handle(device)
@@ -27,6 +28,7 @@ class SeanGenerator:
             if a.dtype not in (np.float32, np.int64):
                 a = a.astype(np.float32)
             self.handle.load_tensor(_lib.MODEL_SEAN, k, a)
+        self.handle.set_option('sean.f16x3', int(self.f16x3))
         self.handle.finalize(_lib.MODEL_SEAN, max_batch, max_size)
         self.max_batch, self.max_size = max_batch, max_size
         return self

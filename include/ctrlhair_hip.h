@@ -53,6 +53,11 @@ const char* ch_last_error(const ch_handle* h);
 int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host, int dtype,
                     const int64_t* shape, int ndim);
 
+/* Options, set before ch_finalize.  "sean.f16x3" (0/1, default 0): run the SEAN generator's MFMA convolutions on the
+ * f16 matrix cores with the 3-term split-operand scheme of ctrlhair_amd/csrc/conv_sh16.h (f32-class accuracy, f32
+ * accumulation; activations between ACE and conv stored as f16 hi/lo pairs) instead of the exact-f32 MFMA kernel. */
+int  ch_set_option(ch_handle* h, const char* key, int value);
+
 /* Fold + pack + upload the loaded tensors: spectral-norm sigma (torch spectral_norm eval semantics,
  * architecture.py:42-46), eval-BN running stats -> per-channel affine (sync_batchnorm/batchnorm.py:52-55),
  * sigmoid(blending) folded into the SPADE / style weights (normalization.py:177-181), one-hot convs -> label

@@ -10,9 +10,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def _gen(sd, max_batch, max_size):
+PATHS = ['f32', 'f16x3']     # exact-f32 MFMA kernel | 3-term split-operand f16 MFMA kernel (conv_sh16.h)
+
+
+def _gen(sd, max_batch, max_size, f16x3=False):
     from ctrlhair_amd.sean.generator import SeanGenerator
-    return SeanGenerator(0).load_state_dict(sd, max_batch=max_batch, max_size=max_size)
+    return SeanGenerator(0, f16x3=f16x3).load_state_dict(sd, max_batch=max_batch, max_size=max_size)
 
 
 def _run(gen, labels, codes, noise):
@@ -26,15 +29,21 @@ def _run(gen, labels, codes, noise):
 _gens = {}
 
 
-def gen_for(ngf, wseed=0):
-    key = (ngf, wseed)
+_sds = {}
+
+
+def gen_for(ngf, wseed=0, path='f32'):
+    key = (ngf, wseed, path)
     if key not in _gens:
         from ctrlhair_amd import procedural as P
-        _gens[key] = _gen(P.sean_state_dict(wseed, ngf), 4 if ngf == 64 else 8, 512 if ngf == 64 else 128)
+        if (ngf, wseed) not in _sds:
+            _sds[(ngf, wseed)] = P.sean_state_dict(wseed, ngf)
+        _gens[key] = _gen(_sds[(ngf, wseed)], 4 if ngf == 64 else 8, 512 if ngf == 64 else 128, f16x3=(path == 'f16x3'))
     return _gens[key]
 
 
-def test_stagewise_tiny_vs_oracle(hip_lib):
+@pytest.mark.parametrize('path', PATHS)
+def test_stagewise_tiny_vs_oracle(hip_lib, path):
     """ngf=16, S=64, B=3: every intermediate stage against the oracle (localises a wrong kernel)."""
     from ctrlhair_amd import procedural as P
     from ctrlhair_amd.sean import arch
@@ -44,7 +53,7 @@ def test_stagewise_tiny_vs_oracle(hip_lib):
     labels, codes, noise = P.blocky_labels(B, S, grid=8), P.style_codes(B), P.noise_planes(B, S, ngf)
     taps = {}
     ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf, taps=taps).numpy()
-    gen = gen_for(ngf)
+    gen = gen_for(ngf, path=path)
     bufs = {}
     for name, t in taps.items():
         bufs[name] = torch.zeros(t.shape, dtype=torch.float32, device=gen.device)
@@ -61,21 +70,23 @@ def test_stagewise_tiny_vs_oracle(hip_lib):
     assert np.abs(out - ref).max() <= TOL
 
 
+@pytest.mark.parametrize('path', PATHS)
 @pytest.mark.parametrize('name', SEAN_CASES)
-def test_golden(hip_lib, name):
+def test_golden(hip_lib, name, path):
     c = Case(name)
-    gen = gen_for(c.ngf, c.wseed)
+    gen = gen_for(c.ngf, c.wseed, path)
     img = _run(gen, c.labels, c.codes, c.noise)
     assert np.isfinite(img).all()
     assert c.max_abs_diff(img) <= TOL
 
 
-def test_batch_chunking_and_determinism(hip_lib):
+@pytest.mark.parametrize('path', PATHS)
+def test_batch_chunking_and_determinism(hip_lib, path):
     """B > max_batch is processed in chunks; same inputs -> bitwise identical output run to run; sample i of a
     batch equals the same sample run alone (no cross-sample op anywhere on the path)."""
     from ctrlhair_amd import procedural as P
     ngf, S, B = 16, 64, 11
-    gen = gen_for(ngf)   # max_batch 8
+    gen = gen_for(ngf, path=path)   # max_batch 8
     labels, codes, noise = P.blocky_labels(B, S, grid=8, seed=5), P.style_codes(B, seed=6), P.noise_planes(B, S, ngf, seed=7)
     a = _run(gen, labels, codes, noise)
     b = _run(gen, labels, codes, noise)
@@ -84,12 +95,25 @@ def test_batch_chunking_and_determinism(hip_lib):
     assert np.abs(one[0] - a[9]).max() <= 1e-6
 
 
-def test_full_size_properties(hip_lib):
+def test_f16x3_close_to_exact_f32(hip_lib):
+    """The split-operand path must agree with the exact-f32 MFMA path far inside the parity tolerance."""
+    from ctrlhair_amd import procedural as P
+    ngf, S, B = 64, 256, 2
+    labels, codes, noise = P.blocky_labels(B, S), P.style_codes(B), P.noise_planes(B, S, ngf)
+    a = _run(gen_for(ngf, path='f32'), labels, codes, noise)
+    b = _run(gen_for(ngf, path='f16x3'), labels, codes, noise)
+    d = np.abs(a - b)
+    print('f16x3 vs f32: max', d.max(), 'mean', d.mean())
+    assert d.max() <= 1e-4
+
+
+@pytest.mark.parametrize('path', PATHS)
+def test_full_size_properties(hip_lib, path):
     """S=512 at ngf=64 (BASELINE config size, B=2): finite, tanh-bounded, not saturated, and a label-region edit
     only changes pixels within the receptive field of that region (locality property)."""
     from ctrlhair_amd import procedural as P
     ngf, S, B = 64, 512, 2
-    gen = gen_for(ngf)
+    gen = gen_for(ngf, path=path)
     labels, codes, noise = P.blocky_labels(B, S), P.style_codes(B), P.noise_planes(B, S, ngf)
     img = _run(gen, labels, codes, noise)
     assert np.isfinite(img).all() and np.abs(img).max() <= 1.0
