@@ -60,9 +60,10 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ngf', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--path', choices=('f32', 'f16x3'), default='f16x3',
+    ap.add_argument('--path', choices=('f32', 'f16x3', 'f16x3v2'), default='f16x3',
                     help='conv arithmetic: f16x3 = 3-term split-operand f16 MFMA, f32 accumulate, f32-class accuracy '
                          '(default; max |delta| vs the exact path 1.5e-5); f32 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32)')
+    ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -85,7 +86,9 @@ def main():
     from ctrlhair_amd.sean.generator import SeanGenerator
     B, S, ngf = args.batch, args.size, args.ngf
     sd = P.sean_state_dict(0, ngf)
-    gen = SeanGenerator(local_rank, f16x3=(args.path == 'f16x3')).load_state_dict(sd, max_batch=B, max_size=S)
+    gen = SeanGenerator(local_rank, f16x3={'f32': 0, 'f16x3': 1, 'f16x3v2': 2}[args.path]).load_state_dict(sd, max_batch=B, max_size=S)
+    if args.dbg:
+        gen.handle.set_option('sean.dbg', args.dbg)
     first = rank * B     # global sample index offset (SURVEY.md 8d Config 4)
     labels = torch.from_numpy(P.blocky_labels(B, S, first=first)).to(dev)
     codes = torch.from_numpy(P.style_codes(B, first=first)).to(dev)
@@ -121,14 +124,14 @@ def main():
     prof_ace = gen.handle.profile_read(1)
     prof_plain = gen.handle.profile_read(0)
     prof_all = gen.handle.profile_read(-1)
-    assert torch.isfinite(out).all()
+    assert args.dbg or torch.isfinite(out).all()
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         # algorithmic (f32-equivalent) conv FLOP/s of the dominant kernel, hipEvent-timed per launch inside the library
         alg = prof_ace['flops'] / (prof_ace['ms'] * 1e-3) / 1e12 if prof_ace['ms'] > 0 else 0.0
-        if args.path == 'f16x3':
+        if args.path.startswith('f16x3'):
             # every f32 product is executed as 3 f16 MFMA products: utilisation is priced on executed MFMA FLOPs
             executed, peak = 3.0 * alg, PEAK_F16_MFMA_TFLOPS
             kname = 'conv_sh16_kernel<KS=3,...,EPI_ACE> (SPADE gamma/beta conv, f16x3 split operands, fused ACE epilogue)'

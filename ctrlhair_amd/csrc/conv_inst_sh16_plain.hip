@@ -3,6 +3,10 @@
 namespace chk {
 template <int KS>
 static hipError_t go(const ConvParams& p, hipStream_t s) {
+    if (p.zeros) {   // v2: LDS-DMA ring, one block per CU
+        if (p.W >= 32) return launch_sh16v2<KS, 32, 16, 1, EPI_PLAIN>(p, p.Mrows, s);
+        if (p.W > 8) return launch_sh16v2<KS, 16, 16, 2, EPI_PLAIN>(p, p.Mrows, s);
+    }
     if (p.W >= 32) return launch_sh16<KS, 32, 16, 1, EPI_PLAIN>(p, p.Mrows, s);
     if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN>(p, p.Mrows, s);
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN>(p, p.Mrows, s);

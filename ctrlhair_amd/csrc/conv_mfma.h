@@ -65,6 +65,8 @@ struct ConvParams {
     long long noise_bstride;
     const uint8_t* lab;     // [B][H][W]
     const float* lut;       // [B*19][9][2][C] or null (unstyled)
+    int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
+    const void* zeros;      // >= 16 zero bytes in device memory (source of out-of-image units for the LDS-DMA path)
     // EPI_NHWC
     int npix_valid;         // number of valid linear pixels (y*W+x < npix_valid)
 };
@@ -144,6 +146,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int Wl = p.in_mode == IN_DIRECT ? p.Win : 2 * p.Win;
     const int HWin = p.Hin * p.Win;
     auto stage = [&](int chunk, int buf) {
+        // No scheduling fence in here on purpose: the compiler issues these loads early and sinks the LDS writes
+        // below the chunk's MFMAs as far as registers allow, which is what overlaps staging with compute.
         float stg[NLOAD];
         const float* src = p.in + ((long long)b0 * p.Cin + (long long)chunk * CK) * HWin;
 #pragma unroll
@@ -292,21 +296,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll 1
                 for (int t = 0; t < 9; ++t) {
                     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                        const int j = lb[yy * p.W + xx];
-                        const float* Lp = p.lut + ((long long)(b * 19 + j) * 9 + t) * (2 * C);
+                    const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                    const int j = lb[in ? yy * p.W + xx : 0];
+                    const float w = in ? 1.f : 0.f;
+                    const float* Lp = p.lut + ((long long)(b * 19 + j) * 9 + t) * (2 * C);
 #pragma unroll
-                        for (int rq = 0; rq < 4; ++rq) {
-                            const int c4 = mtile64 * 32 + 8 * rq + 4 * hi;
-                            if (c4 < C) {   // C % 4 == 0
-                                const float4 g4 = *reinterpret_cast<const float4*>(Lp + c4);
-                                const float4 b4 = *reinterpret_cast<const float4*>(Lp + C + c4);
-                                sg[rq * 4 + 0] += g4.x; sg[rq * 4 + 1] += g4.y;
-                                sg[rq * 4 + 2] += g4.z; sg[rq * 4 + 3] += g4.w;
-                                sbt[rq * 4 + 0] += b4.x; sbt[rq * 4 + 1] += b4.y;
-                                sbt[rq * 4 + 2] += b4.z; sbt[rq * 4 + 3] += b4.w;
-                            }
-                        }
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int c4 = mtile64 * 32 + 8 * rq + 4 * hi;
+                        const int cc = c4 < C ? c4 : 0;               // clamped, rows >= C are never stored
+                        const float4 g4 = *reinterpret_cast<const float4*>(Lp + cc);
+                        const float4 b4 = *reinterpret_cast<const float4*>(Lp + C + cc);
+                        sg[rq * 4 + 0] += w * g4.x; sg[rq * 4 + 1] += w * g4.y;
+                        sg[rq * 4 + 2] += w * g4.z; sg[rq * 4 + 3] += w * g4.w;
+                        sbt[rq * 4 + 0] += w * b4.x; sbt[rq * 4 + 1] += w * b4.y;
+                        sbt[rq * 4 + 2] += w * b4.z; sbt[rq * 4 + 3] += w * b4.w;
                     }
                 }
             }
@@ -315,15 +318,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = mtile64 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (c < C) {
-                    const float gam = acc[0][n][r] + p.bias_g[c] + sg[r];
-                    const float bet = acc[1][n][r] + p.bias_b[c] + sbt[r];
-                    const float xv = p.x[((long long)b * C + c) * (xW * xH) + xpix];
-                    const float nrm = p.bn_a[c] * xv + p.nv[c] * nz + p.bn_d[c];
-                    float o = nrm * (1.f + gam) + bet;
-                    o = apply_act(o, p.act);
-                    p.out[((long long)b * C + c) * HW + (long long)y * p.W + x] = o;
-                }
+                const int cc = c < C ? c : 0;
+                const float gam = acc[0][n][r] + p.bias_g[cc] + sg[r];
+                const float bet = acc[1][n][r] + p.bias_b[cc] + sbt[r];
+                const float xv = p.x[((long long)b * C + cc) * (xW * xH) + xpix];
+                const float nrm = p.bn_a[cc] * xv + p.nv[cc] * nz + p.bn_d[cc];
+                float o = nrm * (1.f + gam) + bet;
+                o = apply_act(o, p.act);
+                if (c < C) p.out[((long long)b * C + c) * HW + (long long)y * p.W + x] = o;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -37,6 +37,144 @@ struct ShCfg {
     static_assert(TW * TH * TB == 512, "block tile is 512 pixels");
 };
 
+template <int TW, int TH, int TB, int EPI>
+__device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)[2][4], int mtile64, int wn, int lane,
+                                              int x0, int y0, int b0) {
+    const int HW = p.H * p.W;
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // Per-channel parameters are loaded ONCE per wave as float4 (a lane's 16 rows are 4 runs of 4 consecutive
+    // channels), not per pixel: the per-(pixel,row) scalar loads were ~3/4 of the epilogue's VMEM instructions.
+    const int hi = lane >> 5, col = lane & 31;
+    if (EPI == EPI_PLAIN) {
+        float4 bias4[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
+                bias4[m][rq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) {
+                    if (row0 + 3 < p.Mrows) bias4[m][rq] = *reinterpret_cast<const float4*>(p.bias + row0);
+                    else {
+                        float t[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int e = 0; e < 4; ++e) if (row0 + e < p.Mrows) t[e] = p.bias[row0 + e];
+                        bias4[m][rq] = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int idx = wn * 128 + n * 32 + col;
+            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+            const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+            if (b >= p.B || y >= p.H || x >= p.W) continue;
+            const long long pix = (long long)y * p.W + x;
+            const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
+            const long long rpix = (long long)(y >> p.res_up) * rW + (x >> p.res_up);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mtile64 * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < p.Mrows) {
+                        const float4 b4 = bias4[m][r >> 2];
+                        const float bv = (r & 3) == 0 ? b4.x : ((r & 3) == 1 ? b4.y : ((r & 3) == 2 ? b4.z : b4.w));
+                        float v = acc[m][n][r] + bv;
+                        float rv = 0.f;
+                        if (p.res) rv = p.res[((long long)b * p.Mrows + row) * (rW * rH) + rpix];
+                        v = p.res_after_act ? apply_act(v, p.act) + rv : apply_act(v + rv, p.act);
+                        p.out[((long long)b * p.Mrows + row) * HW + pix] = v;
+                    }
+                }
+        }
+    } else {  // EPI_ACE -> SH16 output.  Loop order: channel-run (rq) outer so that only one run's parameters
+              // (5 float4) are live; pixel coordinates / noise / packed 3x3 label neighbourhoods are kept per n.
+        const int C = p.C;
+        const int Go = (C + 7) >> 3;
+        const int xW = p.W >> p.x_up, xH = p.H >> p.x_up;
+        _Float16* oh = reinterpret_cast<_Float16*>(p.out);
+        int pb_[4], py_[4], px_[4];
+        float nzv[4];
+        unsigned long long labs[4];          // 9 neighbour labels x 5 bits (31 = outside the image)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int idx = wn * 128 + n * 32 + col;
+            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+            const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+            const bool ok = b < p.B && y < p.H && x < p.W;
+            pb_[n] = ok ? b : -1;
+            py_[n] = y;
+            px_[n] = x;
+            nzv[n] = p.noise[ok ? (long long)b * p.noise_bstride + (long long)x * p.H + y : 0];
+            unsigned long long lv = 0;
+            if (p.lut && ok) {
+                const uint8_t* lb = p.lab + (long long)b * HW;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                    const unsigned jv = lb[in ? yy * p.W + xx : 0];       // unconditional load, select after
+                    lv |= (unsigned long long)(in ? jv : 31u) << (5 * t);
+                }
+            }
+            labs[n] = lv;
+        }
+        auto comp = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int g = mtile64 * 4 + rq;                  // output channel group (8 channels)
+            const int c0 = g * 8 + 4 * hi;                   // this lane's 4 consecutive channels (C % 4 == 0)
+            if (g >= Go) continue;
+            const bool cok = c0 < C;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 pg = cok ? *reinterpret_cast<const float4*>(p.bias_g + c0) : z4;
+            const float4 pb = cok ? *reinterpret_cast<const float4*>(p.bias_b + c0) : z4;
+            const float4 pa = cok ? *reinterpret_cast<const float4*>(p.bn_a + c0) : z4;
+            const float4 pd = cok ? *reinterpret_cast<const float4*>(p.bn_d + c0) : z4;
+            const float4 pn = cok ? *reinterpret_cast<const float4*>(p.nv + c0) : z4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int b = pb_[n], y = py_[n], x = px_[n];
+                if (b < 0) continue;
+                float4 sg = z4, sb = z4;
+                if (p.lut && cok) {
+                    const float* Lb = p.lut + (long long)b * 19 * 9 * (2 * C) + c0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const unsigned j = (unsigned)(labs[n] >> (5 * t)) & 31u;
+                        const float w = j < 19u ? 1.f : 0.f;             // outside the image: contributes 0
+                        const float* Lp = Lb + (long long)((j < 19u ? j : 0u) * 9 + t) * (2 * C);
+                        const float4 g4 = *reinterpret_cast<const float4*>(Lp);
+                        const float4 b4 = *reinterpret_cast<const float4*>(Lp + C);
+                        sg.x += w * g4.x; sg.y += w * g4.y; sg.z += w * g4.z; sg.w += w * g4.w;
+                        sb.x += w * b4.x; sb.y += w * b4.y; sb.z += w * b4.z; sb.w += w * b4.w;
+                    }
+                }
+                const long long xpix = (long long)(y >> p.x_up) * xW + (x >> p.x_up);
+                half4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rq * 4 + e;
+                    const int cc = c0 + e < C ? c0 + e : 0;            // clamped: load unconditionally
+                    const float gam = acc[0][n][r] + comp(pg, e) + comp(sg, e);
+                    const float bet = acc[1][n][r] + comp(pb, e) + comp(sb, e);
+                    const float xv = p.x[((long long)b * C + cc) * (xW * xH) + xpix];
+                    const float nrm = comp(pa, e) * xv + comp(pn, e) * nzv[n] + comp(pd, e);
+                    float o = apply_act(nrm * (1.f + gam) + bet, p.act);
+                    o = c0 + e < C ? o : 0.f;
+                    const _Float16 h = (_Float16)o;
+                    vh[e] = h;
+                    vl[e] = (_Float16)(o - (float)h);
+                }
+                const long long unit = (((long long)b * Go + g) * 2) * HW + (long long)y * p.W + x;
+                *reinterpret_cast<half4*>(oh + unit * 8 + 4 * hi) = vh;
+                *reinterpret_cast<half4*>(oh + (unit + HW) * 8 + 4 * hi) = vl;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // in : SH16 [B][Cin/8][2][H][W][8]   (Cin % 16 == 0; padding channels hold zeros)
 // EPI_PLAIN -> out f32 NCHW [B][Mrows][H][W] (bias / residual / act as conv_mfma)
 // EPI_ACE   -> out SH16 [B][ceil(C/8)][2][H][W][8]  (the fused ACE epilogue of conv_mfma.h, re-split for the next conv)
@@ -74,23 +212,28 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const uint4* gin = reinterpret_cast<const uint4*>(p.in);
-    auto stage = [&](int chunk, int buf) {
-        uint4 stg[NLOAD];
+    // per-thread source offsets of its NLOAD patch units (chunk-invariant part), -1 = outside the image -> zeros.
+    // Hoisted out of the chunk loop: the decode (3 div/mod per unit) was ~half of the kernel's VALU issue.
+    int soff[NLOAD];
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            int u = tid + i * 256;
-            asm volatile("" : "+v"(u));
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (u < UNITS) {
-                const int gh = u / PLANE, rem = u % PLANE;          // gh = group*2 + hl
-                const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
-                const int y = y0 + py - HALO, x = x0 + px - HALO, b = b0 + tb;
-                const int g = chunk * 2 + (gh >> 1);
-                if (b < p.B && g < G && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                    v = gin[(((long long)b * G + g) * 2 + (gh & 1)) * HW + y * p.W + x];
-            }
-            stg[i] = v;
+    for (int i = 0; i < NLOAD; ++i) {
+        const int u = tid + i * 256;
+        soff[i] = -1;
+        if (u < UNITS) {
+            const int gh = u / PLANE, rem = u % PLANE;          // gh = group*2 + hl
+            const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
+            const int y = y0 + py - HALO, x = x0 + px - HALO, b = b0 + tb;
+            if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
         }
+    }
+    auto stage = [&](int chunk, int buf) {
+        // No scheduling fence in here on purpose: the compiler issues these loads early and sinks the LDS writes
+        // below the chunk's MFMAs as far as registers allow, which is what overlaps staging with compute.
+        uint4 stg[NLOAD];
+        const uint4* src = gin + (long long)chunk * 4 * HW;       // 2 groups x (hi, lo) planes per chunk
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
         uint4* dst = smem_u + buf * UNITS;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
@@ -106,8 +249,9 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     __syncthreads();
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
-        if (ch + 1 < p.nchunks) stage(ch + 1, (ch + 1) & 1);
+        if (ch + 1 < p.nchunks && !(p.dbg & 1)) stage(ch + 1, (ch + 1) & 1);
         const uint4* sb = smem_u + (ch & 1) * UNITS;
+        if (p.dbg & 2) { __syncthreads(); continue; }
         const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
         uint4 a_cur[4];
 #pragma unroll
@@ -148,100 +292,153 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------
-    const int hi = lane >> 5, col = lane & 31;
-    if (EPI == EPI_PLAIN) {
+    sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// v2: same arithmetic and layouts, different data movement.  ONE block per CU (4 waves, one per SIMD, up to 512 VGPRs):
+// both operands of a 16-channel chunk -- the input patch AND the block's A fragments -- are moved HBM/L2 -> LDS by the
+// LDS-DMA path (global_load_lds, 16 B per lane, no VGPR round trip) one whole chunk ahead into a 2-stage ring, so the
+// only instructions between MFMAs are ds_read_b128 of fragments and the DMA issues; HBM latency is covered by a full
+// chunk of MFMA work (9 k-steps x 24 MFMAs per wave) instead of by a second resident block.
+// Out-of-image patch units are fetched from a 16-byte zero page (the DMA has no per-lane predicate for "write zero").
+template <int KS, int TW, int TH, int TB>
+struct ShCfg2 : ShCfg<KS, TW, TH, TB> {
+    static constexpr int AUNITS = KS * KS * 4 * 64;                       // A fragments of one chunk (16-byte units)
+    static constexpr int STAGE = ShCfg<KS, TW, TH, TB>::UNITS + AUNITS;   // units per ring stage
+    static constexpr int LDS_BYTES2 = 2 * STAGE * 16;
+    static_assert(LDS_BYTES2 <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+template <int KS, int TW, int TH, int TB, int EPI>
+__global__ __launch_bounds__(256, 1) void conv_sh16v2_kernel(const ConvParams p) {
+    using Cfg = ShCfg2<KS, TW, TH, TB>;
+    constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, HALO = Cfg::HALO;
+    constexpr int NT = KS * KS, AUNITS = Cfg::AUNITS, STAGE = Cfg::STAGE;
+    constexpr int NPATCH = (UNITS + 63) / 64, NA = AUNITS / 64;          // wave-instructions per chunk
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile64 = L % p.mtiles;
+    int nt = L / p.mtiles;
+    const int txi = nt % p.tiles_x; nt /= p.tiles_x;
+    const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
+    const int x0 = txi * TW, y0 = tyi * TH, b0 = nt * TB;
+    const int HW = p.H * p.W;
+    const int G = p.Cin >> 3;
+
+    int ub[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int idx = wn * 128 + n * 32 + col;
-            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-            const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
-            if (b >= p.B || y >= p.H || x >= p.W) continue;
-            const long long pix = (long long)y * p.W + x;
-            const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
-            const long long rpix = (long long)(y >> p.res_up) * rW + (x >> p.res_up);
+    for (int n = 0; n < 4; ++n) {
+        const int idx = wn * 128 + n * 32 + (lane & 31);
+        const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+        ub[n] = (lane >> 5) * 2 * PLANE + tb * (PH * PW) + ty * PW + tx;
+    }
+
+    f32x16 acc[2][4];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mtile64 * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < p.Mrows) {
-                        float v = acc[m][n][r];
-                        if (p.bias) v += p.bias[row];
-                        float rv = 0.f;
-                        if (p.res) rv = p.res[((long long)b * p.Mrows + row) * (rW * rH) + rpix];
-                        v = p.res_after_act ? apply_act(v, p.act) + rv : apply_act(v + rv, p.act);
-                        p.out[((long long)b * p.Mrows + row) * HW + pix] = v;
-                    }
-                }
-        }
-    } else {  // EPI_ACE -> SH16 output
-        const int C = p.C;
-        const int Go = (C + 7) >> 3;
-        const int xW = p.W >> p.x_up, xH = p.H >> p.x_up;
-        _Float16* oh = reinterpret_cast<_Float16*>(p.out);
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int idx = wn * 128 + n * 32 + col;
-            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-            const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
-            if (b >= p.B || y >= p.H || x >= p.W) continue;
-            float sg[16], sbt[16];
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const uint4* gin = reinterpret_cast<const uint4*>(p.in);
+    const uint4* gA = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * AUNITS;
+    const uint4* gzero = reinterpret_cast<const uint4*>(p.zeros);
+
+    // DMA instruction k (0 .. NDMA-1) of this wave for `chunk` into ring stage `st`: wave w owns patch instructions
+    // w, w+4, ... and A instructions w, w+4, ....  Source offsets are chunk-invariant and precomputed (doff).
+    constexpr int NPW = (NPATCH + 3) / 4, NAW = (NA + 3) / 4, NDMA = NPW + NAW;
+    int doff[NPW];      // -1: outside the image (zero page), -2: no instruction / lane inactive
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sg[r] = 0.f; sbt[r] = 0.f; }
-            if (p.lut) {
-                const uint8_t* lb = p.lab + (long long)b * HW;
-#pragma unroll 1
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                        const int j = lb[yy * p.W + xx];
-                        const float* Lp = p.lut + ((long long)(b * 19 + j) * 9 + t) * (2 * C);
-#pragma unroll
-                        for (int rq = 0; rq < 4; ++rq) {
-                            const int c4 = mtile64 * 32 + 8 * rq + 4 * hi;
-                            if (c4 < C) {
-                                const float4 g4 = *reinterpret_cast<const float4*>(Lp + c4);
-                                const float4 b4 = *reinterpret_cast<const float4*>(Lp + C + c4);
-                                sg[rq * 4 + 0] += g4.x; sg[rq * 4 + 1] += g4.y;
-                                sg[rq * 4 + 2] += g4.z; sg[rq * 4 + 3] += g4.w;
-                                sbt[rq * 4 + 0] += b4.x; sbt[rq * 4 + 1] += b4.y;
-                                sbt[rq * 4 + 2] += b4.z; sbt[rq * 4 + 3] += b4.w;
-                            }
-                        }
-                    }
-                }
-            }
-            const float nz = p.noise[(long long)b * p.noise_bstride + (long long)x * p.H + y];
-            const long long xpix = (long long)(y >> p.x_up) * xW + (x >> p.x_up);
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int g = mtile64 * 4 + rq;              // output channel group (8 channels)
-                if (g >= Go) continue;
-                half4 vh, vl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = rq * 4 + e;
-                    const int c = g * 8 + 4 * hi + e;
-                    float o = 0.f;
-                    if (c < C) {
-                        const float gam = acc[0][n][r] + p.bias_g[c] + sg[r];
-                        const float bet = acc[1][n][r] + p.bias_b[c] + sbt[r];
-                        const float xv = p.x[((long long)b * C + c) * (xW * xH) + xpix];
-                        const float nrm = p.bn_a[c] * xv + p.nv[c] * nz + p.bn_d[c];
-                        o = apply_act(nrm * (1.f + gam) + bet, p.act);
-                    }
-                    const _Float16 h = (_Float16)o;
-                    vh[e] = h;
-                    vl[e] = (_Float16)(o - (float)h);
-                }
-                const long long unit = (((long long)b * Go + g) * 2) * HW + (long long)y * p.W + x;
-                *reinterpret_cast<half4*>(oh + unit * 8 + 4 * hi) = vh;
-                *reinterpret_cast<half4*>(oh + (unit + HW) * 8 + 4 * hi) = vl;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < NPW; ++k) {
+        const int ins = wn + k * 4, u = ins * 64 + lane;
+        doff[k] = -2;
+        if (ins < NPATCH && u < UNITS) {
+            const int gh = u / PLANE, rem = u % PLANE;
+            const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
+            const int y = y0 + py - HALO, x = x0 + px - HALO, b = b0 + tb;
+            doff[k] = -1;
+            if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                doff[k] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
         }
     }
+    auto dma_one = [&](int chunk, int st, int k) {
+        uint4* base = smem_u + st * STAGE;
+        if (k < NPW) {
+            const int ins = wn + k * 4;
+            if (doff[k] != -2) {
+                const uint4* src = doff[k] >= 0 ? gin + (long long)chunk * 4 * HW + doff[k] : gzero;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + ins * 64), 16, 0, 0);
+            }
+        } else {
+            const int ins = wn + (k - NPW) * 4;
+            if (ins < NA)
+                __builtin_amdgcn_global_load_lds((glb_void*)(gA + (long long)chunk * AUNITS + ins * 64 + lane),
+                                                 (lds_void*)(base + UNITS + ins * 64), 16, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) dma_one(0, 0, k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        if (ch + 1 < p.nchunks && !(p.dbg & 1)) {
+#pragma unroll
+            for (int k = 0; k < NDMA; ++k) dma_one(ch + 1, (ch + 1) & 1, k);
+        }
+        if (p.dbg & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); continue; }
+        const uint4* sb = smem_u + (ch & 1) * STAGE;
+        const uint4* sa = sb + UNITS + lane;
+        uint4 a_cur[4], bh[4], bl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_cur[q] = sa[q * 64];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            bh[n] = sb[ub[n]];
+            bl[n] = sb[ub[n] + PLANE];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // Hand-ordered software pipeline, pinned with sched_barrier: group i = {1 fragment read of k-step t+1,
+            // 2 MFMAs of k-step t}; consecutive MFMAs hit different accumulators (term-major order).
+            uint4 a_nxt[4], bhn[4], bln[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a_nxt[q] = a_cur[q]; bhn[q] = bh[q]; bln[q] = bl[q]; }
+            const int koff = ((t + 1) / KS) * PW + ((t + 1) % KS);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                if (t + 1 < NT) {
+                    if (i < 4) a_nxt[i] = sa[((t + 1) * 4 + i) * 64];
+                    else if ((i & 1) == 0) bhn[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff];
+                    else bln[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff + PLANE];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * i + jj, term = j >> 3, m = (j & 7) >> 2, n = j & 3;
+                    const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
+                    const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
+                    const half8 xh = __builtin_bit_cast(half8, bh[n]);
+                    const half8 xl = __builtin_bit_cast(half8, bl[n]);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al : ah, term == 1 ? xl : xh, acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a_cur[q] = a_nxt[q]; bh[q] = bhn[q]; bl[q] = bln[q]; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
 }
 
 template <int KS, int TW, int TH, int TB, int EPI>
@@ -262,6 +459,27 @@ hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     p.tiles_b = (p.B + TB - 1) / TB;
     const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+template <int KS, int TW, int TH, int TB, int EPI>
+hipError_t launch_sh16v2(ConvParams p, int rows, hipStream_t stream) {
+    using Cfg = ShCfg2<KS, TW, TH, TB>;
+    auto kern = conv_sh16v2_kernel<KS, TW, TH, TB, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           Cfg::LDS_BYTES2);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.nchunks = (p.Cin + 15) / 16;
+    p.mtiles = (rows + 63) / 64;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.tiles_b = (p.B + TB - 1) / TB;
+    const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES2, stream, p);
     return hipGetLastError();
 }
 

@@ -236,6 +236,9 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         has_zencoder = true;
     }
 
+    zero_page = static_cast<float*>(B.dalloc(256));
+    if (zero_page) (void)hipMemset(zero_page, 0, 256);
+
     // ---- workspace arena --------------------------------------------------------------------------------
     const size_t MB = mb, S = ms;
     for (int k = 1; k <= 5; ++k) {   // res_div 2^k
@@ -393,6 +396,8 @@ struct Runner {
         p.lut = a.styled ? m.lut : nullptr;
         p.act = act;
         p.pad = -1;
+        p.zeros = m.sh16_mode == 2 ? m.zero_page : nullptr;
+        p.dbg = m.dbg;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
               4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
@@ -413,6 +418,8 @@ struct Runner {
         p.res_up = res_up;
         p.act = ACT_NONE;
         p.pad = -1;
+        p.zeros = m.sh16_mode == 2 ? m.zero_page : nullptr;
+        p.dbg = m.dbg;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS;
         timed(0, 2.0 * w.Cout * w.Cin * k2 * npix,
               4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * k2), [&] {

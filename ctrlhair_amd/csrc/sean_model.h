@@ -46,6 +46,9 @@ struct ProfRec {
 
 struct SeanModel {
     int ngf = 0, max_batch = 0, max_size = 0;
+    int sh16_mode = 0;         // 0 exact f32 | 1 f16x3 (register-staged, 2 blocks/CU) | 2 f16x3 v2 (LDS-DMA ring, 1 block/CU)
+    float* zero_page = nullptr;
+    int dbg = 0;               // perf experiments (conv_mfma.h ConvParams::dbg)
     bool use_sh16 = false;     // generator convs on the f16x3 split-operand MFMA path (conv_sh16.h)
     std::vector<BlockW> blocks;
     float *fc_table = nullptr, *fc_bias = nullptr;     // fc conv as label LUT [19*9][16ngf]
