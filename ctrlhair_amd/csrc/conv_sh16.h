@@ -62,6 +62,9 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                 }
             }
+        // f32 outputs of these convs use the "C4" layout [B][C/4][H][W][4]: a lane's 4 consecutive rows of one pixel are
+        // one float4, lanes run along x -> 512 contiguous bytes per half-wave store (and per residual load).
+        const int C4n = (p.Mrows + 3) >> 2;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
@@ -74,16 +77,23 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mtile64 * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < p.Mrows) {
-                        const float4 b4 = bias4[m][r >> 2];
-                        const float bv = (r & 3) == 0 ? b4.x : ((r & 3) == 1 ? b4.y : ((r & 3) == 2 ? b4.z : b4.w));
-                        float v = acc[m][n][r] + bv;
-                        float rv = 0.f;
-                        if (p.res) rv = p.res[((long long)b * p.Mrows + row) * (rW * rH) + rpix];
-                        v = p.res_after_act ? apply_act(v, p.act) + rv : apply_act(v + rv, p.act);
-                        p.out[((long long)b * p.Mrows + row) * HW + pix] = v;
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
+                    if (row0 < p.Mrows) {                       // Mrows % 4 == 0
+                        const float4 b4 = bias4[m][rq];
+                        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.res) rv = reinterpret_cast<const float4*>(p.res)[((long long)b * C4n + (row0 >> 2)) * (rW * rH) + rpix];
+                        float4 v;
+                        v.x = acc[m][n][rq * 4 + 0] + b4.x; v.y = acc[m][n][rq * 4 + 1] + b4.y;
+                        v.z = acc[m][n][rq * 4 + 2] + b4.z; v.w = acc[m][n][rq * 4 + 3] + b4.w;
+                        if (p.res_after_act) {
+                            v.x = apply_act(v.x, p.act) + rv.x; v.y = apply_act(v.y, p.act) + rv.y;
+                            v.z = apply_act(v.z, p.act) + rv.z; v.w = apply_act(v.w, p.act) + rv.w;
+                        } else {
+                            v.x = apply_act(v.x + rv.x, p.act); v.y = apply_act(v.y + rv.y, p.act);
+                            v.z = apply_act(v.z + rv.z, p.act); v.w = apply_act(v.w + rv.w, p.act);
+                        }
+                        reinterpret_cast<float4*>(p.out)[((long long)b * C4n + (row0 >> 2)) * HW + pix] = v;
                     }
                 }
         }
@@ -151,14 +161,15 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                 }
                 const long long xpix = (long long)(y >> p.x_up) * xW + (x >> p.x_up);
+                // x in the C4 layout [B][C/4][h][w][4]: this lane's 4 channels of the pixel are one float4
+                const float4 x4 = reinterpret_cast<const float4*>(p.x)[((long long)b * (C >> 2) + ((cok ? c0 : 0) >> 2)) * (xW * xH) + xpix];
                 half4 vh, vl;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = rq * 4 + e;
-                    const int cc = c0 + e < C ? c0 + e : 0;            // clamped: load unconditionally
                     const float gam = acc[0][n][r] + comp(pg, e) + comp(sg, e);
                     const float bet = acc[1][n][r] + comp(pb, e) + comp(sb, e);
-                    const float xv = p.x[((long long)b * C + cc) * (xW * xH) + xpix];
+                    const float xv = comp(x4, e);
                     const float nrm = comp(pa, e) * xv + comp(pn, e) * nzv[n] + comp(pd, e);
                     float o = apply_act(nrm * (1.f + gam) + bet, p.act);
                     o = c0 + e < C ? o : 0.f;
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     // A fragments: [mtile][chunk][tap][msub][hl][lane] units of 16 B
     const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
 
-    stage(0, 0);
+    if (!(p.dbg & 8)) stage(0, 0);
     __syncthreads();
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
@@ -292,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         __syncthreads();
     }
 
+    if (p.dbg & 4) return;
     sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
 }
 

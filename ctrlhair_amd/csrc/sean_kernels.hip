@@ -34,7 +34,7 @@ constexpr int OH_KC = 32;
 __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __restrict__ lab,
                                                              const float* __restrict__ table,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int B, int H, int W, int K, int relu) {
+                                                             int B, int H, int W, int K, int relu, int c4) {
     __shared__ float T[19 * 9 * OH_KC];
     __shared__ float bs[OH_KC];
     const int k0 = blockIdx.y * OH_KC;
@@ -57,7 +57,6 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
                     ? (lab[b * HW + (long long)yy * W + xx] * 9 + t) * OH_KC
                     : -1;
     }
-    float* o = out + ((long long)b * K + k0) * HW + (pix % HW);
     const int kmax = (K - k0 < OH_KC) ? (K - k0) : OH_KC;
     for (int kk = 0; kk < kmax; ++kk) {
         float v = bs[kk];
@@ -65,15 +64,17 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
         for (int t = 0; t < 9; ++t)
             if (jt[t] >= 0) v += T[jt[t] + kk];
         if (relu) v = v > 0.f ? v : 0.f;
-        o[(long long)kk * HW] = v;
+        const int k = k0 + kk;
+        if (c4) out[(((long long)b * (K >> 2) + (k >> 2)) * HW + (pix % HW)) * 4 + (k & 3)] = v;   // [B][K/4][HW][4]
+        else out[((long long)b * K + k) * HW + (pix % HW)] = v;
     }
 }
 
 hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* bias, float* out, int B, int H, int W,
-                          int K, int relu, hipStream_t s) {
+                          int K, int relu, hipStream_t s, int c4) {
     const long long npix = (long long)B * H * W;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
-    hipLaunchKernelGGL(onehot_conv3x3_kernel, grid, dim3(256), 0, s, lab, table, bias, out, B, H, W, K, relu);
+    hipLaunchKernelGGL(onehot_conv3x3_kernel, grid, dim3(256), 0, s, lab, table, bias, out, B, H, W, K, relu, c4);
     return hipGetLastError();
 }
 
@@ -157,6 +158,20 @@ hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, h
     return hipGetLastError();
 }
 
+// C4 [B][C/4][HW][4] -> f32 NCHW (test taps only)
+__global__ void c4_decode_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, long long HW) {
+    const long long n = (long long)B * C * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i % HW;
+        const int c = (int)((i / HW) % C), b = (int)(i / (HW * C));
+        out[i] = in[(((long long)b * (C >> 2) + (c >> 2)) * HW + p) * 4 + (c & 3)];
+    }
+}
+hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hipStream_t s) {
+    hipLaunchKernelGGL(c4_decode_kernel, dim3(4096), dim3(256), 0, s, in, out, B, C, HW);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Per-region style projection: mu[b,j,:] = relu(fc_mu_j(code[b,j]))  (normalization.py:134,146 + :191-215).
 // Weight-bandwidth bound (19 x 1 MB per ACE).  One wave per 4 output features; lanes split the 512-long dot
@@ -230,7 +245,7 @@ constexpr int CI_TW = 32, CI_TH = 8, CI_CK = 8;
 
 __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                       int Cin, int H, int W) {
+                                                       int Cin, int H, int W, int c4) {
     __shared__ float patch[CI_CK][CI_TH + 2][CI_TW + 2];
     __shared__ float ws[3][CI_CK][9];
     const int tx = threadIdx.x % CI_TW, ty = threadIdx.x / CI_TW;
@@ -245,7 +260,9 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
             const int yy = y0 + py - 1, xx = x0 + px - 1;
             float v = 0.f;
             if (c0 + c < Cin && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                v = x[((long long)b * Cin + c0 + c) * HW + (long long)yy * W + xx];
+                const int ch = c0 + c;
+                v = c4 ? x[(((long long)b * (Cin >> 2) + (ch >> 2)) * HW + (long long)yy * W + xx) * 4 + (ch & 3)]
+                       : x[((long long)b * Cin + ch) * HW + (long long)yy * W + xx];
                 v = v > 0.f ? v : 0.2f * v;
             }
             patch[c][py][px] = v;
@@ -275,9 +292,9 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
 }
 
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
-                         hipStream_t s) {
+                         hipStream_t s, int c4) {
     dim3 grid((W + CI_TW - 1) / CI_TW, (H + CI_TH - 1) / CI_TH, B);
-    hipLaunchKernelGGL(conv_img_kernel, grid, dim3(256), 0, s, x, w, bias, out, B, Cin, H, W);
+    hipLaunchKernelGGL(conv_img_kernel, grid, dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, c4);
     return hipGetLastError();
 }
 

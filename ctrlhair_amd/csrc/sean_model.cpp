@@ -334,6 +334,13 @@ struct Runner {
         if (m.use_sh16) check(sh16_decode(src, it->second, B, C, (long long)hw, st), "tap decode");
         else check(hipMemcpyAsync(it->second, src, (size_t)B * C * hw * 4, hipMemcpyDeviceToDevice, st), "tap copy");
     }
+    // f32 tensors between kernels are NCHW on the exact-f32 path and C4 ([B][C/4][HW][4]) on the f16x3 path
+    void tap_c4(const std::string& name, const float* src, int C, size_t hw) {
+        auto it = m.taps.find(name);
+        if (it == m.taps.end() || !it->second) return;
+        if (m.use_sh16) check(c4_decode(src, it->second, B, C, (long long)hw, st), "tap decode");
+        else check(hipMemcpyAsync(it->second, src, (size_t)B * C * hw * 4, hipMemcpyDeviceToDevice, st), "tap copy");
+    }
     void tap(const std::string& name, const float* src, size_t floats) {
         auto it = m.taps.find(name);
         if (it != m.taps.end() && it->second)
@@ -455,8 +462,8 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         const int sw = S / 32;
         float* x = xa;
         float* y = xb;
-        R.check(onehot_conv3x3(lab_r[5], fc_table, fc_bias, x, B, sw, sw, 16 * ngf, 0, st), "fc");
-        R.tap("fc", x, (size_t)B * 16 * ngf * sw * sw);
+        R.check(onehot_conv3x3(lab_r[5], fc_table, fc_bias, x, B, sw, sw, 16 * ngf, 0, st, use_sh16 ? 1 : 0), "fc");
+        R.tap_c4("fc", x, 16 * ngf, (size_t)sw * sw);
         size_t noff = 0;
         for (const auto& b : blocks) {
             const int r = S / b.res_div;
@@ -470,7 +477,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
                 noff += rr;
                 R.tap_sh16(b.name + ".hs", hs, b.fin, rr);
                 R.conv(b.conv_s, hs, xs, r, nullptr, 0);
-                R.tap(b.name + ".xs", xs, (size_t)B * b.fout * rr);
+                R.tap_c4(b.name + ".xs", xs, b.fout, rr);
                 shortcut = xs;
                 sc_up = 0;
             } else {
@@ -481,15 +488,15 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             noff += rr;
             R.tap_sh16(b.name + ".h0", h0, b.fin, rr);
             R.conv(b.conv_0, h0, dx, r, nullptr, 0);
-            R.tap(b.name + ".dx", dx, (size_t)B * b.fmid * rr);
+            R.tap_c4(b.name + ".dx", dx, b.fmid, rr);
             R.ace(b.ace_1, lab, cd, nz, nf, noff, dx, 0, ACT_LRELU, h1);
             noff += rr;
             R.tap_sh16(b.name + ".h1", h1, b.fmid, rr);
             R.conv(b.conv_1, h1, y, r, shortcut, sc_up);
-            R.tap(b.name, y, (size_t)B * b.fout * rr);
+            R.tap_c4(b.name, y, b.fout, rr);
             std::swap(x, y);
         }
-        R.check(conv_img_tanh(x, img_w, img_b, out + (size_t)bo * 3 * S * S, B, ngf, S, S, st), "conv_img");
+        R.check(conv_img_tanh(x, img_w, img_b, out + (size_t)bo * 3 * S * S, B, ngf, S, S, st, use_sh16 ? 1 : 0), "conv_img");
         if (!R.err.empty()) return R.err;
     }
     return "";
