@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ngf', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--path', choices=('f32', 'f16x3', 'f16x3v2'), default='f16x3',
+    ap.add_argument('--path', choices=('f32', 'f16x3', 'f16x3v2', 'f16x3gen'), default='f16x3',
                     help='conv arithmetic: f16x3 = 3-term split-operand f16 MFMA, f32 accumulate, f32-class accuracy '
                          '(default; max |delta| vs the exact path 1.5e-5); f32 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32)')
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
@@ -86,7 +86,7 @@ def main():
     from ctrlhair_amd.sean.generator import SeanGenerator
     B, S, ngf = args.batch, args.size, args.ngf
     sd = P.sean_state_dict(0, ngf)
-    gen = SeanGenerator(local_rank, f16x3={'f32': 0, 'f16x3': 1, 'f16x3v2': 2}[args.path]).load_state_dict(sd, max_batch=B, max_size=S)
+    gen = SeanGenerator(local_rank, f16x3={'f32': 0, 'f16x3': 1, 'f16x3v2': 2, 'f16x3gen': 3}[args.path]).load_state_dict(sd, max_batch=B, max_size=S)
     if args.dbg:
         gen.handle.set_option('sean.dbg', args.dbg)
     first = rank * B     # global sample index offset (SURVEY.md 8d Config 4)

@@ -65,6 +65,8 @@ struct ConvParams {
     long long noise_bstride;
     const uint8_t* lab;     // [B][H][W]
     const float* lut;       // [B*19][9][2][C] or null (unstyled)
+    const float* gen_table; // GEN kernels: mlp_shared as label table [19*9][Cin] (+ gen_bias [Cin]); input generated in-kernel
+    const float* gen_bias;
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
     const void* zeros;      // >= 16 zero bytes in device memory (source of out-of-image units for the LDS-DMA path)
     // EPI_NHWC

@@ -308,6 +308,213 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// GEN: the SPADE gamma/beta conv *generates its own input*.  Its input actv = relu(mlp_shared(one-hot labels))
+// (normalization.py:239-242,253) is a pure function of the 3x3 label neighbourhood -- a 9-tap gather from a
+// [19 labels x 9 taps][128] table -- so instead of materialising actv in HBM (134 MB per image per ACE at 512^2, written
+// once and re-read by every M-tile block) each block rebuilds the 16-channel slice of its patch in LDS from the uint8
+// label patch and an 11 KB table slice, splits it to f16 hi/lo in registers and writes the SH16 units straight into the
+// MFMA staging buffer.  No HBM staging loads remain on this kernel's critical path (label patch: <1 KB per block).
+template <int TW, int TH, int TB>
+struct ShGenCfg : ShCfg<3, TW, TH, TB> {
+    using Base = ShCfg<3, TW, TH, TB>;
+    static constexpr int LW = Base::PW + 2, LH = Base::PH + 2;            // label patch (halo 2)
+    static constexpr int SLICE = 19 * 9 * 16;                              // floats per table slice (16 channels)
+    static constexpr int OFF_SLICE = Base::UNITS * 16;                     // byte offsets in LDS
+    static constexpr int OFF_BIAS = OFF_SLICE + 2 * SLICE * 4;
+    static constexpr int OFF_LAB = OFF_BIAS + 2 * 16 * 4;
+    static constexpr int LDS_GEN = ((OFF_LAB + TB * LH * LW + 15) / 16) * 16;
+};
+
+template <int TW, int TH, int TB>
+__global__ __launch_bounds__(256, 2) void conv_sh16_gen_kernel(const ConvParams p) {
+    using Cfg = ShGenCfg<TW, TH, TB>;
+    constexpr int KS = 3, PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS;
+    constexpr int NT = 9, LW = Cfg::LW, LH = Cfg::LH, SLICE = Cfg::SLICE;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+    float* s_slice = reinterpret_cast<float*>(reinterpret_cast<char*>(smem_u) + Cfg::OFF_SLICE);
+    float* s_bias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem_u) + Cfg::OFF_BIAS);
+    uint8_t* s_lab = reinterpret_cast<uint8_t*>(smem_u) + Cfg::OFF_LAB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile64 = L % p.mtiles;
+    int nt = L / p.mtiles;
+    const int txi = nt % p.tiles_x; nt /= p.tiles_x;
+    const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
+    const int x0 = txi * TW, y0 = tyi * TH, b0 = nt * TB;
+    const int HW = p.H * p.W;
+
+    int ub[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int idx = wn * 128 + n * 32 + (lane & 31);
+        const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+        ub[n] = (lane >> 5) * 2 * PLANE + tb * (PH * PW) + ty * PW + tx;
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // label patch (255 = outside the image) + table slice / bias of chunk 0
+    for (int e = tid; e < TB * LH * LW; e += 256) {
+        const int tb = e / (LH * LW), ly = (e / LW) % LH, lx = e % LW;
+        const int y = y0 - 2 + ly, x = x0 - 2 + lx, b = b0 + tb;
+        const bool in = b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const uint8_t v = p.lab[in ? (long long)b * HW + y * p.W + x : 0];
+        s_lab[e] = in ? v : (uint8_t)255;
+    }
+    // table in global: [19*9][Cin] floats; slice of chunk c: columns [16c, 16c+16)
+    constexpr int SL4 = SLICE / 4;                              // float4 per slice (684)
+    constexpr int NSL = (SL4 + 255) / 256;                      // float4 loads per thread (3)
+    auto slice_load = [&](int chunk, float4 (&r)[NSL]) {
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int e = tid + i * 256, ee = e < SL4 ? e : 0;
+            r[i] = *reinterpret_cast<const float4*>(p.gen_table + (long long)(ee >> 2) * p.Cin + chunk * 16 + (ee & 3) * 4);
+        }
+    };
+    auto slice_store = [&](int buf, const float4 (&r)[NSL]) {
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int e = tid + i * 256;
+            if (e < SL4) reinterpret_cast<float4*>(s_slice + buf * SLICE)[e] = r[i];
+        }
+    };
+    {
+        float4 r0[NSL];
+        slice_load(0, r0);
+        slice_store(0, r0);
+        if (tid < 16) s_bias[tid] = p.gen_bias[tid];
+    }
+    __syncthreads();
+
+    // build the SH16 patch of `chunk` (16 channels = 2 groups) from labels + table slice `buf`
+    constexpr int NITEM = (2 * PLANE + 255) / 256;
+    auto generate = [&](int buf) {
+        const float* sl = s_slice + buf * SLICE;
+        const float* bs = s_bias + buf * 16;
+#pragma unroll 1
+        for (int i = 0; i < NITEM; ++i) {
+            const int it = tid + i * 256;
+            if (it < 2 * PLANE) {
+                const int g = it / PLANE, q = it % PLANE;
+                const int tb = q / (PH * PW), py = (q / PW) % PH, px = q % PW;
+                const uint8_t* lp = s_lab + tb * (LH * LW) + py * LW + px;
+                float v[8];
+                const bool inside = lp[LW + 1] != 255;          // the patch pixel itself lies in the image
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = bs[g * 8 + c];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int j = lp[(t / 3) * LW + (t % 3)];
+                    if (j != 255) {
+                        const float4* tp = reinterpret_cast<const float4*>(sl + (j * 9 + t) * 16 + g * 8);
+                        const float4 a = tp[0], b = tp[1];
+                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                    }
+                }
+                half8 vh, vl;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float o = inside ? fmaxf(v[c], 0.f) : 0.f;       // ReLU; zero padding outside the image
+                    const _Float16 h = (_Float16)o;
+                    vh[c] = h;
+                    vl[c] = (_Float16)(o - (float)h);
+                }
+                smem_u[(g * 2 + 0) * PLANE + q] = __builtin_bit_cast(uint4, vh);
+                smem_u[(g * 2 + 1) * PLANE + q] = __builtin_bit_cast(uint4, vl);
+            }
+        }
+    };
+
+    const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        float4 rn[NSL];
+        float bn = 0.f;
+        const bool more = ch + 1 < p.nchunks;
+        if (more) {
+            slice_load(ch + 1, rn);
+            bn = p.gen_bias[(ch + 1) * 16 + (tid & 15)];
+        }
+        if (!(p.dbg & 1) || ch == 0) generate(ch & 1);
+        __syncthreads();
+        if (!(p.dbg & 2)) {
+            const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
+            uint4 a_cur[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a_cur[q] = Ac[q * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint4 a_nxt[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a_nxt[q] = a_cur[q];
+                if (t + 1 < NT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a_nxt[q] = Ac[((t + 1) * 4 + q) * 64];
+                }
+                const int koff = (t / KS) * PW + (t % KS);
+                asm volatile("" ::: "memory");
+                uint4 bh[4], bl[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    bh[n] = smem_u[ub[n] + koff];
+                    bl[n] = smem_u[ub[n] + koff + PLANE];
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
+                    const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const half8 xh = __builtin_bit_cast(half8, bh[n]);
+                        const half8 xl = __builtin_bit_cast(half8, bl[n]);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m][n], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+            }
+        }
+        if (more) {
+            slice_store((ch + 1) & 1, rn);
+            if (tid < 16) s_bias[((ch + 1) & 1) * 16 + tid] = bn;
+        }
+        __syncthreads();
+    }
+    if (p.dbg & 4) return;
+    sh16_epilogue<TW, TH, TB, EPI_ACE>(p, acc, mtile64, wn, lane, x0, y0, b0);
+}
+
+template <int TW, int TH, int TB>
+hipError_t launch_sh16_gen(ConvParams p, int rows, hipStream_t stream) {
+    using Cfg = ShGenCfg<TW, TH, TB>;
+    auto kern = conv_sh16_gen_kernel<TW, TH, TB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           Cfg::LDS_GEN);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.nchunks = (p.Cin + 15) / 16;
+    p.mtiles = (rows + 63) / 64;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.tiles_b = (p.B + TB - 1) / TB;
+    const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_GEN, stream, p);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // v2: same arithmetic and layouts, different data movement.  ONE block per CU (4 waves, one per SIMD, up to 512 VGPRs):
 // both operands of a 16-channel chunk -- the input patch AND the block's A fragments -- are moved HBM/L2 -> LDS by the
 // LDS-DMA path (global_load_lds, 16 B per lane, no VGPR round trip) one whole chunk ahead into a 2-stage ring, so the

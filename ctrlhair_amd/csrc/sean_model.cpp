@@ -376,7 +376,9 @@ struct Runner {
             timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
                   [&] { check(conv_nhwc1x1(p, st), "lut gemm"); });
         }
-        if (m.use_sh16)
+        const bool gen = m.sh16_mode == 3;       // SPADE conv generates actv in-kernel: nothing to materialise
+        if (gen) {
+        } else if (m.use_sh16)
             check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
         else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
@@ -405,6 +407,10 @@ struct Runner {
         p.pad = -1;
         p.zeros = m.sh16_mode == 2 ? m.zero_page : nullptr;
         p.dbg = m.dbg;
+        if (gen) {
+            p.gen_table = a.actv_table;
+            p.gen_bias = a.actv_bias;
+        }
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
               4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
