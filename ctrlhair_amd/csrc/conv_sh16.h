@@ -177,9 +177,20 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                     vh[e] = h;
                     vl[e] = (_Float16)(o - (float)h);
                 }
-                const long long unit = (((long long)b * Go + g) * 2) * HW + (long long)y * p.W + x;
-                *reinterpret_cast<half4*>(oh + unit * 8 + 4 * hi) = vh;
-                *reinterpret_cast<half4*>(oh + (unit + HW) * 8 + 4 * hi) = vl;
+                // Lane l (l < 32) holds channels 0-3 of the unit, lane l+32 channels 4-7 of the SAME pixel.  One
+                // v_permlane32_swap per dword hands lane l its partner's hi half and lane l+32 its partner's lo half, so
+                // each lane issues ONE 16-byte store (lanes 0-31: hi plane, 32-63: lo plane; 512 B contiguous each).
+                uint2 wh = __builtin_bit_cast(uint2, vh), wl = __builtin_bit_cast(uint2, vl);
+                {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(wh.x, wl.x, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(wh.y, wl.y, false, false);
+                    wh.x = r0[0]; wl.x = r0[1];
+                    wh.y = r1[0]; wl.y = r1[1];
+                }
+                // lanes < 32 now hold {own hi (ch 0-3) in wh, partner hi (ch 4-7) in wl};
+                // lanes >= 32 hold {partner lo (ch 0-3) in wh, own lo (ch 4-7) in wl}
+                const long long unit = (((long long)b * Go + g) * 2 + hi) * HW + (long long)y * p.W + x;
+                reinterpret_cast<uint4*>(oh)[unit] = make_uint4(wh.x, wh.y, wl.x, wl.y);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
