@@ -202,6 +202,8 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
     bufb = B.falloc(mb * 32 * HW);                      // ping-pong activations (largest: 32 ch at 256^2)
     bufc = B.falloc(mb * 32 * HW);
     lnpart = B.falloc((size_t)mb * 128 * 3);
+    splitk_cap = (long long)8 << 20;
+    splitk_ws = B.falloc((size_t)splitk_cap);
     codecat = B.falloc((size_t)mb * (FACE_DIM + HAIR_DIM));
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "device sync failed";
@@ -218,7 +220,10 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
     int size = S;
     for (int l = 0; l < 7; ++l) {
         float* y = bufs[l & 1];
-        ck(run_conv(enc[w][l], x, y, B, size, size, ConvOpts(), st), "shape enc conv");
+        ConvOpts eo;
+        eo.partial = splitk_ws;
+        eo.partial_cap = splitk_cap;
+        ck(run_conv(enc[w][l], x, y, B, size, size, eo, st), "shape enc conv");
         size /= 2;
         ck(layernorm_act(y, enc_ln[w][l].gamma, enc_ln[w][l].beta, lnpart, B, enc[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st),
            "shape enc ln");
@@ -255,6 +260,8 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
     int size = 2;
     ConvOpts up;
     up.in_mode = IN_UP2_NEAREST;
+    up.partial = splitk_ws;
+    up.partial_cap = splitk_cap;
     for (int l = 0; l < 7; ++l) {
         float* y = bufs[l & 1];
         ck(run_conv(dec[w][l], x, y, B, size, size, up, st), "shape dec conv");
@@ -396,6 +403,8 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
     vec0 = B.falloc((size_t)mb * 512);
     vec1 = B.falloc((size_t)mb * 512);
     vec2 = B.falloc((size_t)mb * 512);
+    splitk_cap = (long long)8 << 20;
+    splitk_ws = B.falloc((size_t)splitk_cap);
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "device sync failed";
     ready = true;
@@ -410,6 +419,7 @@ std::string BiSeNetModel::parse(const float* img, uint8_t* labels, float* logits
     for (int bo = 0; bo < Btot; bo += max_batch) {
         const int B = std::min(max_batch, Btot - bo);
         Ck ck;
+        auto SK = [&](ConvOpts o) { o.partial = splitk_ws; o.partial_cap = splitk_cap; return o; };
         const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8, h16 = H / 16, w16 = W / 16,
                   h32 = H / 32, w32 = W / 32;
         // resnet.py:71-80
@@ -419,17 +429,17 @@ std::string BiSeNetModel::parse(const float* img, uint8_t* labels, float* logits
         auto block = [&](const BasicBlockW& bb, const float* x, float* tmp, float* sc, float* out, int hin, int win) {
             ConvOpts r;
             r.act = ACT_RELU;
-            ck(run_conv(bb.c1, x, tmp, B, hin, win, r, st), "bb conv1");
+            ck(run_conv(bb.c1, x, tmp, B, hin, win, SK(r), st), "bb conv1");
             const int ho = hin / bb.c1.stride, wo = win / bb.c1.stride;
             const float* shortcut = x;
             if (bb.has_down) {
-                ck(run_conv(bb.down, x, sc, B, hin, win, ConvOpts(), st), "bb down");
+                ck(run_conv(bb.down, x, sc, B, hin, win, SK(ConvOpts()), st), "bb down");
                 shortcut = sc;
             }
             ConvOpts o;
             o.act = ACT_RELU;
             o.res = shortcut;
-            ck(run_conv(bb.c2, tmp, out, B, ho, wo, o, st), "bb conv2");
+            ck(run_conv(bb.c2, tmp, out, B, ho, wo, SK(o), st), "bb conv2");
         };
         // layer1 @1/4 (64ch): x=b1 ; scratch: b2, b0 (b0 is large)
         float* t0 = b0;                       // scratch big enough for any 1/4-res 64ch tensor and below
@@ -451,31 +461,31 @@ std::string BiSeNetModel::parse(const float* img, uint8_t* labels, float* logits
         ConvOpts relu;
         relu.act = ACT_RELU;
         // arm32 (model.py:67-83)
-        ck(run_conv(arm32_conv, f32, t0, B, h32, w32, relu, st), "arm32 conv");
+        ck(run_conv(arm32_conv, f32, t0, B, h32, w32, SK(relu), st), "arm32 conv");
         ck(global_avg_pool(t0, vec0, B * 128, h32 * w32, st), "arm32 gap");
         ck(linear(vec0, att32_w, nullptr, att32_scale, att32_shift, vec2, B, 128, 128, 128, 128, ACT_SIGMOID, st), "arm32 atten");
         ck(chan_affine(t0, vec2, 0.f, vec1, nullptr, t1, (long long)B * 128, h32 * w32, st), "feat32_sum");   // feat*atten + avg_up
         ConvOpts up_relu = relu;
         up_relu.in_mode = IN_UP2_NEAREST;
-        ck(run_conv(head32, t1, b1, B, h32, w32, up_relu, st), "conv_head32");                                // feat32_up @1/16
+        ck(run_conv(head32, t1, b1, B, h32, w32, SK(up_relu), st), "conv_head32");                                // feat32_up @1/16
         // arm16
-        ck(run_conv(arm16_conv, f16, t0, B, h16, w16, relu, st), "arm16 conv");
+        ck(run_conv(arm16_conv, f16, t0, B, h16, w16, SK(relu), st), "arm16 conv");
         ck(global_avg_pool(t0, vec0, B * 128, h16 * w16, st), "arm16 gap");
         ck(linear(vec0, att16_w, nullptr, att16_scale, att16_shift, vec2, B, 128, 128, 128, 128, ACT_SIGMOID, st), "arm16 atten");
         ck(chan_affine(t0, vec2, 0.f, nullptr, b1, t1, (long long)B * 128, h16 * w16, st), "feat16_sum");     // feat*atten + feat32_up
-        ck(run_conv(head16, t1, b2, B, h16, w16, up_relu, st), "conv_head16");                                // feat_cp8 @1/8
+        ck(run_conv(head16, t1, b2, B, h16, w16, SK(up_relu), st), "conv_head16");                                // feat_cp8 @1/8
         // FeatureFusionModule (model.py:198-210): convblk(cat[feat8, feat_cp8]) as two 1x1 convs
-        ck(run_conv(ffm_a, f8, t0, B, h8, w8, ConvOpts(), st), "ffm a");
+        ck(run_conv(ffm_a, f8, t0, B, h8, w8, SK(ConvOpts()), st), "ffm a");
         ConvOpts fb = relu;
         fb.res = t0;
-        ck(run_conv(ffm_b, b2, t1, B, h8, w8, fb, st), "ffm b");                                              // feat
+        ck(run_conv(ffm_b, b2, t1, B, h8, w8, SK(fb), st), "ffm b");                                              // feat
         ck(global_avg_pool(t1, vec0, B * 256, h8 * w8, st), "ffm gap");
         ck(linear(vec0, ffm1_w, nullptr, nullptr, nullptr, vec1, B, 256, 64, 256, 64, ACT_RELU, st), "ffm conv1");
         ck(linear(vec1, ffm2_w, nullptr, nullptr, nullptr, vec2, B, 64, 256, 64, 256, ACT_SIGMOID, st), "ffm conv2");
         ck(chan_affine(t1, vec2, 1.f, nullptr, nullptr, t0, (long long)B * 256, h8 * w8, st), "ffm out");     // feat*atten + feat
         // BiSeNetOutput (model.py:43-46)
-        ck(run_conv(out_conv, t0, t1, B, h8, w8, relu, st), "conv_out.conv");
-        ck(run_conv(out_cls, t1, b1, B, h8, w8, ConvOpts(), st), "conv_out.conv_out");                       // [B,19,h8,w8]
+        ck(run_conv(out_conv, t0, t1, B, h8, w8, SK(relu), st), "conv_out.conv");
+        ck(run_conv(out_cls, t1, b1, B, h8, w8, SK(ConvOpts()), st), "conv_out.conv_out");                       // [B,19,h8,w8]
         ck(bilinear_argmax(b1, labels + (size_t)bo * H * W, logits ? logits + (size_t)bo * 19 * H * W : nullptr, remap, B, h8,
                            w8, H, W, st), "bilinear argmax");
         if (!ck.err.empty()) return ck.err;

@@ -41,7 +41,8 @@ struct ShapeModel {
     LnW dec_ln[2][7];
     float* pos = nullptr;      // [40][S*S]
     float *in_hair = nullptr, *in_face = nullptr, *bufa = nullptr, *bufb = nullptr, *bufc = nullptr, *lnpart = nullptr,
-          *codecat = nullptr;
+          *codecat = nullptr, *splitk_ws = nullptr;
+    long long splitk_cap = 0;
     std::string build(const TensorStore& ts, int max_batch);
     std::string encode(const uint8_t* labels, float* hair_code, float* face_code, int B, hipStream_t st);
     // decode: any of hair_logit/face_logit/labels/probs may be null; hair_code may be null when only the face is wanted
@@ -71,7 +72,8 @@ struct BiSeNetModel {
     float *ffm1_w = nullptr, *ffm2_w = nullptr;
     uint8_t* remap = nullptr;
     float *b0 = nullptr, *b1 = nullptr, *b2 = nullptr, *f8 = nullptr, *f16 = nullptr, *f32 = nullptr, *vec0 = nullptr,
-          *vec1 = nullptr, *vec2 = nullptr;
+          *vec1 = nullptr, *vec2 = nullptr, *splitk_ws = nullptr;
+    long long splitk_cap = 0;
     std::string build(const TensorStore& ts, int max_batch, int max_size);
     std::string parse(const float* img, uint8_t* labels, float* logits, int B, int H, int W, hipStream_t st);
     void destroy();

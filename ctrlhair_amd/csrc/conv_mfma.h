@@ -65,6 +65,10 @@ struct ConvParams {
     long long noise_bstride;
     const uint8_t* lab;     // [B][H][W]
     const float* lut;       // [B*19][9][2][C] or null (unstyled)
+    int splitk;             // EPI_PLAIN only: K split over `splitk` blocks, raw partial sums to `partial` slabs
+    int cps;                // chunks per split
+    float* partial;         // [splitk][B][Mrows][H*W] scratch (then splitk_reduce_kernel applies bias/res/act)
+    long long partial_cap;  // floats available in `partial` (0 = split-K disabled)
     const float* gen_table; // GEN kernels: mlp_shared as label table [19*9][Cin] (+ gen_bias [Cin]); input generated in-kernel
     const float* gen_bias;
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
@@ -119,11 +123,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = L % p.mtiles;
     int nt = L / p.mtiles;
+    const int ks = (EPI == EPI_PLAIN && p.splitk > 1) ? nt % p.splitk : 0;     // K slice of this block
+    if (EPI == EPI_PLAIN && p.splitk > 1) nt /= p.splitk;
     const int txi = nt % p.tiles_x; nt /= p.tiles_x;
     const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
     const int x0 = txi * TW, y0 = tyi * TH, b0 = nt * TB;
     const int mtile64 = mt * WM + wm;
     const int HW = p.H * p.W;
+    const int c_lo = (EPI == EPI_PLAIN && p.splitk > 1) ? ks * p.cps : 0;
+    const int c_hi = (EPI == EPI_PLAIN && p.splitk > 1) ? (c_lo + p.cps < p.nchunks ? c_lo + p.cps : p.nchunks) : p.nchunks;
 
     // per-lane LDS offsets of the window origin for the 4 N-subtiles
     int loff[4];
@@ -187,12 +195,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const float4* Ap = reinterpret_cast<const float4*>(p.wpk) +
                        ((long long)mtile64 * p.nchunks) * (NG * 2 * 64) + lane;
 
-    stage(0, 0);
+    stage(c_lo, 0);
     __syncthreads();
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        if (ch + 1 < p.nchunks) stage(ch + 1, (ch + 1) & 1);
-        const float* sb = smem + (ch & 1) * SE;
+    for (int ch = c_lo; ch < c_hi; ++ch) {
+        if (ch + 1 < c_hi) stage(ch + 1, (ch + 1 - c_lo) & 1);
+        const float* sb = smem + ((ch - c_lo) & 1) * SE;
         const float4* Ac = Ap + (long long)ch * (NG * 2 * 64);
         float4 a0 = Ac[0], a1 = Ac[64];
         float bv[4], bn[4];
@@ -254,7 +262,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mtile64 * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < p.Mrows) {
+                    if (row < p.Mrows && p.splitk > 1) {
+                        p.partial[(((long long)ks * p.B + b) * p.Mrows + row) * HW + pix] = acc[m][n][r];
+                    } else if (row < p.Mrows) {
                         float v = acc[m][n][r];
                         if (p.bias) v += p.bias[row];
                         float rv = 0.f;
@@ -334,6 +344,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     }
 }
 
+// out = act(sum_s partial[s] + bias (+ res))  (NCHW; same epilogue semantics as EPI_PLAIN).  Slabs are summed in a
+// fixed order: bit-reproducible run to run.
+template <int DUMMY>
+__global__ void splitk_reduce_kernel(const ConvParams p) {
+    const long long HW = (long long)p.H * p.W, n = (long long)p.B * p.Mrows * HW;
+    const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; ++s) v += p.partial[(long long)s * n + i];
+        const int row = (int)((i / HW) % p.Mrows);
+        if (p.bias) v += p.bias[row];
+        float rv = 0.f;
+        if (p.res) {
+            const long long pix = i % HW;
+            const int y = (int)(pix / p.W), x = (int)(pix % p.W);
+            rv = p.res[(i / HW) * (rW * rH) + (long long)(y >> p.res_up) * rW + (x >> p.res_up)];
+        }
+        p.out[i] = p.res_after_act ? apply_act(v, p.act) + rv : apply_act(v + rv, p.act);
+    }
+}
+
 // host-side launcher for one instantiation
 template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
 hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
@@ -353,8 +384,28 @@ hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.tiles_b = (p.B + TB - 1) / TB;
-    const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    p.splitk = 1;
+    p.cps = p.nchunks;
+    if (EPI == EPI_PLAIN && p.partial && grid < 192 && p.nchunks >= 8) {
+        // few tiles but a long reduction (low-resolution, wide layers: shape VAE, BiSeNet tail): split K so that
+        // ~2 blocks per CU stream the weights concurrently; partial sums go to slabs and are reduced deterministically.
+        const long long slab = (long long)p.B * p.Mrows * p.H * p.W;
+        int sk = (512 + grid - 1) / grid;
+        if (sk > p.nchunks / 2) sk = p.nchunks / 2;
+        if ((long long)sk * slab > p.partial_cap) sk = (int)(p.partial_cap / slab);
+        if (sk > 1) {
+            p.cps = (p.nchunks + sk - 1) / sk;
+            p.splitk = (p.nchunks + p.cps - 1) / p.cps;
+            grid *= p.splitk;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
+    if (p.splitk > 1) {
+        const long long n = (long long)p.B * p.Mrows * p.H * p.W;
+        const int rg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(rg), dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

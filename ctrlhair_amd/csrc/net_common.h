@@ -163,6 +163,8 @@ struct ConvOpts {
     const float* res = nullptr;
     int res_up = 0;
     int res_after_act = 0;
+    float* partial = nullptr;      // split-K scratch (optional): enables split-K for few-tile / long-K layers
+    long long partial_cap = 0;
 };
 
 inline int conv_out_size(const ConvLayer& L, int in, int in_mode) {
@@ -192,6 +194,8 @@ inline hipError_t run_conv(const ConvLayer& L, const float* in, float* out, int 
     p.res_up = o.res_up;
     p.res_after_act = o.res_after_act;
     p.act = o.act;
+    p.partial = o.partial;
+    p.partial_cap = o.partial_cap;
     if (L.stride == 2) return conv_plain_s2(p, L.KS, st);
     if (L.KS == 3) return conv_plain3(p, st);
     if (L.KS == 1) return conv_plain1(p, st);
