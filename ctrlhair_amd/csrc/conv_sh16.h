@@ -244,7 +244,12 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         if (u < UNITS) {
             const int gh = u / PLANE, rem = u % PLANE;          // gh = group*2 + hl
             const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
-            const int y = y0 + py - HALO, x = x0 + px - HALO, b = b0 + tb;
+            int y = y0 + py - HALO, x = x0 + px - HALO;
+            const int b = b0 + tb;
+            if (p.pad_mode == PAD_REFLECT) {      // nn.ReflectionPad2d (Zencoder, architecture.py:174)
+                y = y < 0 ? -y : (y >= p.H ? 2 * (p.H - 1) - y : y);
+                x = x < 0 ? -x : (x >= p.W ? 2 * (p.W - 1) - x : x);
+            }
             if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                 soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
         }

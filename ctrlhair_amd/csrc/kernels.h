@@ -16,11 +16,11 @@ hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, floa
 hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hipStream_t s);
 hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s);
 // misc_kernels.hip
-hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s);
+hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16 = nullptr, int C = 0);
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
                          int act, hipStream_t s);
 hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B, int F, int h, int w, int S,
-                       hipStream_t s);
+                       hipStream_t s, int c4 = 0);
 hipError_t maxpool3x3s2(const float* in, float* out, long long planes, int H, int W, hipStream_t s);
 hipError_t global_avg_pool(const float* in, float* out, int planes, int HW, hipStream_t s);
 hipError_t chan_affine(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,

@@ -30,7 +30,10 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // ---------------------------------------------------------------------------------------------------------
 // nn.InstanceNorm2d(affine=False, eps=1e-5) + activation, in place (architecture.py:158-172).  One block per
 // (b,c) plane, two-pass statistics (mean, then biased variance), third pass writes.
-__global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x, int HW, float eps, int act) {
+// sh16 != nullptr: the normalised plane is written (instead of in place) as f16 hi/lo in the SH16 layout
+// [B][C/8][2][HW][8] of conv_sh16.h (plane index = b*C + c), feeding the f16x3 conv directly.
+__global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x, int HW, float eps, int act,
+                                                           _Float16* __restrict__ sh16, int C) {
     __shared__ float red[4];
     float* p = x + (long long)blockIdx.x * HW;
     float s = 0.f;
@@ -43,10 +46,21 @@ __global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x
     }
     const float var = block_sum(q, red) / HW;
     const float rstd = 1.f / sqrtf(var + eps);
+    if (sh16) {
+        const int b = blockIdx.x / C, c = blockIdx.x % C;
+        _Float16* oh = sh16 + ((((long long)b * (C >> 3) + (c >> 3)) * 2) * HW) * 8 + (c & 7);
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const float v = act_fn((p[i] - mean) * rstd, act);
+            const _Float16 h = (_Float16)v;
+            oh[(long long)i * 8] = h;
+            oh[((long long)HW + i) * 8] = (_Float16)(v - (float)h);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < HW; i += 256) p[i] = act_fn((p[i] - mean) * rstd, act);
 }
-hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s) {
-    hipLaunchKernelGGL(instnorm_act_kernel, dim3(planes), dim3(256), 0, s, x, HW, eps, act);
+hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16, int C) {
+    hipLaunchKernelGGL(instnorm_act_kernel, dim3(planes), dim3(256), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C);
     return hipGetLastError();
 }
 
@@ -121,11 +135,14 @@ hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float*
 // (0 if the region is absent).  One block per (f, b); 19 register accumulators per thread.
 __global__ __launch_bounds__(256) void region_mean_kernel(const float* __restrict__ codes,
                                                           const uint8_t* __restrict__ lab, float* __restrict__ out,
-                                                          int F, int h, int w, int S) {
+                                                          int F, int h, int w, int S, int c4) {
     __shared__ float red[4];
     const int f = blockIdx.x, b = blockIdx.y;
     const int fy = S / h, fx = S / w;
-    const float* p = codes + ((long long)b * F + f) * h * w;
+    // c4: codes in the C4 layout [B][F/4][h*w][4] (output of the f16x3 conv), else NCHW
+    const float* p = c4 ? codes + ((long long)b * (F >> 2) + (f >> 2)) * h * w * 4 + (f & 3)
+                        : codes + ((long long)b * F + f) * h * w;
+    const int ps = c4 ? 4 : 1;
     const uint8_t* lb = lab + (long long)b * S * S;
     float acc[19], cnt[19];
 #pragma unroll
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(256) void region_mean_kernel(const float* __restric
     for (int i = threadIdx.x; i < h * w; i += 256) {
         const int y = i / w, x = i % w;
         const int l = lb[(long long)(y * fy) * S + x * fx];
-        const float v = p[i];
+        const float v = p[(long long)i * ps];
 #pragma unroll
         for (int j = 0; j < 19; ++j)
             if (l == j) { acc[j] += v; cnt[j] += 1.f; }
@@ -146,8 +163,8 @@ __global__ __launch_bounds__(256) void region_mean_kernel(const float* __restric
     }
 }
 hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B, int F, int h, int w, int S,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(region_mean_kernel, dim3(F, B), dim3(256), 0, s, codes, lab, out, F, h, w, S);
+                       hipStream_t s, int c4) {
+    hipLaunchKernelGGL(region_mean_kernel, dim3(F, B), dim3(256), 0, s, codes, lab, out, F, h, w, S, c4);
     return hipGetLastError();
 }
 

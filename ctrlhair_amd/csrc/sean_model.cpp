@@ -232,6 +232,11 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             z10 = make_conv(B, w, B.vec("Zencoder.model.10.bias", 256), 256, 128, 3, 1, 1);
         }
         plain("Zencoder.model.14", 512, 256, 1, z14);
+        if (use_sh16) {   // the 256->512 conv is 91 % of the Zencoder FLOPs: run it on the f16x3 path too
+            auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
+            const float* wp = w14.data();
+            z14_sh = B.upload(pack_A_sh16(512, 256, 3, [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; }));
+        }
         if (!B.err.empty()) return B.err;
         has_zencoder = true;
     }
@@ -260,7 +265,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     outmax = std::max(outmax, (size_t)MB * 16 * ngf * (S / 32) * (S / 32));
     if (has_zencoder) {   // Zencoder activations live in h0/hs (<= 512 ch at S/2) and dx/h1 (<= 64 ch at S/2)
         h0max = std::max(h0max, MB * S * S * 128);
-        midmax = std::max(midmax, MB * S * S * 16);
+        midmax = std::max(midmax, MB * S * S * (use_sh16 ? 64 : 16));
     }
     lut = static_cast<float*>(B.dalloc(lutmax * 4));
     actv = static_cast<float*>(B.dalloc(MB * S * S * HID * 4));
@@ -534,13 +539,33 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         ck(run_conv(z7, dx, h1, B, h2, h2, zero, st), "zenc conv3");
         ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
         ck(run_conv(z10, h1, hs, B, h4, h4, zins, st), "zenc convT");
-        ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
-        ck(run_conv(z14, hs, h0, B, h2, h2, last, st), "zenc conv5");
-        ck(region_mean(h0, labels + (size_t)bo * S * S, codes_out + (size_t)bo * LABEL_NC * STYLE, B, STYLE, h2, h2, S, st),
-           "region_mean");
+        if (use_sh16) {
+            // InstanceNorm + lrelu written straight into the SH16 layout -> f16x3 conv (reflection pad, tanh) -> C4
+            ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st, h1, 256), "zenc in4");
+            ConvParams p{};
+            p.in = h1;
+            p.wpk = z14_sh;
+            p.out = h0;
+            p.B = B;
+            p.Cin = 256;
+            p.H = h2;
+            p.W = h2;
+            p.Mrows = 512;
+            p.bias = z14.bias;
+            p.act = ACT_TANH;
+            p.pad_mode = PAD_REFLECT;
+            ck(conv_sh16_plain(p, 3, st), "zenc conv5 (f16x3)");
+        } else {
+            ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
+            ck(run_conv(z14, hs, h0, B, h2, h2, last, st), "zenc conv5");
+        }
+        ck(region_mean(h0, labels + (size_t)bo * S * S, codes_out + (size_t)bo * LABEL_NC * STYLE, B, STYLE, h2, h2, S, st,
+                       use_sh16 ? 1 : 0), "region_mean");
         auto it = taps.find("zenc.feat");
-        if (it != taps.end() && it->second)
-            ck(hipMemcpyAsync(it->second, h0, (size_t)B * STYLE * h2 * h2 * 4, hipMemcpyDeviceToDevice, st), "tap");
+        if (it != taps.end() && it->second) {
+            if (use_sh16) ck(c4_decode(h0, it->second, B, STYLE, (long long)h2 * h2, st), "tap");
+            else ck(hipMemcpyAsync(it->second, h0, (size_t)B * STYLE * h2 * h2 * 4, hipMemcpyDeviceToDevice, st), "tap");
+        }
         if (!err.empty()) return err;
     }
     return "";

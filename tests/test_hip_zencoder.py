@@ -10,18 +10,23 @@ TOL = 1e-3
 _gen = {}
 
 
-def gen():
-    if 'g' not in _gen:
+PATHS = ['f32', 'f16x3']
+
+
+def gen(path='f32'):
+    if path not in _gen:
         from ctrlhair_amd import procedural as P
         from ctrlhair_amd.sean.generator import SeanGenerator
-        _gen['g'] = SeanGenerator(0).load_state_dict(P.sean_state_dict(0, 16), max_batch=2, max_size=512)
-    return _gen['g']
+        _gen[path] = SeanGenerator(0, f16x3=int(path == 'f16x3')).load_state_dict(P.sean_state_dict(0, 16), max_batch=2,
+                                                                                   max_size=512)
+    return _gen[path]
 
 
-def test_feature_map_and_codes_vs_oracle(hip_lib):
+@pytest.mark.parametrize('path', PATHS)
+def test_feature_map_and_codes_vs_oracle(hip_lib, path):
     from ctrlhair_amd import procedural as P
     from oracle import sean_oracle as O
-    g = gen()
+    g = gen(path)
     B, S = 3, 128     # B > max_batch exercises chunking
     lab, img = P.blocky_labels(B, S, grid=8, seed=9), P.synthetic_images(B, S, seed=10)
     taps = {}
@@ -36,10 +41,11 @@ def test_feature_map_and_codes_vs_oracle(hip_lib):
     assert np.abs(codes.cpu().numpy() - ref).max() <= TOL
 
 
+@pytest.mark.parametrize('path', PATHS)
 @pytest.mark.parametrize('name', ZENC_CASES)
-def test_golden(hip_lib, name):
+def test_golden(hip_lib, name, path):
     c = ZencCase(name)
-    g = gen()
+    g = gen(path)
     codes = g.encode(torch.from_numpy(c.img).to(g.device), torch.from_numpy(c.labels).to(g.device))
     torch.cuda.synchronize()
     out = codes.cpu().numpy()

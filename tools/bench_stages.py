@@ -46,6 +46,7 @@ def main():
     out = {'device': torch.cuda.get_device_name(0), 'batch': B, 'size': S, 'unit': 'ms per batch'}
 
     out['zencoder_f32'] = timeit(lambda: m.generator.encode(img, lab512))
+    out['zencoder_f16x3_last_conv'] = timeit(lambda: gen16.encode(img, lab512))
     out['bisenet_f32'] = timeit(lambda: m.face_parsing.parse_tensor(img))
     out['shape_encode_f32'] = timeit(lambda: m.mask_generator.encode_labels(lab256))
     hc, fc = m.mask_generator.encode_labels(lab256)
@@ -67,7 +68,7 @@ def main():
         lab, _ = m.face_parsing.parse_tensor(img)
         l256 = lab[:, ::2, ::2].contiguous()
         hcode, fcode = m.mask_generator.encode_labels(l256)
-        c = m.generator.encode(img, lab)
+        c = gen16.encode(img, lab)
         h = c[:, 13].contiguous()
         d = m.solver_feature.dis({'code': h})
         r = m.solver_feature.rgb_model({'code': h})
