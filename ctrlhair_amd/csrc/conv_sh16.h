@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, NLOAD = Cfg::NLOAD, HALO = Cfg::HALO;
     constexpr int NT = KS * KS;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
-
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int mtile64 = L % p.mtiles;
