@@ -142,6 +142,20 @@ class HairEditor:
         change_status(self.sean_model, 'UI_mode')
         return self.sean_model(data, mode='UI_mode')[0]
 
+    def gen_imgs(self, codes, parsings, noise=None, seed: int = 0):
+        """Batched gen_img (the reference only offers batch 1, hair_editor.py:159-179, and loops
+        over it in shape_branch/validation_in_train.py:114-121 / color_texture_branch/solver.py:270-299).
+        codes [B,19,512], parsings [B,S,S] or [B,1,S,S] label maps -> images [B,3,S,S].  Per sample, all-zero code rows
+        (absent regions) fall back to the median style code exactly like gen_img (:165-168)."""
+        codes = torch.as_tensor(codes).to(self.device).float()
+        lab = torch.as_tensor(np.asarray(parsings) if not isinstance(parsings, torch.Tensor) else parsings)
+        lab = lab.reshape(lab.shape[0], lab.shape[-2], lab.shape[-1]).to(self.device).to(torch.uint8).contiguous()
+        if self._median is None:
+            self.load_average_feature()
+        zero = (codes == 0).all(dim=2, keepdim=True)
+        codes = torch.where(zero, self._median[None].expand_as(codes), codes).contiguous()
+        return self.models.generator.generate(lab, codes, noise, seed=seed)
+
     def generate_by_sean(self, face_img_code, hair_code, target_seg, noise=None):
         """hair_editor.py:181-206 (face_img_code [19,512], hair_code [512])."""
         obj_dic = self.load_average_feature()

@@ -109,3 +109,19 @@ def test_hip_backend_matches_cpu_plumbing(hip_lib, cpu_run):
     assert (g['cur_mask'] != c['cur_mask']).mean() < 1e-3          # label flips only at fp32 ties
     d = np.abs(g['out'].astype(np.int32) - c['out'].astype(np.int32))
     assert d.max() <= 1 or (d > 1).mean() < 1e-3, (d.max(), (d > 1).mean())   # uint8 truncation of |delta|<=1e-3 floats
+
+
+@pytest.mark.gpu
+def test_batched_gen_imgs_equals_per_sample(hip_lib):
+    """N1: gen_imgs(codes[B], masks[B]) == stacking gen_img per sample (incl. the median-code fallback for zero rows)."""
+    from ctrlhair_amd.hair_editor import HairEditor
+    he = HairEditor(True, True, weights=weights(), device=0, max_batch=4)
+    B, S = 3, 256
+    labels = P.blocky_labels(B, S, seed=9)
+    codes = P.style_codes(B, seed=10)
+    codes[1, 5] = 0.0                              # absent region -> median code
+    noise = torch.from_numpy(P.noise_planes(B, S, NGF, seed=11)).cuda()
+    batched = he.gen_imgs(codes, labels, noise=noise)
+    for b in range(B):
+        one = he.gen_img(codes[b:b + 1], labels[b][None, None], noise=noise[b:b + 1])
+        assert float((one - batched[b]).abs().max()) <= 1e-6

@@ -1,6 +1,6 @@
 #!/bin/bash
 # perf ablations of the f16x3 conv kernels: dbg 1 = no staging after chunk 0, 2 = no MFMA loop, 3 = both
-for p in f16x3 f32; do for d in 0; do
+for p in f16x3; do for d in 0 4; do
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --path $p --dbg $d 2>/dev/null | tail -1 > /tmp/ab.json
 python - <<PY
 import json

@@ -62,6 +62,13 @@ def main():
     out['sean_generator_f32'] = timeit(lambda: m.generator.generate(lab512, codes, noise), warm=1, it=3)
     out['sean_generator_f16x3'] = timeit(lambda: gen16.generate(lab512, codes, noise), warm=1, it=5)
 
+    # single-image latency of the render call behind Backend.output() (ui/backend.py:147-175), explicit noise
+    for s_ in (256, 512):
+        l1 = lab512[:1, ::(512 // s_), ::(512 // s_)].contiguous()
+        n1 = torch.from_numpy(P.noise_planes(1, s_, 64)).to(dev)
+        out[f'sean_generator_f16x3_batch1_{s_}'] = timeit(lambda: gen16.generate(l1, codes[:1], n1), warm=2, it=10)
+        out[f'sean_generator_f32_batch1_{s_}'] = timeit(lambda: m.generator.generate(l1, codes[:1], n1), warm=2, it=5)
+
     # BASELINE config 3: full pipeline, batch 8 (BiSeNet@512 -> remap -> nearest 256 -> shape enc -> Zencoder@512 ->
     # colour enc/pred/gen with a slider delta -> shape dec -> nearest x2 -> generator@512), blending off.
     def pipeline():
