@@ -39,7 +39,7 @@ struct ShCfg {
 
 template <int TW, int TH, int TB, int EPI>
 __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)[2][4], int mtile64, int wn, int lane,
-                                              int x0, int y0, int b0) {
+                                              int x0, int y0, int b0, int ks = 0) {
     const int HW = p.H * p.W;
     // ---- epilogue ------------------------------------------------------------------------------------------
     // Per-channel parameters are loaded ONCE per wave as float4 (a lane's 16 rows are 4 runs of 4 consecutive
@@ -79,7 +79,12 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
-                    if (row0 < p.Mrows) {                       // Mrows % 4 == 0
+                    if (row0 < p.Mrows && p.splitk > 1) {       // split-K: raw partial sums to this slice's C4 slab
+                        float4 v;
+                        v.x = acc[m][n][rq * 4 + 0]; v.y = acc[m][n][rq * 4 + 1];
+                        v.z = acc[m][n][rq * 4 + 2]; v.w = acc[m][n][rq * 4 + 3];
+                        reinterpret_cast<float4*>(p.partial)[(((long long)ks * p.B + b) * C4n + (row0 >> 2)) * HW + pix] = v;
+                    } else if (row0 < p.Mrows) {                // Mrows % 4 == 0
                         const float4 b4 = bias4[m][rq];
                         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (p.res) rv = reinterpret_cast<const float4*>(p.res)[((long long)b * C4n + (row0 >> 2)) * (rW * rH) + rpix];
@@ -210,6 +215,11 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int mtile64 = L % p.mtiles;
     int nt = L / p.mtiles;
+    const bool split = EPI == EPI_PLAIN && p.splitk > 1;
+    const int ks = split ? nt % p.splitk : 0;            // K slice of this block (split-K, low-resolution layers)
+    if (split) nt /= p.splitk;
+    const int c_lo = split ? ks * p.cps : 0;
+    const int c_hi = split ? (c_lo + p.cps < p.nchunks ? c_lo + p.cps : p.nchunks) : p.nchunks;
     const int txi = nt % p.tiles_x; nt /= p.tiles_x;
     const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
     const int x0 = txi * TW, y0 = tyi * TH, b0 = nt * TB;
@@ -271,12 +281,12 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     // A fragments: [mtile][chunk][tap][msub][hl][lane] units of 16 B
     const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
 
-    if (!(p.dbg & 8)) stage(0, 0);
+    if (!(p.dbg & 8)) stage(c_lo, 0);
     __syncthreads();
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        if (ch + 1 < p.nchunks && !(p.dbg & 1)) stage(ch + 1, (ch + 1) & 1);
-        const uint4* sb = smem_u + (ch & 1) * UNITS;
+    for (int ch = c_lo; ch < c_hi; ++ch) {
+        if (ch + 1 < c_hi && !(p.dbg & 1)) stage(ch + 1, (ch + 1 - c_lo) & 1);
+        const uint4* sb = smem_u + ((ch - c_lo) & 1) * UNITS;
         if (p.dbg & 2) { __syncthreads(); continue; }
         const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
         uint4 a_cur[4];
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     }
 
     if (p.dbg & 4) return;
-    sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
+    sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0, ks);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -675,6 +685,41 @@ __global__ __launch_bounds__(256, 1) void conv_sh16v2_kernel(const ConvParams p)
     sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
 }
 
+// split-K reduce for the C4 layout: out = act(sum_s partial[s] + bias (+ res)), fixed summation order (reproducible)
+template <int DUMMY>
+__global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
+    const long long HW = (long long)p.H * p.W;
+    const int C4n = (p.Mrows + 3) >> 2;
+    const long long n = (long long)p.B * C4n * HW;       // float4 elements
+    const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < p.splitk; ++s) {
+            const float4 t = reinterpret_cast<const float4*>(p.partial)[(long long)s * n + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int cg = (int)((i / HW) % C4n);
+        if (p.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cg * 4);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.res) {
+            const long long pix = i % HW;
+            const int y = (int)(pix / p.W), x = (int)(pix % p.W);
+            rv = reinterpret_cast<const float4*>(p.res)[(i / HW) * (rW * rH) + (long long)(y >> p.res_up) * rW + (x >> p.res_up)];
+        }
+        if (p.res_after_act) {
+            v.x = apply_act(v.x, p.act) + rv.x; v.y = apply_act(v.y, p.act) + rv.y;
+            v.z = apply_act(v.z, p.act) + rv.z; v.w = apply_act(v.w, p.act) + rv.w;
+        } else {
+            v.x = apply_act(v.x + rv.x, p.act); v.y = apply_act(v.y + rv.y, p.act);
+            v.z = apply_act(v.z + rv.z, p.act); v.w = apply_act(v.w + rv.w, p.act);
+        }
+        reinterpret_cast<float4*>(p.out)[i] = v;
+    }
+}
+
 template <int KS, int TW, int TH, int TB, int EPI>
 hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
@@ -692,7 +737,25 @@ hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     p.tiles_y = (p.H + TH - 1) / TH;
     p.tiles_b = (p.B + TB - 1) / TB;
     const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, stream, p);
+    p.splitk = 1;
+    p.cps = p.nchunks;
+    if (EPI == EPI_PLAIN && p.partial && grid < 192 && p.nchunks >= 8) {
+        // few tiles, long reduction (low-resolution 1024-channel layers, small batches): split K over more blocks
+        const long long slab = (long long)p.B * ((p.Mrows + 3) / 4 * 4) * p.H * p.W;
+        int sk = (512 + grid - 1) / grid;
+        if (sk > p.nchunks / 2) sk = p.nchunks / 2;
+        if ((long long)sk * slab > p.partial_cap) sk = (int)(p.partial_cap / slab);
+        if (sk > 1) {
+            p.cps = (p.nchunks + sk - 1) / sk;
+            p.splitk = (p.nchunks + p.cps - 1) / p.cps;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid * p.splitk), dim3(256), Cfg::LDS_BYTES, stream, p);
+    if (p.splitk > 1) {
+        const long long n = (long long)p.B * ((p.Mrows + 3) / 4) * p.H * p.W;
+        const int rg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(sh16_splitk_reduce_kernel<0>, dim3(rg), dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

@@ -181,7 +181,7 @@ constexpr int FCMU_BT = 8;
 
 __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ codes, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ mu_img, int B,
-                                                    int Npad) {
+                                                    int Npad, float* __restrict__ mu_rows) {
     const int j = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o0 = (blockIdx.x * 4 + wave) * 4;           // 4 output features per wave
@@ -225,15 +225,17 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
                 for (int t = 0; t < FCMU_BT; ++t)
                     if (bb + t < B) {
                         const float v = part[i][t] + bias[j * 512 + o0 + i];
-                        mu_img[(long long)(o0 + i) * Npad + (bb + t) * 19 + j] = v > 0.f ? v : 0.f;
+                        const float r = v > 0.f ? v : 0.f;
+                        if (mu_rows) mu_rows[((long long)(bb + t) * 19 + j) * 512 + o0 + i] = r;   // [N][512] for the GEMV path
+                        else mu_img[(long long)(o0 + i) * Npad + (bb + t) * 19 + j] = r;
                     }
         }
     }
 }
 
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad,
-                 hipStream_t s) {
-    hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad);
+                 hipStream_t s, float* mu_rows) {
+    hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad, mu_rows);
     return hipGetLastError();
 }
 

@@ -199,6 +199,16 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     return gb ? ab * cbp[((size_t)c * STYLE + k) * 9 + t] : ag * cgp[((size_t)c * STYLE + k) * 9 + t];
                 });
                 a.lut_wpk = B.upload(lp);
+                if (max_batch * LABEL_NC <= 64) {   // small batches (interactive use): the LUT build is a weight-streaming GEMV
+                    std::vector<float> rows((size_t)18 * C * STYLE);
+                    for (int row = 0; row < 18 * C; ++row) {
+                        const int t = row / (2 * C), gb = (row / C) & 1, cc = row % C;
+                        const float* src = gb ? cbp : cgp;
+                        const float al = gb ? ab : ag;
+                        for (int k = 0; k < STYLE; ++k) rows[(size_t)row * STYLE + k] = al * src[((size_t)cc * STYLE + k) * 9 + t];
+                    }
+                    a.lut_rows = B.upload(rows);
+                }
             }
             a.bn_a = B.upload(va);
             a.bn_d = B.upload(vd);
@@ -241,6 +251,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         has_zencoder = true;
     }
 
+    splitk_cap = (long long)16 << 20;     // 64 MiB of split-K slabs (low-resolution layers only)
+    splitk_ws = B.falloc((size_t)splitk_cap);
     zero_page = static_cast<float*>(B.dalloc(256));
     if (zero_page) (void)hipMemset(zero_page, 0, 256);
 
@@ -366,6 +378,14 @@ struct Runner {
         const double npix = (double)B * r * r;
         if (a.styled) {
             const int N = B * LABEL_NC, npad = ((N + 31) / 32) * 32;
+            if (a.lut_rows && N <= 64) {
+                // interactive batch sizes: P[n][row] = sum_k W[row][k] mu[n][k] as a batched GEMV (weight-bandwidth bound)
+                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, m.mu_img), "fc_mu");
+                timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N), [&] {
+                    check(linear(m.mu_img, a.lut_rows, nullptr, nullptr, nullptr, m.lut, N, STYLE, 18 * a.C, STYLE, 18 * a.C,
+                                 ACT_NONE, st), "lut gemv");
+                });
+            } else {
             check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st), "fc_mu");
             ConvParams p{};
             p.in = m.mu_img;
@@ -380,6 +400,7 @@ struct Runner {
             p.pad = -1;
             timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
                   [&] { check(conv_nhwc1x1(p, st), "lut gemm"); });
+            }
         }
         const bool gen = m.sh16_mode == 3;       // SPADE conv generates actv in-kernel: nothing to materialise
         if (gen) {
@@ -438,6 +459,8 @@ struct Runner {
         p.pad = -1;
         p.zeros = m.sh16_mode == 2 ? m.zero_page : nullptr;
         p.dbg = m.dbg;
+        p.partial = m.splitk_ws;
+        p.partial_cap = m.splitk_cap;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS;
         timed(0, 2.0 * w.Cout * w.Cin * k2 * npix,
               4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * k2), [&] {

@@ -28,6 +28,7 @@ struct AceW {
     float *actv_table = nullptr, *actv_bias = nullptr;   // mlp_shared as label LUT [19*9][128]
     float *fcmu_w = nullptr, *fcmu_b = nullptr;          // [19][512][512], [19][512]
     float* lut_wpk = nullptr;                   // rows (tap, gamma|beta, c) x K=512
+    float* lut_rows = nullptr;                  // same rows, plain [18C][512] (GEMV path for batches <= 3)
 };
 
 struct BlockW {
@@ -48,6 +49,8 @@ struct SeanModel {
     int ngf = 0, max_batch = 0, max_size = 0;
     int sh16_mode = 0;         // 0 exact f32 | 1 f16x3 (register-staged, 2 blocks/CU) | 2 f16x3 v2 (LDS-DMA ring, 1 block/CU)
     float* zero_page = nullptr;
+    float* splitk_ws = nullptr;
+    long long splitk_cap = 0;
     int dbg = 0;               // perf experiments (conv_mfma.h ConvParams::dbg)
     bool use_sh16 = false;     // generator convs on the f16x3 split-operand MFMA path (conv_sh16.h)
     std::vector<BlockW> blocks;

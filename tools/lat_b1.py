@@ -1,0 +1,28 @@
+"""Single-image render latency (the call behind Backend.output): python tools/lat_b1.py [S]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ctrlhair_amd import procedural as P
+from ctrlhair_amd.sean.generator import SeanGenerator
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+for mode, name in ((1, 'f16x3'), (0, 'f32')):
+    g = SeanGenerator(0, f16x3=mode).load_state_dict(P.sean_state_dict(0, 64), max_batch=1, max_size=S)
+    dev = g.device
+    l = torch.from_numpy(P.blocky_labels(1, S)).to(dev)
+    c = torch.from_numpy(P.style_codes(1)).to(dev)
+    n = torch.from_numpy(P.noise_planes(1, S, 64)).to(dev)
+    for _ in range(3):
+        g.generate(l, c, n)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        g.generate(l, c, n)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'{name} S={S} batch 1: {e0.elapsed_time(e1) / 20:.3f} ms per image')
+    del g
