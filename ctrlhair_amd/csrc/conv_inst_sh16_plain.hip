@@ -3,6 +3,8 @@
 namespace chk {
 template <int KS>
 static hipError_t go(const ConvParams& p, hipStream_t s) {
+    if ((p.dbg & 64) && p.W >= 32 && !(p.partial && p.mtiles_hint_small))   // v3: wave-specialised persistent kernel
+        return launch_sh16v3<KS, 32, 16, 1, EPI_PLAIN>(p, p.Mrows, s);
     if (p.zeros) {   // v2: LDS-DMA ring, one block per CU
         if (p.W >= 32) return launch_sh16v2<KS, 32, 16, 1, EPI_PLAIN>(p, p.Mrows, s);
         if (p.W > 8) return launch_sh16v2<KS, 16, 16, 2, EPI_PLAIN>(p, p.Mrows, s);
@@ -12,6 +14,7 @@ static hipError_t go(const ConvParams& p, hipStream_t s) {
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN>(p, p.Mrows, s);
 }
 hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s) {
+    if (p.act > ACT_RELU) return hipErrorInvalidValue;   // the f16x3 epilogues implement none / leaky / relu only
     return KS == 3 ? go<3>(p, s) : (KS == 1 ? go<1>(p, s) : hipErrorInvalidValue);
 }
 }  // namespace chk

@@ -37,6 +37,49 @@ struct ShCfg {
     static_assert(TW * TH * TB == 512, "block tile is 512 pixels");
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// ACE modulation of 4 consecutive channels of one pixel, written on float2 pairs so that the arithmetic maps onto the
+// packed-f32 VALU ops (v_pk_add/mul/fma_f32) and v_cvt_pk_f16_f32: o = act((a*x + n*nz + d) * (1 + gamma) + beta) with
+// gamma = acc_g + (bias_g + style_g), beta likewise; act = max(o, slope*o) (slope 1 / 0.2 / 0 = none / leaky / relu).
+// Returns the f16 hi halves in .x/.y and the residual lo halves in .z/.w (two channels per dword).
+__device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3, float b0, float b1, float b2, float b3,
+                                          const float4& bg, const float4& bb, const float4& pa, const float4& pd,
+                                          const float4& pn, const float4& x4, float nz, float slope) {
+    uint4 w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 ag = h ? f32x2{g2, g3} : f32x2{g0, g1}, ab = h ? f32x2{b2, b3} : f32x2{b0, b1};
+        const f32x2 vbg = h ? f32x2{bg.z, bg.w} : f32x2{bg.x, bg.y}, vbb = h ? f32x2{bb.z, bb.w} : f32x2{bb.x, bb.y};
+        const f32x2 va = h ? f32x2{pa.z, pa.w} : f32x2{pa.x, pa.y}, vd = h ? f32x2{pd.z, pd.w} : f32x2{pd.x, pd.y};
+        const f32x2 vn = h ? f32x2{pn.z, pn.w} : f32x2{pn.x, pn.y}, vx = h ? f32x2{x4.z, x4.w} : f32x2{x4.x, x4.y};
+        const f32x2 gam1 = (ag + vbg) + 1.f;
+        const f32x2 bet = ab + vbb;
+        const f32x2 nrm = va * vx + (vn * nz + vd);
+        f32x2 o = nrm * gam1 + bet;
+        const f32x2 os = o * slope;
+        o.x = fmaxf(o.x, os.x);
+        o.y = fmaxf(o.y, os.y);
+        const f16x2 hh = __builtin_convertvector(o, f16x2);
+        const f32x2 lo = o - __builtin_convertvector(hh, f32x2);
+        const f16x2 ll = __builtin_convertvector(lo, f16x2);
+        if (h == 0) { w.x = __builtin_bit_cast(unsigned, hh); w.z = __builtin_bit_cast(unsigned, ll); }
+        else        { w.y = __builtin_bit_cast(unsigned, hh); w.w = __builtin_bit_cast(unsigned, ll); }
+    }
+    return w;
+}
+
+__device__ __forceinline__ float act_slope(int act) { return act == ACT_NONE ? 1.f : (act == ACT_LRELU ? 0.2f : 0.f); }
+
+// lanes l / l+32 hold channels 0-3 / 4-7 of the same pixel: one v_permlane32_swap per dword leaves lanes < 32 with the
+// 8 hi halves and lanes >= 32 with the 8 lo halves, i.e. one 16-byte SH16 unit per lane
+__device__ __forceinline__ uint4 sh16_pair_swap(const uint4& w) {
+    auto r0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+    return make_uint4(r0[0], r1[0], r0[1], r1[1]);
+}
+
 template <int TW, int TH, int TB, int EPI>
 __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)[2][4], int mtile64, int wn, int lane,
                                               int x0, int y0, int b0, int ks = 0) {
@@ -65,6 +108,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
         // f32 outputs of these convs use the "C4" layout [B][C/4][H][W][4]: a lane's 4 consecutive rows of one pixel are
         // one float4, lanes run along x -> 512 contiguous bytes per half-wave store (and per residual load).
         const int C4n = (p.Mrows + 3) >> 2;
+        const float slope = act_slope(p.act);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
@@ -91,12 +135,14 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                         float4 v;
                         v.x = acc[m][n][rq * 4 + 0] + b4.x; v.y = acc[m][n][rq * 4 + 1] + b4.y;
                         v.z = acc[m][n][rq * 4 + 2] + b4.z; v.w = acc[m][n][rq * 4 + 3] + b4.w;
+                        // act = max(v, slope*v): none / leaky / relu without a per-element switch
                         if (p.res_after_act) {
-                            v.x = apply_act(v.x, p.act) + rv.x; v.y = apply_act(v.y, p.act) + rv.y;
-                            v.z = apply_act(v.z, p.act) + rv.z; v.w = apply_act(v.w, p.act) + rv.w;
+                            v.x = fmaxf(v.x, slope * v.x) + rv.x; v.y = fmaxf(v.y, slope * v.y) + rv.y;
+                            v.z = fmaxf(v.z, slope * v.z) + rv.z; v.w = fmaxf(v.w, slope * v.w) + rv.w;
                         } else {
-                            v.x = apply_act(v.x + rv.x, p.act); v.y = apply_act(v.y + rv.y, p.act);
-                            v.z = apply_act(v.z + rv.z, p.act); v.w = apply_act(v.w + rv.w, p.act);
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                            v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+                            v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
                         }
                         reinterpret_cast<float4*>(p.out)[((long long)b * C4n + (row0 >> 2)) * HW + pix] = v;
                     }
@@ -107,7 +153,6 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
         const int C = p.C;
         const int Go = (C + 7) >> 3;
         const int xW = p.W >> p.x_up, xH = p.H >> p.x_up;
-        _Float16* oh = reinterpret_cast<_Float16*>(p.out);
         int pb_[4], py_[4], px_[4];
         float nzv[4];
         unsigned long long labs[4];          // 9 neighbour labels x 5 bits (31 = outside the image)
@@ -134,68 +179,58 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
             }
             labs[n] = lv;
         }
-        auto comp = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
+        // Addressing: wave-uniform 64-bit bases (sample b0) + 32-bit per-lane byte offsets.
+        const float slope = act_slope(p.act);
+        const int xHW = xW * xH;
+        const char* xbase = reinterpret_cast<const char*>(p.x) + (long long)b0 * (C >> 2) * xHW * 16;
+        char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
+        const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * 19 * 9 * (2 * C) * 4;
+        unsigned xo_[4], oo_[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const unsigned tb = pb_[n] < 0 ? 0u : (unsigned)(pb_[n] - b0);
+            xo_[n] = (tb * (unsigned)(C >> 2) * xHW + (unsigned)(py_[n] >> p.x_up) * xW + (unsigned)(px_[n] >> p.x_up)) * 16u;
+            oo_[n] = ((tb * Go * 2 + hi) * (unsigned)HW + (unsigned)py_[n] * p.W + (unsigned)px_[n]) * 16u;
+        }
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const int g = mtile64 * 4 + rq;                  // output channel group (8 channels)
             const int c0 = g * 8 + 4 * hi;                   // this lane's 4 consecutive channels (C % 4 == 0)
             if (g >= Go) continue;
             const bool cok = c0 < C;
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 pg = cok ? *reinterpret_cast<const float4*>(p.bias_g + c0) : z4;
-            const float4 pb = cok ? *reinterpret_cast<const float4*>(p.bias_b + c0) : z4;
-            const float4 pa = cok ? *reinterpret_cast<const float4*>(p.bn_a + c0) : z4;
-            const float4 pd = cok ? *reinterpret_cast<const float4*>(p.bn_d + c0) : z4;
-            const float4 pn = cok ? *reinterpret_cast<const float4*>(p.nv + c0) : z4;
+            const int cc = cok ? c0 : 0;
+            const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + cc);
+            const float4 pb = *reinterpret_cast<const float4*>(p.bias_b + cc);
+            const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + cc);
+            const float4 pd = *reinterpret_cast<const float4*>(p.bn_d + cc);
+            const float4 pn = *reinterpret_cast<const float4*>(p.nv + cc);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int b = pb_[n], y = py_[n], x = px_[n];
-                if (b < 0) continue;
+                if (pb_[n] < 0) continue;
+                const unsigned tb = (unsigned)(pb_[n] - b0);
                 float4 sg = z4, sb = z4;
-                if (p.lut && cok) {
-                    const float* Lb = p.lut + (long long)b * 19 * 9 * (2 * C) + c0;
+                if (p.lut) {
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const unsigned j = (unsigned)(labs[n] >> (5 * t)) & 31u;
                         const float w = j < 19u ? 1.f : 0.f;             // outside the image: contributes 0
-                        const float* Lp = Lb + (long long)((j < 19u ? j : 0u) * 9 + t) * (2 * C);
+                        const char* Lp = lbase + (((tb * 19u + (j < 19u ? j : 0u)) * 9u + t) * (unsigned)(2 * C) + (unsigned)cc) * 4u;
                         const float4 g4 = *reinterpret_cast<const float4*>(Lp);
-                        const float4 b4 = *reinterpret_cast<const float4*>(Lp + C);
+                        const float4 b4 = *reinterpret_cast<const float4*>(Lp + C * 4);
                         sg.x += w * g4.x; sg.y += w * g4.y; sg.z += w * g4.z; sg.w += w * g4.w;
                         sb.x += w * b4.x; sb.y += w * b4.y; sb.z += w * b4.z; sb.w += w * b4.w;
                     }
                 }
-                const long long xpix = (long long)(y >> p.x_up) * xW + (x >> p.x_up);
                 // x in the C4 layout [B][C/4][h][w][4]: this lane's 4 channels of the pixel are one float4
-                const float4 x4 = reinterpret_cast<const float4*>(p.x)[((long long)b * (C >> 2) + ((cok ? c0 : 0) >> 2)) * (xW * xH) + xpix];
-                half4 vh, vl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = rq * 4 + e;
-                    const float gam = acc[0][n][r] + comp(pg, e) + comp(sg, e);
-                    const float bet = acc[1][n][r] + comp(pb, e) + comp(sb, e);
-                    const float xv = comp(x4, e);
-                    const float nrm = comp(pa, e) * xv + comp(pn, e) * nzv[n] + comp(pd, e);
-                    float o = apply_act(nrm * (1.f + gam) + bet, p.act);
-                    o = c0 + e < C ? o : 0.f;
-                    const _Float16 h = (_Float16)o;
-                    vh[e] = h;
-                    vl[e] = (_Float16)(o - (float)h);
-                }
-                // Lane l (l < 32) holds channels 0-3 of the unit, lane l+32 channels 4-7 of the SAME pixel.  One
-                // v_permlane32_swap per dword hands lane l its partner's hi half and lane l+32 its partner's lo half, so
-                // each lane issues ONE 16-byte store (lanes 0-31: hi plane, 32-63: lo plane; 512 B contiguous each).
-                uint2 wh = __builtin_bit_cast(uint2, vh), wl = __builtin_bit_cast(uint2, vl);
-                {
-                    auto r0 = __builtin_amdgcn_permlane32_swap(wh.x, wl.x, false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(wh.y, wl.y, false, false);
-                    wh.x = r0[0]; wl.x = r0[1];
-                    wh.y = r1[0]; wl.y = r1[1];
-                }
-                // lanes < 32 now hold {own hi (ch 0-3) in wh, partner hi (ch 4-7) in wl};
-                // lanes >= 32 hold {partner lo (ch 0-3) in wh, own lo (ch 4-7) in wl}
-                const long long unit = (((long long)b * Go + g) * 2 + hi) * HW + (long long)y * p.W + x;
-                reinterpret_cast<uint4*>(oh)[unit] = make_uint4(wh.x, wh.y, wl.x, wl.y);
+                const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo_[n] + (unsigned)(cc >> 2) * xHW * 16u));
+                const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
+                const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
+                uint4 w = ace_quad(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
+                                   acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
+                                   bg, bb, pa, pd, pn, x4, nzv[n], slope);
+                if (!cok) w = make_uint4(0, 0, 0, 0);            // padding channels of the last group hold zeros
+                *reinterpret_cast<uint4*>(obase + (oo_[n] + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -539,6 +574,354 @@ hipError_t launch_sh16_gen(ConvParams p, int rows, hipStream_t stream) {
     return hipGetLastError();
 }
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+// -----------------------------------------------------------------------------------------------------------------
+// v3: wave-specialised persistent kernel.  One 512-thread block per CU: waves 0-3 are CONSUMERS (fragment reads + MFMA
+// + epilogue), waves 4-7 are LOADERS (HBM/L2 -> VGPR -> LDS staging of the input patches, one chunk ahead in
+// registers, two LDS stages).  A wave's vector-memory results return in order, so a wave that mixes multi-microsecond
+// patch loads with its L1-resident A-fragment loads stalls its MFMA stream on every chunk; here the long-latency loads
+// live in other waves.  Blocks are persistent (grid = #CUs) and walk the tile list with a static stride, so the loaders
+// already fetch the next tile's first chunks while the consumers run the epilogue (no exposed prologue).
+template <int KS, int TW, int TH, int TB, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p) {
+    using Cfg = ShCfg<KS, TW, TH, TB>;
+    constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, HALO = Cfg::HALO;
+    constexpr int NT = KS * KS;
+    constexpr int NLD = (UNITS + 255) / 256;                 // units per loader thread per chunk
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+    // LDS map (16-byte units): [2 patch stages][xs: 8 channel-runs x 512 px float4][par: 8 runs x 5 float4][nz: 512 f32]
+    //                          [lab: TB*(TH+2)*(TW+2) bytes]  -- the last four are the ACE epilogue's operands, staged by
+    // the loaders during the tile's final chunks so that the consumers' epilogue performs no global-memory round trip.
+    constexpr int XS0 = 2 * UNITS, PAR0 = XS0 + 8 * 512, NZ0 = PAR0 + 8 * 5, LAB0 = NZ0 + 128;
+    constexpr int LW = TW + 2, LH = TH + 2;
+    constexpr bool pre = EPI == EPI_ACE;    /* host guarantees nchunks >= 3 */       // epilogue operands prefetched through LDS
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int wn = wave & 3, ltid = tid & 255;
+    const int HW = p.H * p.W;
+    const int G = p.Cin >> 3;
+    const int ntiles = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    const int first = xcd_remap(blockIdx.x, gridDim.x);      // logical slot of this block inside one round of tiles
+    const int my_tiles = first < ntiles ? (ntiles - 1 - first) / (int)gridDim.x + 1 : 0;
+    const int Q = my_tiles * p.nchunks;                       // chunks this block will process
+    const uint4* gin = reinterpret_cast<const uint4*>(p.in);
+
+    auto tile_coords = [&](int k, int& mtile64, int& x0, int& y0, int& b0) {
+        const int L = first + k * (int)gridDim.x;
+        mtile64 = L % p.mtiles;
+        int nt = L / p.mtiles;
+        const int txi = nt % p.tiles_x; nt /= p.tiles_x;
+        const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
+        x0 = txi * TW; y0 = tyi * TH; b0 = nt * TB;
+    };
+
+    if (loader) {
+        // ---------------------------------------------------------------- loaders
+        int soff[NLD];
+        int cur_tile = -1;
+        auto set_tile = [&](int k) {
+            int mt, x0, y0, b0;
+            tile_coords(k, mt, x0, y0, b0);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int u = ltid + i * 256;
+                soff[i] = -1;
+                if (u < UNITS) {
+                    const int gh = u / PLANE, rem = u % PLANE;
+                    const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
+                    int y = y0 + py - HALO, x = x0 + px - HALO;
+                    const int b = b0 + tb;
+                    if (p.pad_mode == PAD_REFLECT) {
+                        y = y < 0 ? -y : (y >= p.H ? 2 * (p.H - 1) - y : y);
+                        x = x < 0 ? -x : (x >= p.W ? 2 * (p.W - 1) - x : x);
+                    }
+                    if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                        soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
+                }
+            }
+            cur_tile = k;
+        };
+        uint4 stg[NLD];
+        auto load_chunk = [&](int q) {           // global chunk index q -> (tile, chunk)
+            const int k = q / p.nchunks, ch = q % p.nchunks;
+            if (k != cur_tile) set_tile(k);
+            const uint4* src = gin + (long long)ch * 4 * HW;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+        };
+        auto store_chunk = [&](int stage) {
+            uint4* dst = smem_u + stage * UNITS;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int u = ltid + i * 256;
+                if (u < UNITS) dst[u] = stg[i];
+            }
+        };
+        // ---- ACE epilogue operands of tile k: x (C4, optionally x2 up-sampled read), per-channel parameters, noise,
+        // label patch.  Loaded into registers at the tile's second-to-last chunk, written to LDS at its last chunk.
+        float4 parr = make_float4(0.f, 0.f, 0.f, 0.f);
+        float nzr[2] = {0.f, 0.f};
+        uint8_t labr[4] = {255, 255, 255, 255};
+        // x goes global -> LDS by DMA (no VGPR round trip), one channel run (64 lanes x 8 instructions) at a time, spread
+        // over chunks 1 .. nchunks-2 of the tile (never chunk 0: the consumers may still be reading the previous tile's
+        // operands until they pass the first barrier of this tile).
+        auto epi_dma = [&](int k, int ch) {
+            int mt, x0, y0, b0;
+            tile_coords(k, mt, x0, y0, b0);
+            const int C = p.C, xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
+            long long po[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = (wn * 2 + j) * 64 + lane;
+                const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+                const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+                const bool ok = b < p.B && y < p.H && x < p.W;
+                po[j] = ok ? (long long)b * (C >> 2) * xHW + (long long)(y >> p.x_up) * xW + (x >> p.x_up) : -1;
+            }
+            const int span = p.nchunks - 2;
+#pragma unroll
+            for (int run = 0; run < 8; ++run) {
+                if (1 + run * span / 8 != ch) continue;
+                const int cg = mt * 8 + run;
+                const bool cok = cg * 4 < C;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4* src = reinterpret_cast<const float4*>(p.x) + (cok && po[j] >= 0 ? po[j] + (long long)cg * xHW : 0);
+                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(smem_u + XS0 + run * 512 + (wn * 2 + j) * 64),
+                                                     16, 0, 0);
+                }
+            }
+        };
+        auto epi_load = [&](int k) {
+            int mt, x0, y0, b0;
+            tile_coords(k, mt, x0, y0, b0);
+            const int C = p.C;
+            if (ltid < 40) {                                              // par[run][which]: bias_g, bias_b, bn_a, bn_d, nv
+                const int run = ltid / 5, which = ltid % 5;
+                const int c0 = (mt * 8 + run) * 4;
+                const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
+                parr = *reinterpret_cast<const float4*>(src + (c0 < C ? c0 : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = ltid + i * 256;
+                const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+                const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+                const bool ok = b < p.B && y < p.H && x < p.W;
+                nzr[i] = p.noise[ok ? (long long)b * p.noise_bstride + (long long)x * p.H + y : 0];
+            }
+            if (p.lut) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = ltid + i * 256;
+                    labr[i] = 255;
+                    if (e < TB * LH * LW) {
+                        const int tb = e / (LH * LW), ly = (e / LW) % LH, lx = e % LW;
+                        const int b = b0 + tb, y = y0 - 1 + ly, x = x0 - 1 + lx;
+                        const bool in = b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                        const uint8_t v = p.lab[in ? (long long)b * HW + y * p.W + x : 0];
+                        labr[i] = in ? v : (uint8_t)255;
+                    }
+                }
+            }
+        };
+        auto epi_store = [&]() {
+            if (ltid < 40) reinterpret_cast<float4*>(smem_u + PAR0)[ltid] = parr;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) reinterpret_cast<float*>(smem_u + NZ0)[ltid + i * 256] = nzr[i];
+            if (p.lut) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = ltid + i * 256;
+                    if (e < TB * LH * LW) reinterpret_cast<uint8_t*>(smem_u + LAB0)[e] = labr[i];
+                }
+            }
+        };
+        if (Q > 0) {
+            load_chunk(0);
+            store_chunk(0);
+            if (Q > 1) load_chunk(1);
+        }
+        __syncthreads();                                      // stage 0 ready
+        for (int q = 0; q < Q; ++q) {
+            const int k = q / p.nchunks, ch = q % p.nchunks;
+            if (q + 1 < Q) store_chunk((q + 1) & 1);          // chunk q+1 (loaded one iteration ago) -> other stage
+            if (pre && ch == p.nchunks - 1) epi_store();      // consumers read these after this iteration's barrier
+            if (pre && ch >= 1 && ch <= p.nchunks - 2) epi_dma(k, ch);   // complete (in-order) before the next store_chunk
+            if (q + 2 < Q) load_chunk(q + 2);                 // in flight during the consumers' next chunk
+            if (pre && ch == p.nchunks - 2) epi_load(k);
+            if (pre && ch == p.nchunks - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumers
+    int ub[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int idx = wn * 128 + n * 32 + (lane & 31);
+        const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+        ub[n] = (lane >> 5) * 2 * PLANE + tb * (PH * PW) + ty * PW + tx;
+    }
+    __syncthreads();                                          // stage 0 ready
+    int q = 0;
+    for (int k = 0; k < my_tiles; ++k) {
+        int mtile64, x0, y0, b0;
+        tile_coords(k, mtile64, x0, y0, b0);
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
+        for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
+            const uint4* sb = smem_u + (q & 1) * UNITS;
+            const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
+            // One wave per SIMD: nothing hides a stalled MFMA stream, so the k-step is hand-ordered and pinned with
+            // sched_barrier: group i = {1 operand fetch of k-step t+1 (4 A loads from L1/L2, 8 B ds_read_b128), 2 MFMAs
+            // of k-step t}; consecutive MFMAs hit different accumulators (term-major order).
+            uint4 a_cur[4], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a_cur[i] = Ac[i * 64];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bh[n] = sb[ub[n]];
+                bl[n] = sb[ub[n] + PLANE];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint4 a_nxt[4], bhn[4], bln[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a_nxt[i] = a_cur[i]; bhn[i] = bh[i]; bln[i] = bl[i]; }
+                const int koff = ((t + 1) / KS) * PW + ((t + 1) % KS);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    if (t + 1 < NT) {
+                        if (i < 4) a_nxt[i] = Ac[((t + 1) * 4 + i) * 64];
+                        else if ((i & 1) == 0) bhn[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff];
+                        else bln[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff + PLANE];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = 2 * i + jj, term = j >> 3, m = (j & 7) >> 2, n = j & 3;
+                        const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
+                        const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
+                        const half8 xh = __builtin_bit_cast(half8, bh[n]);
+                        const half8 xl = __builtin_bit_cast(half8, bl[n]);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al : ah, term == 1 ? xl : xh, acc[m][n], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a_cur[i] = a_nxt[i]; bh[i] = bhn[i]; bl[i] = bln[i]; }
+            }
+            __syncthreads();
+        }
+        // after the last chunk's barrier the consumers no longer touch LDS: the loaders go on staging the next tile
+        // while the epilogue runs
+        if (p.dbg & 4) continue;
+        if constexpr (!pre) {
+            sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
+        } else {
+            // ---- ACE epilogue fed from LDS (x, parameters, noise, labels): no global load except the style-LUT gathers
+            const int C = p.C, Go = (C + 7) >> 3;
+            const int hi = lane >> 5, col = lane & 31;
+            const float4* xs = reinterpret_cast<const float4*>(smem_u + XS0);
+            const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0);
+            const float* nzs = reinterpret_cast<const float*>(smem_u + NZ0);
+            const uint8_t* labs8 = reinterpret_cast<const uint8_t*>(smem_u + LAB0);
+            const float slope = act_slope(p.act);
+            char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
+                const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * 19 * 9 * (2 * C) * 4;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int idx = wn * 128 + n * 32 + col;
+                const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+                const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+                if (b >= p.B || y >= p.H || x >= p.W) continue;
+                const float nz = nzs[idx];
+                const uint8_t* lp = labs8 + tb * (LH * LW) + ty * LW + tx;      // 3x3 neighbourhood origin
+                unsigned long long lv = 0;
+                if (p.lut) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const unsigned j = lp[(t / 3) * LW + (t % 3)];
+                        lv |= (unsigned long long)(j < 19u ? j : 31u) << (5 * t);
+                    }
+                }
+                const unsigned oo = (((unsigned)tb * Go * 2 + hi) * (unsigned)HW + (unsigned)y * p.W + (unsigned)x) * 16u;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int g = mtile64 * 4 + rq, run = rq * 2 + hi, c0 = g * 8 + 4 * hi;
+                    if (g >= Go) continue;
+                    const bool cok = c0 < C;
+                    const unsigned cc = cok ? c0 : 0;
+                    const float4 pg = par[run * 5 + 0], pb = par[run * 5 + 1], pa = par[run * 5 + 2], pd = par[run * 5 + 3],
+                                 pn = par[run * 5 + 4];
+                    const float4 x4 = xs[run * 512 + idx];
+                    float4 sg = z4, sb = z4;
+                    if (p.lut) {
+#pragma unroll 3
+                        for (int t = 0; t < 9; ++t) {
+                            const unsigned j = (unsigned)(lv >> (5 * t)) & 31u;
+                            const float w = j < 19u ? 1.f : 0.f;
+                            const char* Lp = lbase + ((((unsigned)tb * 19u + (j < 19u ? j : 0u)) * 9u + t) * (unsigned)(2 * C) + cc) * 4u;
+                            const float4 g4 = *reinterpret_cast<const float4*>(Lp);
+                            const float4 b4 = *reinterpret_cast<const float4*>(Lp + C * 4);
+                            sg.x += w * g4.x; sg.y += w * g4.y; sg.z += w * g4.z; sg.w += w * g4.w;
+                            sb.x += w * b4.x; sb.y += w * b4.y; sb.z += w * b4.z; sb.w += w * b4.w;
+                        }
+                    }
+                    const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
+                    const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
+                    uint4 w = ace_quad(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
+                                       acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
+                                       bg, bb, pa, pd, pn, x4, nz, slope);
+                    if (!cok) w = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(obase + (oo + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int TW, int TH, int TB, int EPI>
+hipError_t launch_sh16v3(ConvParams p, int rows, hipStream_t stream) {
+    using Cfg = ShCfg<KS, TW, TH, TB>;
+    auto kern = conv_sh16v3_kernel<KS, TW, TH, TB, EPI>;
+    // patch ring + (ACE) epilogue operands: xs 64 KiB, parameters, noise, label patch
+    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * Cfg::UNITS + 8 * 512 + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
+                                          : Cfg::LDS_BYTES;
+    static bool attr_set = false;
+    static int ncu = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           V3_LDS);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    p.nchunks = (p.Cin + 15) / 16;
+    p.mtiles = (rows + 63) / 64;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.tiles_b = (p.B + TB - 1) / TB;
+    p.splitk = 1;
+    const int ntiles = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), V3_LDS, stream, p);
+    return hipGetLastError();
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // v2: same arithmetic and layouts, different data movement.  ONE block per CU (4 waves, one per SIMD, up to 512 VGPRs):
 // both operands of a 16-channel chunk -- the input patch AND the block's A fragments -- are moved HBM/L2 -> LDS by the
@@ -554,8 +937,6 @@ struct ShCfg2 : ShCfg<KS, TW, TH, TB> {
     static_assert(LDS_BYTES2 <= 160 * 1024, "ring does not fit the 160 KiB LDS");
 };
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void glb_void;
 
 template <int KS, int TW, int TH, int TB, int EPI>
 __global__ __launch_bounds__(256, 1) void conv_sh16v2_kernel(const ConvParams p) {

@@ -461,6 +461,7 @@ struct Runner {
         p.dbg = m.dbg;
         p.partial = m.splitk_ws;
         p.partial_cap = m.splitk_cap;
+        p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS;
         timed(0, 2.0 * w.Cout * w.Cin * k2 * npix,
               4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * k2), [&] {
