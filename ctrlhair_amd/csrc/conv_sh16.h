@@ -644,15 +644,17 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
             }
             cur_tile = k;
         };
-        uint4 stg[NLD];
-        auto load_chunk = [&](int q) {           // global chunk index q -> (tile, chunk)
+        // Two register sets: the patch of chunk q+3 is requested while chunk q is being consumed, i.e. every load has two
+        // full chunk times (~6 us) to return before it is written to LDS -- one chunk time is less than a loaded HBM trip.
+        uint4 stgA[NLD], stgB[NLD];
+        auto load_chunk = [&](int q, uint4 (&stg)[NLD]) {           // global chunk index q -> (tile, chunk)
             const int k = q / p.nchunks, ch = q % p.nchunks;
             if (k != cur_tile) set_tile(k);
             const uint4* src = gin + (long long)ch * 4 * HW;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
         };
-        auto store_chunk = [&](int stage) {
+        auto store_chunk = [&](int stage, const uint4 (&stg)[NLD]) {
             uint4* dst = smem_u + stage * UNITS;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
@@ -741,20 +743,26 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
             }
         };
         if (Q > 0) {
-            load_chunk(0);
-            store_chunk(0);
-            if (Q > 1) load_chunk(1);
+            load_chunk(0, stgA);
+            if (Q > 1) load_chunk(1, stgB);
+            store_chunk(0, stgA);
+            if (Q > 2) load_chunk(2, stgA);
         }
         __syncthreads();                                      // stage 0 ready
-        for (int q = 0; q < Q; ++q) {
+        // iteration q: chunk q+1 (requested two iterations ago) -> LDS stage (q+1)&1, request chunk q+3
+        auto iter = [&](int q, uint4 (&stg)[NLD]) {
             const int k = q / p.nchunks, ch = q % p.nchunks;
-            if (q + 1 < Q) store_chunk((q + 1) & 1);          // chunk q+1 (loaded one iteration ago) -> other stage
+            if (q + 1 < Q) store_chunk((q + 1) & 1, stg);
             if (pre && ch == p.nchunks - 1) epi_store();      // consumers read these after this iteration's barrier
-            if (pre && ch >= 1 && ch <= p.nchunks - 2) epi_dma(k, ch);   // complete (in-order) before the next store_chunk
-            if (q + 2 < Q) load_chunk(q + 2);                 // in flight during the consumers' next chunk
+            if (pre && ch >= 1 && ch <= p.nchunks - 2) epi_dma(k, ch);
+            if (q + 3 < Q) load_chunk(q + 3, stg);
             if (pre && ch == p.nchunks - 2) epi_load(k);
             if (pre && ch == p.nchunks - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+        };
+        for (int q = 0; q < Q; q += 2) {
+            iter(q, stgB);
+            if (q + 1 < Q) iter(q + 1, stgA);
         }
         return;
     }
@@ -780,15 +788,18 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
         const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
+        uint4 a_cur[4];
         for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
             const uint4* sb = smem_u + (q & 1) * UNITS;
             const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
             // One wave per SIMD: nothing hides a stalled MFMA stream, so the k-step is hand-ordered and pinned with
             // sched_barrier: group i = {1 operand fetch of k-step t+1 (4 A loads from L1/L2, 8 B ds_read_b128), 2 MFMAs
             // of k-step t}; consecutive MFMAs hit different accumulators (term-major order).
-            uint4 a_cur[4], bh[4], bl[4];
+            uint4 bh[4], bl[4];
+            if (ch == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a_cur[i] = Ac[i * 64];
+                for (int i = 0; i < 4; ++i) a_cur[i] = Ac[i * 64];
+            }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 bh[n] = sb[ub[n]];
@@ -802,6 +813,9 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
                 const int koff = ((t + 1) / KS) * PW + ((t + 1) % KS);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
+                    // the A fragments of the NEXT chunk's first tap follow this chunk's in memory: fetched across the
+                    // chunk barrier (they do not depend on it), so only the LDS reads restart after the barrier
+                    if (t + 1 == NT && i < 4 && ch + 1 < p.nchunks) a_nxt[i] = Ac[(NT * 4 + i) * 64];
                     if (t + 1 < NT) {
                         if (i < 4) a_nxt[i] = Ac[((t + 1) * 4 + i) * 64];
                         else if ((i & 1) == 0) bhn[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff];
