@@ -14,7 +14,6 @@ static hipError_t go(const ConvParams& p, hipStream_t s) {
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN>(p, p.Mrows, s);
 }
 hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s) {
-    if (p.act > ACT_RELU) return hipErrorInvalidValue;   // the f16x3 epilogues implement none / leaky / relu only
     return KS == 3 ? go<3>(p, s) : (KS == 1 ? go<1>(p, s) : hipErrorInvalidValue);
 }
 }  // namespace chk

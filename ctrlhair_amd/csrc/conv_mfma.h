@@ -65,6 +65,9 @@ struct ConvParams {
     long long noise_bstride;
     const uint8_t* lab;     // [B][H][W]
     const float* lut;       // [B*19][9][2][C] or null (unstyled)
+    int lut_bs;             // f16x3 path: columns per sample (20: labels 0-18 + an all-zero column 19 = outside the image)
+    int lut_rs, lut_ns;     // f16x3 path: element (row = (t*2+gb)*C + c, n = b*lut_bs+j) lives at lut[row*lut_rs + n*lut_ns]
+                            // (1, 18C) = rows contiguous per n;  (Npad, 4) = C4 layout written by the f16x3 LUT GEMM
     int splitk;             // EPI_PLAIN only: K split over `splitk` blocks, raw partial sums to `partial` slabs
     int cps;                // chunks per split
     float* partial;         // [splitk][B][Mrows][H*W] scratch (then splitk_reduce_kernel applies bias/res/act)

@@ -136,7 +136,15 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                         v.x = acc[m][n][rq * 4 + 0] + b4.x; v.y = acc[m][n][rq * 4 + 1] + b4.y;
                         v.z = acc[m][n][rq * 4 + 2] + b4.z; v.w = acc[m][n][rq * 4 + 3] + b4.w;
                         // act = max(v, slope*v): none / leaky / relu without a per-element switch
-                        if (p.res_after_act) {
+                        if (p.act > ACT_RELU) {                     // tanh / sigmoid (Zencoder head): rare, uniform branch
+                            if (p.res_after_act) {
+                                v.x = apply_act(v.x, p.act) + rv.x; v.y = apply_act(v.y, p.act) + rv.y;
+                                v.z = apply_act(v.z, p.act) + rv.z; v.w = apply_act(v.w, p.act) + rv.w;
+                            } else {
+                                v.x = apply_act(v.x + rv.x, p.act); v.y = apply_act(v.y + rv.y, p.act);
+                                v.z = apply_act(v.z + rv.z, p.act); v.w = apply_act(v.w + rv.w, p.act);
+                            }
+                        } else if (p.res_after_act) {
                             v.x = fmaxf(v.x, slope * v.x) + rv.x; v.y = fmaxf(v.y, slope * v.y) + rv.y;
                             v.z = fmaxf(v.z, slope * v.z) + rv.z; v.w = fmaxf(v.w, slope * v.w) + rv.w;
                         } else {
@@ -155,7 +163,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
         const int xW = p.W >> p.x_up, xH = p.H >> p.x_up;
         int pb_[4], py_[4], px_[4];
         float nzv[4];
-        unsigned long long labs[4];          // 9 neighbour labels x 5 bits (31 = outside the image)
+        unsigned long long labs[4];          // 9 neighbour labels x 5 bits (19 = outside the image: the LUT's zero column)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
@@ -174,7 +182,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
                     const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
                     const unsigned jv = lb[in ? yy * p.W + xx : 0];       // unconditional load, select after
-                    lv |= (unsigned long long)(in ? jv : 31u) << (5 * t);
+                    lv |= (unsigned long long)(in ? jv : 19u) << (5 * t);
                 }
             }
             labs[n] = lv;
@@ -184,7 +192,8 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
         const int xHW = xW * xH;
         const char* xbase = reinterpret_cast<const char*>(p.x) + (long long)b0 * (C >> 2) * xHW * 16;
         char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
-        const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * 19 * 9 * (2 * C) * 4;
+        const unsigned lrs = (unsigned)p.lut_rs * 4u, lns = (unsigned)p.lut_ns * 4u;      // LUT strides in bytes
+        const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * p.lut_bs * lns;
         unsigned xo_[4], oo_[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -211,15 +220,18 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                 const unsigned tb = (unsigned)(pb_[n] - b0);
                 float4 sg = z4, sb = z4;
                 if (p.lut) {
+                    // style term: sum over the 9 taps of LUT[(sample, label at the tap)][tap]; taps outside the image carry
+                    // label 19, the all-zero column.  32-bit offsets from a wave-uniform base.
+                    const unsigned cb = tb * (unsigned)p.lut_bs * lns + (unsigned)cc * lrs;
+                    const unsigned lo30 = (unsigned)labs[n], hi15 = (unsigned)(labs[n] >> 30);
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const unsigned j = (unsigned)(labs[n] >> (5 * t)) & 31u;
-                        const float w = j < 19u ? 1.f : 0.f;             // outside the image: contributes 0
-                        const char* Lp = lbase + (((tb * 19u + (j < 19u ? j : 0u)) * 9u + t) * (unsigned)(2 * C) + (unsigned)cc) * 4u;
-                        const float4 g4 = *reinterpret_cast<const float4*>(Lp);
-                        const float4 b4 = *reinterpret_cast<const float4*>(Lp + C * 4);
-                        sg.x += w * g4.x; sg.y += w * g4.y; sg.z += w * g4.z; sg.w += w * g4.w;
-                        sb.x += w * b4.x; sb.y += w * b4.y; sb.z += w * b4.z; sb.w += w * b4.w;
+                        const unsigned j = t < 6 ? (lo30 >> (5 * t)) & 31u : (hi15 >> (5 * (t - 6))) & 31u;
+                        const unsigned o1 = cb + j * lns + (unsigned)(t * 2 * C) * lrs;
+                        const float4 g4 = *reinterpret_cast<const float4*>(lbase + o1);
+                        const float4 b4 = *reinterpret_cast<const float4*>(lbase + (o1 + (unsigned)C * lrs));
+                        sg.x += g4.x; sg.y += g4.y; sg.z += g4.z; sg.w += g4.w;
+                        sb.x += b4.x; sb.y += b4.y; sb.z += b4.z; sb.w += b4.w;
                     }
                 }
                 // x in the C4 layout [B][C/4][h][w][4]: this lane's 4 channels of the pixel are one float4
@@ -591,10 +603,13 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
     constexpr int NT = KS * KS;
     constexpr int NLD = (UNITS + 255) / 256;                 // units per loader thread per chunk
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
-    // LDS map (16-byte units): [2 patch stages][xs: 8 channel-runs x 512 px float4][par: 8 runs x 5 float4][nz: 512 f32]
-    //                          [lab: TB*(TH+2)*(TW+2) bytes]  -- the last four are the ACE epilogue's operands, staged by
-    // the loaders during the tile's final chunks so that the consumers' epilogue performs no global-memory round trip.
-    constexpr int XS0 = 2 * UNITS, PAR0 = XS0 + 8 * 512, NZ0 = PAR0 + 8 * 5, LAB0 = NZ0 + 128;
+    // LDS map (16-byte units): 2 stages of [input patch UNITS | A fragments AUNITS], then (ACE) the epilogue's small
+    // operands [par: 8 runs x 5 float4][nz: 512 f32][lab: TB*(TH+2)*(TW+2) bytes].  The A fragments of a chunk are one
+    // contiguous, already lane-ordered block in global memory: the loaders move it with LDS-DMA (global_load_lds, 16 B
+    // per lane, no VGPR round trip), so the consumers' MFMA stream never waits on an L2 round trip.
+    constexpr int AUNITS = NT * 4 * 64, STAGE = UNITS + AUNITS;
+    constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + 8 * 5, LAB0 = NZ0 + 128;
+    constexpr int NDA = AUNITS / 256;                        // A DMA instructions per loader thread per chunk
     constexpr int LW = TW + 2, LH = TH + 2;
     constexpr bool pre = EPI == EPI_ACE;    /* host guarantees nchunks >= 3 */       // epilogue operands prefetched through LDS
 
@@ -652,51 +667,34 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
             if (k != cur_tile) set_tile(k);
             const uint4* src = gin + (long long)ch * 4 * HW;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NLD; ++i) {                          // exactly NLD loads, always (vmcnt bookkeeping below)
+                const uint4 v = src[soff[i] >= 0 ? soff[i] : 0];
+                stg[i] = soff[i] >= 0 ? v : make_uint4(0, 0, 0, 0);
+            }
+        };
+        const uint4* gA = reinterpret_cast<const uint4*>(p.wpk);
+        auto dma_A = [&](int q) {                                     // A fragments of global chunk q -> its LDS stage
+            int mt, x0, y0, b0;
+            tile_coords(q / p.nchunks, mt, x0, y0, b0);
+            const uint4* src = gA + ((long long)mt * p.nchunks + q % p.nchunks) * AUNITS + ltid;
+            uint4* dst = smem_u + (q & 1) * STAGE + UNITS + wn * 64;
+#pragma unroll
+            for (int i = 0; i < NDA; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + i * 256), (lds_void*)(dst + i * 256), 16, 0, 0);
         };
         auto store_chunk = [&](int stage, const uint4 (&stg)[NLD]) {
-            uint4* dst = smem_u + stage * UNITS;
+            uint4* dst = smem_u + stage * STAGE;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int u = ltid + i * 256;
                 if (u < UNITS) dst[u] = stg[i];
             }
         };
-        // ---- ACE epilogue operands of tile k: x (C4, optionally x2 up-sampled read), per-channel parameters, noise,
-        // label patch.  Loaded into registers at the tile's second-to-last chunk, written to LDS at its last chunk.
+        // ---- small ACE epilogue operands of tile k: per-channel parameters, noise, label patch.  Loaded into registers at
+        // the tile's second-to-last chunk, written to LDS at its last chunk.
         float4 parr = make_float4(0.f, 0.f, 0.f, 0.f);
         float nzr[2] = {0.f, 0.f};
         uint8_t labr[4] = {255, 255, 255, 255};
-        // x goes global -> LDS by DMA (no VGPR round trip), one channel run (64 lanes x 8 instructions) at a time, spread
-        // over chunks 1 .. nchunks-2 of the tile (never chunk 0: the consumers may still be reading the previous tile's
-        // operands until they pass the first barrier of this tile).
-        auto epi_dma = [&](int k, int ch) {
-            int mt, x0, y0, b0;
-            tile_coords(k, mt, x0, y0, b0);
-            const int C = p.C, xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
-            long long po[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = (wn * 2 + j) * 64 + lane;
-                const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-                const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
-                const bool ok = b < p.B && y < p.H && x < p.W;
-                po[j] = ok ? (long long)b * (C >> 2) * xHW + (long long)(y >> p.x_up) * xW + (x >> p.x_up) : -1;
-            }
-            const int span = p.nchunks - 2;
-#pragma unroll
-            for (int run = 0; run < 8; ++run) {
-                if (1 + run * span / 8 != ch) continue;
-                const int cg = mt * 8 + run;
-                const bool cok = cg * 4 < C;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float4* src = reinterpret_cast<const float4*>(p.x) + (cok && po[j] >= 0 ? po[j] + (long long)cg * xHW : 0);
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(smem_u + XS0 + run * 512 + (wn * 2 + j) * 64),
-                                                     16, 0, 0);
-                }
-            }
-        };
         auto epi_load = [&](int k) {
             int mt, x0, y0, b0;
             tile_coords(k, mt, x0, y0, b0);
@@ -743,21 +741,31 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
             }
         };
         if (Q > 0) {
+            dma_A(0);
             load_chunk(0, stgA);
             if (Q > 1) load_chunk(1, stgB);
             store_chunk(0, stgA);
             if (Q > 2) load_chunk(2, stgA);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                      // stage 0 ready
-        // iteration q: chunk q+1 (requested two iterations ago) -> LDS stage (q+1)&1, request chunk q+3
+        // iteration q: A(q+1) by DMA and patch q+1 (requested two iterations ago) -> LDS stage (q+1)&1, request patch q+3.
+        // Vector-memory results return in order, so waiting until only the NLD newest loads (the patch just requested)
+        // are outstanding guarantees that the DMA has landed, without draining the patch prefetch.
         auto iter = [&](int q, uint4 (&stg)[NLD]) {
             const int k = q / p.nchunks, ch = q % p.nchunks;
-            if (q + 1 < Q) store_chunk((q + 1) & 1, stg);
+            if (q + 1 < Q) {
+                dma_A(q + 1);
+                store_chunk((q + 1) & 1, stg);
+            }
             if (pre && ch == p.nchunks - 1) epi_store();      // consumers read these after this iteration's barrier
-            if (pre && ch >= 1 && ch <= p.nchunks - 2) epi_dma(k, ch);
-            if (q + 3 < Q) load_chunk(q + 3, stg);
-            if (pre && ch == p.nchunks - 2) epi_load(k);
-            if (pre && ch == p.nchunks - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (q + 3 < Q) {
+                load_chunk(q + 3, stg);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (pre && ch == p.nchunks - 2) epi_load(k);      // younger than everything waited on above
             __syncthreads();
         };
         for (int q = 0; q < Q; q += 2) {
@@ -787,19 +795,15 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
-        uint4 a_cur[4];
         for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
-            const uint4* sb = smem_u + (q & 1) * UNITS;
-            const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
+            const uint4* sb = smem_u + (q & 1) * STAGE;
+            const uint4* sa = sb + UNITS + lane;
             // One wave per SIMD: nothing hides a stalled MFMA stream, so the k-step is hand-ordered and pinned with
-            // sched_barrier: group i = {1 operand fetch of k-step t+1 (4 A loads from L1/L2, 8 B ds_read_b128), 2 MFMAs
-            // of k-step t}; consecutive MFMAs hit different accumulators (term-major order).
-            uint4 bh[4], bl[4];
-            if (ch == 0) {
+            // sched_barrier: group i = {1 operand fetch of k-step t+1 (4 A + 8 B ds_read_b128), 2 MFMAs of k-step t};
+            // consecutive MFMAs hit different accumulators (term-major order).
+            uint4 a_cur[4], bh[4], bl[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a_cur[i] = Ac[i * 64];
-            }
+            for (int i = 0; i < 4; ++i) a_cur[i] = sa[i * 64];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 bh[n] = sb[ub[n]];
@@ -813,11 +817,8 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
                 const int koff = ((t + 1) / KS) * PW + ((t + 1) % KS);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    // the A fragments of the NEXT chunk's first tap follow this chunk's in memory: fetched across the
-                    // chunk barrier (they do not depend on it), so only the LDS reads restart after the barrier
-                    if (t + 1 == NT && i < 4 && ch + 1 < p.nchunks) a_nxt[i] = Ac[(NT * 4 + i) * 64];
                     if (t + 1 < NT) {
-                        if (i < 4) a_nxt[i] = Ac[((t + 1) * 4 + i) * 64];
+                        if (i < 4) a_nxt[i] = sa[((t + 1) * 4 + i) * 64];
                         else if ((i & 1) == 0) bhn[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff];
                         else bln[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff + PLANE];
                     }
@@ -846,13 +847,15 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
             // ---- ACE epilogue fed from LDS (x, parameters, noise, labels): no global load except the style-LUT gathers
             const int C = p.C, Go = (C + 7) >> 3;
             const int hi = lane >> 5, col = lane & 31;
-            const float4* xs = reinterpret_cast<const float4*>(smem_u + XS0);
+            const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
+            const char* xbase = reinterpret_cast<const char*>(p.x) + (long long)b0 * (C >> 2) * xHW * 16;
             const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0);
             const float* nzs = reinterpret_cast<const float*>(smem_u + NZ0);
             const uint8_t* labs8 = reinterpret_cast<const uint8_t*>(smem_u + LAB0);
             const float slope = act_slope(p.act);
             char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
-                const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * 19 * 9 * (2 * C) * 4;
+            const unsigned lrs = (unsigned)p.lut_rs * 4u, lns = (unsigned)p.lut_ns * 4u;
+            const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * p.lut_bs * lns;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -862,15 +865,16 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
                 if (b >= p.B || y >= p.H || x >= p.W) continue;
                 const float nz = nzs[idx];
                 const uint8_t* lp = labs8 + tb * (LH * LW) + ty * LW + tx;      // 3x3 neighbourhood origin
-                unsigned long long lv = 0;
+                unsigned loff[9];                 // per-tap byte offset of (sample, label) column + tap row block
                 if (p.lut) {
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const unsigned j = lp[(t / 3) * LW + (t % 3)];
-                        lv |= (unsigned long long)(j < 19u ? j : 31u) << (5 * t);
+                        const unsigned j = lp[(t / 3) * LW + (t % 3)];          // 255 outside the image -> zero column 19
+                        loff[t] = ((unsigned)tb * (unsigned)p.lut_bs + (j < 19u ? j : 19u)) * lns + (unsigned)(t * 2 * C) * lrs;
                     }
                 }
                 const unsigned oo = (((unsigned)tb * Go * 2 + hi) * (unsigned)HW + (unsigned)y * p.W + (unsigned)x) * 16u;
+                const unsigned xo = ((unsigned)tb * (unsigned)(C >> 2) * xHW + (unsigned)(y >> p.x_up) * xW + (unsigned)(x >> p.x_up)) * 16u;
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const int g = mtile64 * 4 + rq, run = rq * 2 + hi, c0 = g * 8 + 4 * hi;
@@ -879,18 +883,16 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
                     const unsigned cc = cok ? c0 : 0;
                     const float4 pg = par[run * 5 + 0], pb = par[run * 5 + 1], pa = par[run * 5 + 2], pd = par[run * 5 + 3],
                                  pn = par[run * 5 + 4];
-                    const float4 x4 = xs[run * 512 + idx];
+                    const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo + (cc >> 2) * (unsigned)xHW * 16u));
                     float4 sg = z4, sb = z4;
                     if (p.lut) {
-#pragma unroll 3
+#pragma unroll
                         for (int t = 0; t < 9; ++t) {
-                            const unsigned j = (unsigned)(lv >> (5 * t)) & 31u;
-                            const float w = j < 19u ? 1.f : 0.f;
-                            const char* Lp = lbase + ((((unsigned)tb * 19u + (j < 19u ? j : 0u)) * 9u + t) * (unsigned)(2 * C) + cc) * 4u;
-                            const float4 g4 = *reinterpret_cast<const float4*>(Lp);
-                            const float4 b4 = *reinterpret_cast<const float4*>(Lp + C * 4);
-                            sg.x += w * g4.x; sg.y += w * g4.y; sg.z += w * g4.z; sg.w += w * g4.w;
-                            sb.x += w * b4.x; sb.y += w * b4.y; sb.z += w * b4.z; sb.w += w * b4.w;
+                            const unsigned o1 = loff[t] + cc * lrs;
+                            const float4 g4 = *reinterpret_cast<const float4*>(lbase + o1);
+                            const float4 b4 = *reinterpret_cast<const float4*>(lbase + (o1 + (unsigned)C * lrs));
+                            sg.x += g4.x; sg.y += g4.y; sg.z += g4.z; sg.w += g4.w;
+                            sb.x += b4.x; sb.y += b4.y; sb.z += b4.z; sb.w += b4.w;
                         }
                     }
                     const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
@@ -910,9 +912,10 @@ template <int KS, int TW, int TH, int TB, int EPI>
 hipError_t launch_sh16v3(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     auto kern = conv_sh16v3_kernel<KS, TW, TH, TB, EPI>;
-    // patch ring + (ACE) epilogue operands: xs 64 KiB, parameters, noise, label patch
-    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * Cfg::UNITS + 8 * 512 + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
-                                          : Cfg::LDS_BYTES;
+    // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
+    constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
+    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
+                                          : 2 * V3_STAGE * 16;
     static bool attr_set = false;
     static int ncu = 256;
     if (!attr_set) {

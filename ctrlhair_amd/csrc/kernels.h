@@ -11,7 +11,7 @@ hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const flo
                                int K, int relu, hipStream_t s);
 hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, hipStream_t s);
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad, hipStream_t s,
-                 float* mu_rows = nullptr);
+                 float* mu_rows = nullptr, int sh16 = 0, int bs = 19);
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                          hipStream_t s, int c4 = 0);
 hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hipStream_t s);

@@ -181,7 +181,7 @@ constexpr int FCMU_BT = 8;
 
 __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ codes, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ mu_img, int B,
-                                                    int Npad, float* __restrict__ mu_rows) {
+                                                    int Npad, float* __restrict__ mu_rows, int sh16, int bs) {
     const int j = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o0 = (blockIdx.x * 4 + wave) * 4;           // 4 output features per wave
@@ -226,16 +226,31 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
                     if (bb + t < B) {
                         const float v = part[i][t] + bias[j * 512 + o0 + i];
                         const float r = v > 0.f ? v : 0.f;
-                        if (mu_rows) mu_rows[((long long)(bb + t) * 19 + j) * 512 + o0 + i] = r;   // [N][512] for the GEMV path
-                        else mu_img[(long long)(o0 + i) * Npad + (bb + t) * 19 + j] = r;
+                        const int o = o0 + i, n = (bb + t) * bs + j;      // bs = 19, or 20 with a zero column per sample
+                        if (bs > 19 && j == 0) {   // (re)write the zero column: the image pitch Npad changes with the batch
+                            const int nz = (bb + t) * bs + 19;
+                            if (mu_rows) mu_rows[(long long)nz * 512 + o] = 0.f;
+                            else if (sh16) {
+                                _Float16* mh = reinterpret_cast<_Float16*>(mu_img);
+                                mh[(((long long)(o >> 3) * 2 + 0) * Npad + nz) * 8 + (o & 7)] = (_Float16)0.f;
+                                mh[(((long long)(o >> 3) * 2 + 1) * Npad + nz) * 8 + (o & 7)] = (_Float16)0.f;
+                            }
+                        }
+                        if (mu_rows) mu_rows[(long long)n * 512 + o] = r;   // [N][512] for the GEMV path
+                        else if (sh16) {   // split-operand image [512/8][hi|lo][Npad][8] for the f16x3 LUT GEMM
+                            _Float16* mh = reinterpret_cast<_Float16*>(mu_img);
+                            const _Float16 h = (_Float16)r;
+                            mh[(((long long)(o >> 3) * 2 + 0) * Npad + n) * 8 + (o & 7)] = h;
+                            mh[(((long long)(o >> 3) * 2 + 1) * Npad + n) * 8 + (o & 7)] = (_Float16)(r - (float)h);
+                        } else mu_img[(long long)o * Npad + n] = r;
                     }
         }
     }
 }
 
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad,
-                 hipStream_t s, float* mu_rows) {
-    hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad, mu_rows);
+                 hipStream_t s, float* mu_rows, int sh16, int bs) {
+    hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad, mu_rows, sh16, bs);
     return hipGetLastError();
 }
 

@@ -194,12 +194,12 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 // LUT GEMM rows (t, gamma|beta, c) <- alpha * W[c][k][t]
                 const float* cgp = cg->f32();
                 const float* cbp = cb->f32();
-                auto lp = pack_A(18 * C, STYLE, 1, CK_KS1, [&](int row, int k, int) {
+                auto getl = [&](int row, int k, int) {
                     const int t = row / (2 * C), gb = (row / C) & 1, c = row % C;
                     return gb ? ab * cbp[((size_t)c * STYLE + k) * 9 + t] : ag * cgp[((size_t)c * STYLE + k) * 9 + t];
-                });
-                a.lut_wpk = B.upload(lp);
-                if (max_batch * LABEL_NC <= 64) {   // small batches (interactive use): the LUT build is a weight-streaming GEMV
+                };
+                a.lut_wpk = B.upload(use_sh16 ? pack_A_sh16(18 * C, STYLE, 1, getl) : pack_A(18 * C, STYLE, 1, CK_KS1, getl));
+                if (max_batch * (LABEL_NC + 1) <= 64) {   // small batches (interactive use): the LUT build is a weight-streaming GEMV
                     std::vector<float> rows((size_t)18 * C * STYLE);
                     for (int row = 0; row < 18 * C; ++row) {
                         const int t = row / (2 * C), gb = (row / C) & 1, cc = row % C;
@@ -264,12 +264,13 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     }
     size_t nf = noise_floats(ms);
     noise_ws = static_cast<float*>(B.dalloc(MB * nf * 4));
-    const size_t npad = ((MB * LABEL_NC + 31) / 32) * 32;
+    const size_t npad = ((MB * (LABEL_NC + 1) + 31) / 32) * 32;     // f16x3 path: 20 columns per sample (19 = zero column)
     mu_img = static_cast<float*>(B.dalloc((size_t)STYLE * npad * 4));
+    if (mu_img) (void)hipMemset(mu_img, 0, (size_t)STYLE * npad * 4);      // pad columns stay zero
     size_t lutmax = 0, h0max = 0, midmax = 0, outmax = 0;
     for (const auto& b : blocks) {
         const size_t r = S / b.res_div, px = MB * r * r;
-        if (b.styled) lutmax = std::max(lutmax, (size_t)MB * LABEL_NC * 18 * b.fin);
+        if (b.styled) lutmax = std::max(lutmax, npad * 18 * b.fin);      // npad columns: the f16x3 LUT GEMM writes the pad too
         h0max = std::max(h0max, px * b.fin);
         midmax = std::max(midmax, px * b.fmid);
         outmax = std::max(outmax, px * b.fout);
@@ -376,15 +377,37 @@ struct Runner {
         const int r = S / a.res_div;
         const uint8_t* lab = labels_at(labfull, a.res_div);
         const double npix = (double)B * r * r;
+        int lut_rs = 1, lut_ns = 18 * a.C, lut_bs = LABEL_NC;
         if (a.styled) {
-            const int N = B * LABEL_NC, npad = ((N + 31) / 32) * 32;
+            // f16x3 path: one extra all-zero column per sample (mu = 0 -> LUT = 0) that taps outside the image point at
+            const int bs = m.use_sh16 ? LABEL_NC + 1 : LABEL_NC;
+            const int N = B * bs, npad = ((N + 31) / 32) * 32;
+            lut_bs = bs;
             if (a.lut_rows && N <= 64) {
                 // interactive batch sizes: P[n][row] = sum_k W[row][k] mu[n][k] as a batched GEMV (weight-bandwidth bound)
-                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, m.mu_img), "fc_mu");
+                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, m.mu_img, 0, bs), "fc_mu");
                 timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N), [&] {
                     check(linear(m.mu_img, a.lut_rows, nullptr, nullptr, nullptr, m.lut, N, STYLE, 18 * a.C, STYLE, 18 * a.C,
                                  ACT_NONE, st), "lut gemv");
                 });
+            } else if (m.use_sh16) {
+                // f16x3 LUT GEMM: 1x1 conv over the [npad/32 x 32] "image" of (sample, label) columns, C4 output
+                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs), "fc_mu");
+                ConvParams p{};
+                p.in = m.mu_img;
+                p.wpk = a.lut_wpk;
+                p.out = m.lut;
+                p.B = 1;
+                p.Cin = STYLE;
+                p.H = npad / 32;
+                p.W = 32;
+                p.Mrows = 18 * a.C;
+                p.pad = -1;
+                p.act = ACT_NONE;
+                timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
+                      [&] { check(conv_sh16_plain(p, 1, st), "lut gemm"); });
+                lut_rs = npad;
+                lut_ns = 4;
             } else {
             check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st), "fc_mu");
             ConvParams p{};
@@ -429,6 +452,9 @@ struct Runner {
         p.noise_bstride = (long long)nf;
         p.lab = lab;
         p.lut = a.styled ? m.lut : nullptr;
+        p.lut_rs = lut_rs;
+        p.lut_ns = lut_ns;
+        p.lut_bs = lut_bs;
         p.act = act;
         p.pad = -1;
         p.zeros = m.sh16_mode == 2 ? m.zero_page : nullptr;
