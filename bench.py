@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ngf', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--path', choices=('f32', 'f16x3', 'f16x3v2', 'f16x3gen'), default='f16x3',
+    ap.add_argument('--path', choices=('f32', 'f16x3'), default='f16x3',
                     help='conv arithmetic: f16x3 = 3-term split-operand f16 MFMA, f32 accumulate, f32-class accuracy '
                          '(default; max |delta| vs the exact path 1.5e-5); f32 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32)')
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
@@ -86,7 +86,7 @@ def main():
     from ctrlhair_amd.sean.generator import SeanGenerator
     B, S, ngf = args.batch, args.size, args.ngf
     sd = P.sean_state_dict(0, ngf)
-    gen = SeanGenerator(local_rank, f16x3={'f32': 0, 'f16x3': 1, 'f16x3v2': 2, 'f16x3gen': 3}[args.path]).load_state_dict(sd, max_batch=B, max_size=S)
+    gen = SeanGenerator(local_rank, f16x3=args.path == 'f16x3').load_state_dict(sd, max_batch=B, max_size=S)
     if args.dbg:
         gen.handle.set_option('sean.dbg', args.dbg)
     first = rank * B     # global sample index offset (SURVEY.md 8d Config 4)
@@ -134,7 +134,7 @@ def main():
         if args.path.startswith('f16x3'):
             # every f32 product is executed as 3 f16 MFMA products: utilisation is priced on executed MFMA FLOPs
             executed, peak = 3.0 * alg, PEAK_F16_MFMA_TFLOPS
-            kname = 'conv_sh16_kernel<KS=3,...,EPI_ACE> (SPADE gamma/beta conv, f16x3 split operands, fused ACE epilogue)'
+            kname = 'conv_sh16_ws_kernel / conv_sh16_kernel <KS=3,...,EPI_ACE> (SPADE gamma/beta conv, f16x3 split operands, fused ACE epilogue)'
             dtype = 'f32 storage + f32 accumulate; conv products as 3-term f16 split on MFMA (f32-class: |delta| <= 1.5e-5 vs exact f32)'
         else:
             executed, peak = alg, PEAK_F32_MFMA_TFLOPS

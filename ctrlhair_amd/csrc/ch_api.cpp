@@ -212,7 +212,6 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
     if (std::strcmp(key, "sean.f16x3") == 0) {
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.f16x3) must precede ch_finalize");
         h->sean.use_sh16 = value != 0;
-        h->sean.sh16_mode = value;
         return CH_OK;
     }
     if (std::strcmp(key, "sean.dbg") == 0) {

@@ -72,11 +72,8 @@ struct ConvParams {
     int cps;                // chunks per split
     float* partial;         // [splitk][B][Mrows][H*W] scratch (then splitk_reduce_kernel applies bias/res/act)
     long long partial_cap;  // floats available in `partial` (0 = split-K disabled)
-    const float* gen_table; // GEN kernels: mlp_shared as label table [19*9][Cin] (+ gen_bias [Cin]); input generated in-kernel
-    const float* gen_bias;
-    int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over v3)
+    int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over the persistent kernel)
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
-    const void* zeros;      // >= 16 zero bytes in device memory (source of out-of-image units for the LDS-DMA path)
     // EPI_NHWC
     int npix_valid;         // number of valid linear pixels (y*W+x < npix_valid)
 };

@@ -380,224 +380,18 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// GEN: the SPADE gamma/beta conv *generates its own input*.  Its input actv = relu(mlp_shared(one-hot labels))
-// (normalization.py:239-242,253) is a pure function of the 3x3 label neighbourhood -- a 9-tap gather from a
-// [19 labels x 9 taps][128] table -- so instead of materialising actv in HBM (134 MB per image per ACE at 512^2, written
-// once and re-read by every M-tile block) each block rebuilds the 16-channel slice of its patch in LDS from the uint8
-// label patch and an 11 KB table slice, splits it to f16 hi/lo in registers and writes the SH16 units straight into the
-// MFMA staging buffer.  No HBM staging loads remain on this kernel's critical path (label patch: <1 KB per block).
-template <int TW, int TH, int TB>
-struct ShGenCfg : ShCfg<3, TW, TH, TB> {
-    using Base = ShCfg<3, TW, TH, TB>;
-    static constexpr int LW = Base::PW + 2, LH = Base::PH + 2;            // label patch (halo 2)
-    static constexpr int SLICE = 19 * 9 * 16;                              // floats per table slice (16 channels)
-    static constexpr int OFF_SLICE = Base::UNITS * 16;                     // byte offsets in LDS
-    static constexpr int OFF_BIAS = OFF_SLICE + 2 * SLICE * 4;
-    static constexpr int OFF_LAB = OFF_BIAS + 2 * 16 * 4;
-    static constexpr int LDS_GEN = ((OFF_LAB + TB * LH * LW + 15) / 16) * 16;
-};
-
-template <int TW, int TH, int TB>
-__global__ __launch_bounds__(256, 2) void conv_sh16_gen_kernel(const ConvParams p) {
-    using Cfg = ShGenCfg<TW, TH, TB>;
-    constexpr int KS = 3, PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS;
-    constexpr int NT = 9, LW = Cfg::LW, LH = Cfg::LH, SLICE = Cfg::SLICE;
-    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
-    float* s_slice = reinterpret_cast<float*>(reinterpret_cast<char*>(smem_u) + Cfg::OFF_SLICE);
-    float* s_bias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem_u) + Cfg::OFF_BIAS);
-    uint8_t* s_lab = reinterpret_cast<uint8_t*>(smem_u) + Cfg::OFF_LAB;
-
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int mtile64 = L % p.mtiles;
-    int nt = L / p.mtiles;
-    const int txi = nt % p.tiles_x; nt /= p.tiles_x;
-    const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
-    const int x0 = txi * TW, y0 = tyi * TH, b0 = nt * TB;
-    const int HW = p.H * p.W;
-
-    int ub[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int idx = wn * 128 + n * 32 + (lane & 31);
-        const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-        ub[n] = (lane >> 5) * 2 * PLANE + tb * (PH * PW) + ty * PW + tx;
-    }
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    // label patch (255 = outside the image) + table slice / bias of chunk 0
-    for (int e = tid; e < TB * LH * LW; e += 256) {
-        const int tb = e / (LH * LW), ly = (e / LW) % LH, lx = e % LW;
-        const int y = y0 - 2 + ly, x = x0 - 2 + lx, b = b0 + tb;
-        const bool in = b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        const uint8_t v = p.lab[in ? (long long)b * HW + y * p.W + x : 0];
-        s_lab[e] = in ? v : (uint8_t)255;
-    }
-    // table in global: [19*9][Cin] floats; slice of chunk c: columns [16c, 16c+16)
-    constexpr int SL4 = SLICE / 4;                              // float4 per slice (684)
-    constexpr int NSL = (SL4 + 255) / 256;                      // float4 loads per thread (3)
-    auto slice_load = [&](int chunk, float4 (&r)[NSL]) {
-#pragma unroll
-        for (int i = 0; i < NSL; ++i) {
-            const int e = tid + i * 256, ee = e < SL4 ? e : 0;
-            r[i] = *reinterpret_cast<const float4*>(p.gen_table + (long long)(ee >> 2) * p.Cin + chunk * 16 + (ee & 3) * 4);
-        }
-    };
-    auto slice_store = [&](int buf, const float4 (&r)[NSL]) {
-#pragma unroll
-        for (int i = 0; i < NSL; ++i) {
-            const int e = tid + i * 256;
-            if (e < SL4) reinterpret_cast<float4*>(s_slice + buf * SLICE)[e] = r[i];
-        }
-    };
-    {
-        float4 r0[NSL];
-        slice_load(0, r0);
-        slice_store(0, r0);
-        if (tid < 16) s_bias[tid] = p.gen_bias[tid];
-    }
-    __syncthreads();
-
-    // build the SH16 patch of `chunk` (16 channels = 2 groups) from labels + table slice `buf`
-    constexpr int NITEM = (2 * PLANE + 255) / 256;
-    auto generate = [&](int buf) {
-        const float* sl = s_slice + buf * SLICE;
-        const float* bs = s_bias + buf * 16;
-#pragma unroll 1
-        for (int i = 0; i < NITEM; ++i) {
-            const int it = tid + i * 256;
-            if (it < 2 * PLANE) {
-                const int g = it / PLANE, q = it % PLANE;
-                const int tb = q / (PH * PW), py = (q / PW) % PH, px = q % PW;
-                const uint8_t* lp = s_lab + tb * (LH * LW) + py * LW + px;
-                float v[8];
-                const bool inside = lp[LW + 1] != 255;          // the patch pixel itself lies in the image
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = bs[g * 8 + c];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int j = lp[(t / 3) * LW + (t % 3)];
-                    if (j != 255) {
-                        const float4* tp = reinterpret_cast<const float4*>(sl + (j * 9 + t) * 16 + g * 8);
-                        const float4 a = tp[0], b = tp[1];
-                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-                        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-                    }
-                }
-                half8 vh, vl;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float o = inside ? fmaxf(v[c], 0.f) : 0.f;       // ReLU; zero padding outside the image
-                    const _Float16 h = (_Float16)o;
-                    vh[c] = h;
-                    vl[c] = (_Float16)(o - (float)h);
-                }
-                smem_u[(g * 2 + 0) * PLANE + q] = __builtin_bit_cast(uint4, vh);
-                smem_u[(g * 2 + 1) * PLANE + q] = __builtin_bit_cast(uint4, vl);
-            }
-        }
-    };
-
-    const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
-
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        float4 rn[NSL];
-        float bn = 0.f;
-        const bool more = ch + 1 < p.nchunks;
-        if (more) {
-            slice_load(ch + 1, rn);
-            bn = p.gen_bias[(ch + 1) * 16 + (tid & 15)];
-        }
-        if (!(p.dbg & 1) || ch == 0) generate(ch & 1);
-        __syncthreads();
-        if (!(p.dbg & 2)) {
-            const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
-            uint4 a_cur[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a_cur[q] = Ac[q * 64];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                uint4 a_nxt[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a_nxt[q] = a_cur[q];
-                if (t + 1 < NT) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a_nxt[q] = Ac[((t + 1) * 4 + q) * 64];
-                }
-                const int koff = (t / KS) * PW + (t % KS);
-                asm volatile("" ::: "memory");
-                uint4 bh[4], bl[4];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    bh[n] = smem_u[ub[n] + koff];
-                    bl[n] = smem_u[ub[n] + koff + PLANE];
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
-                    const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const half8 xh = __builtin_bit_cast(half8, bh[n]);
-                        const half8 xl = __builtin_bit_cast(half8, bl[n]);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m][n], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
-            }
-        }
-        if (more) {
-            slice_store((ch + 1) & 1, rn);
-            if (tid < 16) s_bias[((ch + 1) & 1) * 16 + tid] = bn;
-        }
-        __syncthreads();
-    }
-    if (p.dbg & 4) return;
-    sh16_epilogue<TW, TH, TB, EPI_ACE>(p, acc, mtile64, wn, lane, x0, y0, b0);
-}
-
-template <int TW, int TH, int TB>
-hipError_t launch_sh16_gen(ConvParams p, int rows, hipStream_t stream) {
-    using Cfg = ShGenCfg<TW, TH, TB>;
-    auto kern = conv_sh16_gen_kernel<TW, TH, TB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_GEN);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    p.nchunks = (p.Cin + 15) / 16;
-    p.mtiles = (rows + 63) / 64;
-    p.tiles_x = (p.W + TW - 1) / TW;
-    p.tiles_y = (p.H + TH - 1) / TH;
-    p.tiles_b = (p.B + TB - 1) / TB;
-    const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_GEN, stream, p);
-    return hipGetLastError();
-}
-
+// Wave-specialised persistent variant (large layers).  One 512-thread block per CU: waves 0-3 are CONSUMERS (LDS
+// fragment reads + MFMA + epilogue), waves 4-7 are LOADERS: input patches HBM/L2 -> VGPR -> LDS three chunks ahead (two
+// register sets), A fragments L2 -> LDS by DMA (global_load_lds), both into a 2-stage ring.  A wave's vector-memory
+// results return in order, so a wave that mixes multi-microsecond patch loads with its A-fragment loads stalls its MFMA
+// stream on every chunk; here the consumers issue no vector-memory load at all inside the main loop.  Blocks are
+// persistent (grid = #CUs) and walk the tile list with a static stride, so the loaders already stage the next tile's
+// first chunks while the consumers run the epilogue (no exposed prologue).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-// -----------------------------------------------------------------------------------------------------------------
-// v3: wave-specialised persistent kernel.  One 512-thread block per CU: waves 0-3 are CONSUMERS (fragment reads + MFMA
-// + epilogue), waves 4-7 are LOADERS (HBM/L2 -> VGPR -> LDS staging of the input patches, one chunk ahead in
-// registers, two LDS stages).  A wave's vector-memory results return in order, so a wave that mixes multi-microsecond
-// patch loads with its L1-resident A-fragment loads stalls its MFMA stream on every chunk; here the long-latency loads
-// live in other waves.  Blocks are persistent (grid = #CUs) and walk the tile list with a static stride, so the loaders
-// already fetch the next tile's first chunks while the consumers run the epilogue (no exposed prologue).
 template <int KS, int TW, int TH, int TB, int EPI>
-__global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, HALO = Cfg::HALO;
     constexpr int NT = KS * KS;
@@ -909,9 +703,9 @@ __global__ __launch_bounds__(512, 2) void conv_sh16v3_kernel(const ConvParams p)
 }
 
 template <int KS, int TW, int TH, int TB, int EPI>
-hipError_t launch_sh16v3(ConvParams p, int rows, hipStream_t stream) {
+hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
-    auto kern = conv_sh16v3_kernel<KS, TW, TH, TB, EPI>;
+    auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
     constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
@@ -937,150 +731,6 @@ hipError_t launch_sh16v3(ConvParams p, int rows, hipStream_t stream) {
     const int grid = ntiles < ncu ? ntiles : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), V3_LDS, stream, p);
     return hipGetLastError();
-}
-
-// -----------------------------------------------------------------------------------------------------------------
-// v2: same arithmetic and layouts, different data movement.  ONE block per CU (4 waves, one per SIMD, up to 512 VGPRs):
-// both operands of a 16-channel chunk -- the input patch AND the block's A fragments -- are moved HBM/L2 -> LDS by the
-// LDS-DMA path (global_load_lds, 16 B per lane, no VGPR round trip) one whole chunk ahead into a 2-stage ring, so the
-// only instructions between MFMAs are ds_read_b128 of fragments and the DMA issues; HBM latency is covered by a full
-// chunk of MFMA work (9 k-steps x 24 MFMAs per wave) instead of by a second resident block.
-// Out-of-image patch units are fetched from a 16-byte zero page (the DMA has no per-lane predicate for "write zero").
-template <int KS, int TW, int TH, int TB>
-struct ShCfg2 : ShCfg<KS, TW, TH, TB> {
-    static constexpr int AUNITS = KS * KS * 4 * 64;                       // A fragments of one chunk (16-byte units)
-    static constexpr int STAGE = ShCfg<KS, TW, TH, TB>::UNITS + AUNITS;   // units per ring stage
-    static constexpr int LDS_BYTES2 = 2 * STAGE * 16;
-    static_assert(LDS_BYTES2 <= 160 * 1024, "ring does not fit the 160 KiB LDS");
-};
-
-
-template <int KS, int TW, int TH, int TB, int EPI>
-__global__ __launch_bounds__(256, 1) void conv_sh16v2_kernel(const ConvParams p) {
-    using Cfg = ShCfg2<KS, TW, TH, TB>;
-    constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, HALO = Cfg::HALO;
-    constexpr int NT = KS * KS, AUNITS = Cfg::AUNITS, STAGE = Cfg::STAGE;
-    constexpr int NPATCH = (UNITS + 63) / 64, NA = AUNITS / 64;          // wave-instructions per chunk
-    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int mtile64 = L % p.mtiles;
-    int nt = L / p.mtiles;
-    const int txi = nt % p.tiles_x; nt /= p.tiles_x;
-    const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
-    const int x0 = txi * TW, y0 = tyi * TH, b0 = nt * TB;
-    const int HW = p.H * p.W;
-    const int G = p.Cin >> 3;
-
-    int ub[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int idx = wn * 128 + n * 32 + (lane & 31);
-        const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-        ub[n] = (lane >> 5) * 2 * PLANE + tb * (PH * PW) + ty * PW + tx;
-    }
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    const uint4* gin = reinterpret_cast<const uint4*>(p.in);
-    const uint4* gA = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * AUNITS;
-    const uint4* gzero = reinterpret_cast<const uint4*>(p.zeros);
-
-    // DMA instruction k (0 .. NDMA-1) of this wave for `chunk` into ring stage `st`: wave w owns patch instructions
-    // w, w+4, ... and A instructions w, w+4, ....  Source offsets are chunk-invariant and precomputed (doff).
-    constexpr int NPW = (NPATCH + 3) / 4, NAW = (NA + 3) / 4, NDMA = NPW + NAW;
-    int doff[NPW];      // -1: outside the image (zero page), -2: no instruction / lane inactive
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) {
-        const int ins = wn + k * 4, u = ins * 64 + lane;
-        doff[k] = -2;
-        if (ins < NPATCH && u < UNITS) {
-            const int gh = u / PLANE, rem = u % PLANE;
-            const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
-            const int y = y0 + py - HALO, x = x0 + px - HALO, b = b0 + tb;
-            doff[k] = -1;
-            if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                doff[k] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
-        }
-    }
-    auto dma_one = [&](int chunk, int st, int k) {
-        uint4* base = smem_u + st * STAGE;
-        if (k < NPW) {
-            const int ins = wn + k * 4;
-            if (doff[k] != -2) {
-                const uint4* src = doff[k] >= 0 ? gin + (long long)chunk * 4 * HW + doff[k] : gzero;
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + ins * 64), 16, 0, 0);
-            }
-        } else {
-            const int ins = wn + (k - NPW) * 4;
-            if (ins < NA)
-                __builtin_amdgcn_global_load_lds((glb_void*)(gA + (long long)chunk * AUNITS + ins * 64 + lane),
-                                                 (lds_void*)(base + UNITS + ins * 64), 16, 0, 0);
-        }
-    };
-
-#pragma unroll
-    for (int k = 0; k < NDMA; ++k) dma_one(0, 0, k);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        if (ch + 1 < p.nchunks && !(p.dbg & 1)) {
-#pragma unroll
-            for (int k = 0; k < NDMA; ++k) dma_one(ch + 1, (ch + 1) & 1, k);
-        }
-        if (p.dbg & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); continue; }
-        const uint4* sb = smem_u + (ch & 1) * STAGE;
-        const uint4* sa = sb + UNITS + lane;
-        uint4 a_cur[4], bh[4], bl[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a_cur[q] = sa[q * 64];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            bh[n] = sb[ub[n]];
-            bl[n] = sb[ub[n] + PLANE];
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            // Hand-ordered software pipeline, pinned with sched_barrier: group i = {1 fragment read of k-step t+1,
-            // 2 MFMAs of k-step t}; consecutive MFMAs hit different accumulators (term-major order).
-            uint4 a_nxt[4], bhn[4], bln[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { a_nxt[q] = a_cur[q]; bhn[q] = bh[q]; bln[q] = bl[q]; }
-            const int koff = ((t + 1) / KS) * PW + ((t + 1) % KS);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                if (t + 1 < NT) {
-                    if (i < 4) a_nxt[i] = sa[((t + 1) * 4 + i) * 64];
-                    else if ((i & 1) == 0) bhn[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff];
-                    else bln[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff + PLANE];
-                }
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int j = 2 * i + jj, term = j >> 3, m = (j & 7) >> 2, n = j & 3;
-                    const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
-                    const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
-                    const half8 xh = __builtin_bit_cast(half8, bh[n]);
-                    const half8 xl = __builtin_bit_cast(half8, bl[n]);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al : ah, term == 1 ? xl : xh, acc[m][n], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { a_cur[q] = a_nxt[q]; bh[q] = bhn[q]; bl[q] = bln[q]; }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
 }
 
 // split-K reduce for the C4 layout: out = act(sum_s partial[s] + bias (+ res)), fixed summation order (reproducible)
@@ -1154,27 +804,6 @@ hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
         const int rg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(sh16_splitk_reduce_kernel<0>, dim3(rg), dim3(256), 0, stream, p);
     }
-    return hipGetLastError();
-}
-
-template <int KS, int TW, int TH, int TB, int EPI>
-hipError_t launch_sh16v2(ConvParams p, int rows, hipStream_t stream) {
-    using Cfg = ShCfg2<KS, TW, TH, TB>;
-    auto kern = conv_sh16v2_kernel<KS, TW, TH, TB, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_BYTES2);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    p.nchunks = (p.Cin + 15) / 16;
-    p.mtiles = (rows + 63) / 64;
-    p.tiles_x = (p.W + TW - 1) / TW;
-    p.tiles_y = (p.H + TH - 1) / TH;
-    p.tiles_b = (p.B + TB - 1) / TB;
-    const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES2, stream, p);
     return hipGetLastError();
 }
 

@@ -253,8 +253,6 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
 
     splitk_cap = (long long)16 << 20;     // 64 MiB of split-K slabs (low-resolution layers only)
     splitk_ws = B.falloc((size_t)splitk_cap);
-    zero_page = static_cast<float*>(B.dalloc(256));
-    if (zero_page) (void)hipMemset(zero_page, 0, 256);
 
     // ---- workspace arena --------------------------------------------------------------------------------
     const size_t MB = mb, S = ms;
@@ -425,9 +423,7 @@ struct Runner {
                   [&] { check(conv_nhwc1x1(p, st), "lut gemm"); });
             }
         }
-        const bool gen = m.sh16_mode == 3;       // SPADE conv generates actv in-kernel: nothing to materialise
-        if (gen) {
-        } else if (m.use_sh16)
+        if (m.use_sh16)
             check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
         else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
@@ -457,12 +453,7 @@ struct Runner {
         p.lut_bs = lut_bs;
         p.act = act;
         p.pad = -1;
-        p.zeros = m.sh16_mode == 2 ? m.zero_page : nullptr;
         p.dbg = m.dbg;
-        if (gen) {
-            p.gen_table = a.actv_table;
-            p.gen_bias = a.actv_bias;
-        }
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
               4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
@@ -483,7 +474,6 @@ struct Runner {
         p.res_up = res_up;
         p.act = ACT_NONE;
         p.pad = -1;
-        p.zeros = m.sh16_mode == 2 ? m.zero_page : nullptr;
         p.dbg = m.dbg;
         p.partial = m.splitk_ws;
         p.partial_cap = m.splitk_cap;

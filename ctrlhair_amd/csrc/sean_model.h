@@ -47,8 +47,6 @@ struct ProfRec {
 
 struct SeanModel {
     int ngf = 0, max_batch = 0, max_size = 0;
-    int sh16_mode = 0;         // 0 exact f32 | 1 f16x3 (register-staged, 2 blocks/CU) | 2 f16x3 v2 (LDS-DMA ring, 1 block/CU)
-    float* zero_page = nullptr;
     float* splitk_ws = nullptr;
     long long splitk_cap = 0;
     int dbg = 0;               // perf experiments (conv_mfma.h ConvParams::dbg)

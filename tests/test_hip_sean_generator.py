@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-PATHS = ['f32', 'f16x3', 'f16x3v2', 'f16x3gen', 'f16x3v3']     # exact-f32 MFMA kernel | 3-term split-operand f16 MFMA kernel (conv_sh16.h)
+# exact-f32 MFMA kernel | 3-term split-operand f16 MFMA kernels (conv_sh16.h), default dispatch | the same with every
+# eligible layer forced onto the wave-specialised persistent kernel | ... onto the 2-blocks-per-CU kernel
+PATHS = ['f32', 'f16x3', 'f16x3ws', 'f16x3nows']
 
 
 def _gen(sd, max_batch, max_size, f16x3=False):
@@ -38,9 +40,9 @@ def gen_for(ngf, wseed=0, path='f32'):
         from ctrlhair_amd import procedural as P
         if (ngf, wseed) not in _sds:
             _sds[(ngf, wseed)] = P.sean_state_dict(wseed, ngf)
-        _gens[key] = _gen(_sds[(ngf, wseed)], 4 if ngf == 64 else 8, 512 if ngf == 64 else 128, f16x3={'f32': 0, 'f16x3': 1, 'f16x3v2': 2, 'f16x3gen': 3, 'f16x3v3': 1}[path])
-        if path == 'f16x3v3':
-            _gens[key].handle.set_option('sean.dbg', 64)     # wave-specialised persistent conv kernel
+        _gens[key] = _gen(_sds[(ngf, wseed)], 4 if ngf == 64 else 8, 512 if ngf == 64 else 128, f16x3=path != 'f32')
+        if path in ('f16x3ws', 'f16x3nows'):
+            _gens[key].handle.set_option('sean.dbg', 64 if path == 'f16x3ws' else 128)
     return _gens[key]
 
 
