@@ -128,8 +128,10 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
             vl[e] = (_Float16)(v - (float)h);
         }
         const long long unit = (((long long)b * G + g) * 2) * HW + (pix % HW);
-        out[unit] = __builtin_bit_cast(uint4, vh);
-        out[unit + HW] = __builtin_bit_cast(uint4, vl);
+        // streaming stores: the planes are consumed by the next kernel from HBM/L2, never re-read here
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, vh), reinterpret_cast<u32x4*>(out + unit));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, vl), reinterpret_cast<u32x4*>(out + unit + HW));
     }
 }
 
@@ -308,9 +310,90 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
     }
 }
 
+// Same op for the C4 activation layout [B][Cin/4][H][W][4] (f16x3 path): one float4 = 4 channels of a pixel, so the
+// staging loads are 16 B per lane and every LDS read feeds 12 FMAs.  Channel groups are double-buffered in LDS with the
+// next group's loads in flight during the current group's FMAs; weights sit in LDS as [group][tap][co] float4 and are
+// read with wave-uniform (broadcast) addresses.  HBM-read bound: x is read once (+ halo).
+constexpr int CI4_MAXG = 16;
+__global__ __launch_bounds__(256) void conv_img_c4_kernel(const float4* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                          int Cin, int H, int W) {
+    constexpr int PW = CI_TW + 2, PH = CI_TH + 2, NP = PW * PH;
+    __shared__ float4 patch[2][NP];
+    __shared__ float4 ws4[CI4_MAXG * 9 * 3];
+    const int G = Cin >> 2;
+    const int tx = threadIdx.x % CI_TW, ty = threadIdx.x / CI_TW;
+    const int x0 = blockIdx.x * CI_TW, y0 = blockIdx.y * CI_TH, b = blockIdx.z;
+    const long long HW = (long long)H * W;
+    for (int e = threadIdx.x; e < G * 9 * 3; e += 256) {
+        const int g = e / 27, t = (e / 3) % 9, co = e % 3;
+        const float* wp = w + ((long long)co * Cin + g * 4) * 9 + t;
+        ws4[e] = make_float4(wp[0], wp[9], wp[18], wp[27]);
+    }
+    int off[2];                       // this thread's (up to) two patch elements: pixel offset or -1 (outside / none)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int py = e / PW, px = e % PW, yy = y0 + py - 1, xx = x0 + px - 1;
+        off[i] = (e < NP && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? yy * W + xx : -1;
+    }
+    const float4* xb = x + (long long)b * G * HW;
+    float4 r[2];
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 v = xb[(long long)g * HW + (off[i] >= 0 ? off[i] : 0)];
+            r[i] = off[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = threadIdx.x + i * 256;
+            if (e < NP) {
+                float4 v = r[i];
+                v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y);
+                v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w);
+                patch[st][e] = v;
+            }
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) fetch(g + 1);
+        const float4* pp = patch[g & 1] + ty * PW + tx;
+        const float4* wg = ws4 + g * 27;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 v = pp[(t / 3) * PW + t % 3];
+            const float4 w0 = wg[t * 3 + 0], w1 = wg[t * 3 + 1], w2 = wg[t * 3 + 2];
+            a0 += w0.x * v.x + w0.y * v.y + w0.z * v.z + w0.w * v.w;
+            a1 += w1.x * v.x + w1.y * v.y + w1.z * v.z + w1.w * v.w;
+            a2 += w2.x * v.x + w2.y * v.y + w2.z * v.z + w2.w * v.w;
+        }
+        if (g + 1 < G) stash((g + 1) & 1);
+        __syncthreads();
+    }
+    const int xx = x0 + tx, yy = y0 + ty;
+    if (xx < W && yy < H) {
+        float* o = out + (long long)b * 3 * HW + (long long)yy * W + xx;
+        o[0] = tanhf(a0 + bias[0]);
+        o[HW] = tanhf(a1 + bias[1]);
+        o[2 * HW] = tanhf(a2 + bias[2]);
+    }
+}
+
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                          hipStream_t s, int c4) {
     dim3 grid((W + CI_TW - 1) / CI_TW, (H + CI_TH - 1) / CI_TH, B);
+    if (c4 && Cin % 4 == 0 && Cin <= 4 * CI4_MAXG) {
+        hipLaunchKernelGGL(conv_img_c4_kernel, grid, dim3(256), 0, s, reinterpret_cast<const float4*>(x), w, bias, out, B,
+                           Cin, H, W);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(conv_img_kernel, grid, dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, c4);
     return hipGetLastError();
 }
