@@ -60,9 +60,10 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ngf', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--path', choices=('f32', 'f16x3'), default='f16x3',
+    ap.add_argument('--path', choices=('f32', 'f16x3', 'f16'), default='f16x3',
                     help='conv arithmetic: f16x3 = 3-term split-operand f16 MFMA, f32 accumulate, f32-class accuracy '
-                         '(default; max |delta| vs the exact path 1.5e-5); f32 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32)')
+                         '(default; max |delta| vs the exact path 1.5e-5); f32 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32); '
+                         'f16 = single-term f16 operands (reduced precision, BASELINE configs[4]; informational)')
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -86,7 +87,7 @@ def main():
     from ctrlhair_amd.sean.generator import SeanGenerator
     B, S, ngf = args.batch, args.size, args.ngf
     sd = P.sean_state_dict(0, ngf)
-    gen = SeanGenerator(local_rank, f16x3=args.path == 'f16x3').load_state_dict(sd, max_batch=B, max_size=S)
+    gen = SeanGenerator(local_rank, f16x3={'f32': 0, 'f16x3': 1, 'f16': 2}[args.path]).load_state_dict(sd, max_batch=B, max_size=S)
     if args.dbg:
         gen.handle.set_option('sean.dbg', args.dbg)
     first = rank * B     # global sample index offset (SURVEY.md 8d Config 4)
@@ -131,7 +132,12 @@ def main():
         value = world * B * args.steps / dt
         # algorithmic (f32-equivalent) conv FLOP/s of the dominant kernel, hipEvent-timed per launch inside the library
         alg = prof_ace['flops'] / (prof_ace['ms'] * 1e-3) / 1e12 if prof_ace['ms'] > 0 else 0.0
-        if args.path.startswith('f16x3'):
+        if args.path == 'f16':
+            # reduced-precision configuration (BASELINE.json configs[4] class; NOT the headline): one f16 MFMA product per term
+            executed, peak = alg, PEAK_F16_MFMA_TFLOPS
+            kname = 'conv_sh16_ws_kernel / conv_sh16_kernel <KS=3,...,EPI_ACE,TERMS=1> (SPADE gamma/beta conv, f16 operands, fused ACE epilogue)'
+            dtype = 'f16 operands on MFMA, f32 accumulate, f32 normalisation/modulation (reduced precision: tolerance 5e-2)'
+        elif args.path.startswith('f16x3'):
             # every f32 product is executed as 3 f16 MFMA products: utilisation is priced on executed MFMA FLOPs
             executed, peak = 3.0 * alg, PEAK_F16_MFMA_TFLOPS
             kname = 'conv_sh16_ws_kernel / conv_sh16_kernel <KS=3,...,EPI_ACE> (SPADE gamma/beta conv, f16x3 split operands, fused ACE epilogue)'

@@ -252,7 +252,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 // in : SH16 [B][Cin/8][2][H][W][8]   (Cin % 16 == 0; padding channels hold zeros)
 // EPI_PLAIN -> out f32 NCHW [B][Mrows][H][W] (bias / residual / act as conv_mfma)
 // EPI_ACE   -> out SH16 [B][ceil(C/8)][2][H][W][8]  (the fused ACE epilogue of conv_mfma.h, re-split for the next conv)
-template <int KS, int TW, int TH, int TB, int EPI>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, NLOAD = Cfg::NLOAD, HALO = Cfg::HALO;
@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             }
             if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                 soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
+            if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
         }
     }
     auto stage = [&](int chunk, int buf) {
@@ -364,8 +365,10 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
                 for (int n = 0; n < 4; ++n) {
                     const half8 xh = __builtin_bit_cast(half8, bh[n]);
                     const half8 xl = __builtin_bit_cast(half8, bl[n]);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m][n], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m][n], 0, 0, 0);
+                    }
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m][n], 0, 0, 0);
                 }
             }
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-template <int KS, int TW, int TH, int TB, int EPI>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
 __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, HALO = Cfg::HALO;
@@ -449,6 +452,8 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     }
                     if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                         soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
+                    if (TERMS == 1 && (gh & 1)) soff[i] = -1;
+            if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
                 }
             }
             cur_tile = k;
@@ -619,6 +624,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * i + jj, term = j >> 3, m = (j & 7) >> 2, n = j & 3;
+                        if (TERMS == 1 && term != 2) continue;
                         const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
                         const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
                         const half8 xh = __builtin_bit_cast(half8, bh[n]);
@@ -702,10 +708,10 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     }
 }
 
-template <int KS, int TW, int TH, int TB, int EPI>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
 hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
-    auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI>;
+    auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
     constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
@@ -768,10 +774,10 @@ __global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
     }
 }
 
-template <int KS, int TW, int TH, int TB, int EPI>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
 hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
-    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI>;
+    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -808,7 +814,37 @@ hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
 }
 
 // implemented in conv_inst_sh16*.hip
-hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s);   // SH16 in -> f32 NCHW out
+// ---- layer -> kernel selection, shared by the 3-term (f32-class) and 1-term (plain f16 operands) instantiation files
+template <int TERMS>
+hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
+    if (p.act > ACT_RELU) return hipErrorInvalidValue;   // the ACE epilogue implements none / leaky / relu only
+    const int rows = ((p.C + 31) / 32) * 64;
+    // dbg bit 64 forces the wave-specialised persistent kernel, bit 128 forbids it; default: layers with at least two
+    // rounds of tiles per CU (its loaders then hide every tile's prologue behind the previous tile's epilogue)
+    const long long ntiles = (long long)(rows / 64) * ((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+    const bool ws_ok = p.W >= 32 && p.Cin >= 48;
+    if (ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512)))
+        return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS>(p, rows, s);
+    if (p.W >= 32) return launch_sh16<3, 32, 16, 1, EPI_ACE, TERMS>(p, rows, s);
+    if (p.W > 8) return launch_sh16<3, 16, 16, 2, EPI_ACE, TERMS>(p, rows, s);
+    return launch_sh16<3, 8, 8, 8, EPI_ACE, TERMS>(p, rows, s);
+}
+
+template <int KS, int TERMS>
+hipError_t dispatch_sh16_plain(const ConvParams& p, hipStream_t s) {
+    // dbg bit 64: wave-specialised persistent kernel (measured slower than the 2-blocks-per-CU kernel for the plain
+    // epilogue, whose residual loads it cannot hide; kept selectable for profiling)
+    if ((p.dbg & 64) && p.W >= 32 && !(p.partial && p.mtiles_hint_small))
+        return launch_sh16_ws<KS, 32, 16, 1, EPI_PLAIN, TERMS>(p, p.Mrows, s);
+    if (p.W >= 32) return launch_sh16<KS, 32, 16, 1, EPI_PLAIN, TERMS>(p, p.Mrows, s);
+    if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN, TERMS>(p, p.Mrows, s);
+    return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, TERMS>(p, p.Mrows, s);
+}
+
+// p.terms == 1 selects the single-term instantiations (operands rounded to f16, f32 accumulate: BASELINE configs[4])
+hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s);   // SH16 in -> f32 C4 out
 hipError_t conv_sh16_ace(const ConvParams& p, hipStream_t s);             // SH16 in -> SH16 out (fused ACE)
+hipError_t conv_h16_plain(const ConvParams& p, int KS, hipStream_t s);    // the TERMS = 1 instantiations
+hipError_t conv_h16_ace(const ConvParams& p, hipStream_t s);
 
 }  // namespace chk

@@ -402,6 +402,7 @@ struct Runner {
                 p.Mrows = 18 * a.C;
                 p.pad = -1;
                 p.act = ACT_NONE;
+                p.terms = m.terms;
                 timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
                       [&] { check(conv_sh16_plain(p, 1, st), "lut gemm"); });
                 lut_rs = npad;
@@ -454,6 +455,7 @@ struct Runner {
         p.act = act;
         p.pad = -1;
         p.dbg = m.dbg;
+        p.terms = m.terms;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
               4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
@@ -475,6 +477,7 @@ struct Runner {
         p.act = ACT_NONE;
         p.pad = -1;
         p.dbg = m.dbg;
+        p.terms = m.terms;
         p.partial = m.splitk_ws;
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;

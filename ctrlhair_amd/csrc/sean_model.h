@@ -50,6 +50,7 @@ struct SeanModel {
     float* splitk_ws = nullptr;
     long long splitk_cap = 0;
     int dbg = 0;               // perf experiments (conv_mfma.h ConvParams::dbg)
+    int terms = 3;             // f16 MFMA path: 3 = split operands (f32-class), 1 = f16 operands (BASELINE configs[4] class)
     bool use_sh16 = false;     // generator convs on the f16x3 split-operand MFMA path (conv_sh16.h)
     std::vector<BlockW> blocks;
     float *fc_table = nullptr, *fc_bias = nullptr;     // fc conv as label LUT [19*9][16ngf]

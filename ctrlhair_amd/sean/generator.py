@@ -14,8 +14,9 @@ from .. import lib as _lib
 
 class SeanGenerator:
     def __init__(self, device: int = 0, f16x3=False):
-        """f16x3: False = exact-f32 MFMA convs (v_mfma_f32_32x32x2_f32); True = 3-term split-operand f16 MFMA convs with
-        f32 accumulation (conv_sh16.h): f32-class results (max |delta| vs the exact path 1.5e-5), ~3x faster."""
+        """f16x3: False/0 = exact-f32 MFMA convs (v_mfma_f32_32x32x2_f32); True/1 = 3-term split-operand f16 MFMA convs with
+        f32 accumulation (conv_sh16.h): f32-class results (max |delta| vs the exact path 1.5e-5), ~3x faster; 2 = single-term
+        f16 operands with f32 accumulation (reduced precision, tolerance 5e-2 -- BASELINE.json configs[4])."""
         self.f16x3 = f16x3
         self.device_index = device
         self.device = torch.device('cuda', device)

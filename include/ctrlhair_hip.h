@@ -53,9 +53,12 @@ const char* ch_last_error(const ch_handle* h);
 int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host, int dtype,
                     const int64_t* shape, int ndim);
 
-/* Options, set before ch_finalize.  "sean.f16x3" (0/1, default 0): run the SEAN generator's MFMA convolutions on the
- * f16 matrix cores with the 3-term split-operand scheme of ctrlhair_amd/csrc/conv_sh16.h (f32-class accuracy, f32
- * accumulation; activations between ACE and conv stored as f16 hi/lo pairs) instead of the exact-f32 MFMA kernel. */
+/* Options, set before ch_finalize.  "sean.f16x3" (default 0) selects the arithmetic of the SEAN generator's MFMA convs:
+ *   0  exact f32 (v_mfma_f32_32x32x2_f32);
+ *   1  f16 matrix cores with the 3-term split-operand scheme of ctrlhair_amd/csrc/conv_sh16.h: f32-class accuracy, f32
+ *      accumulation, activations between ACE and conv stored as f16 hi/lo pairs;
+ *   2  f16 matrix cores, single term: operands rounded to f16, f32 accumulation and f32 normalisation / modulation
+ *      (the reduced-precision configuration of BASELINE.json configs[4]; tolerance 5e-2). */
 int  ch_set_option(ch_handle* h, const char* key, int value);
 
 /* Fold + pack + upload the loaded tensors: spectral-norm sigma (torch spectral_norm eval semantics,

@@ -13,6 +13,7 @@ TOL = 1e-3
 # exact-f32 MFMA kernel | 3-term split-operand f16 MFMA kernels (conv_sh16.h), default dispatch | the same with every
 # eligible layer forced onto the wave-specialised persistent kernel | ... onto the 2-blocks-per-CU kernel
 PATHS = ['f32', 'f16x3', 'f16x3ws', 'f16x3nows']
+PATH_TOL = {'f16': 5e-2}      # single-term f16 operands: the reduced-precision configuration (BASELINE.json configs[4])
 
 
 def _gen(sd, max_batch, max_size, f16x3=False):
@@ -40,7 +41,7 @@ def gen_for(ngf, wseed=0, path='f32'):
         from ctrlhair_amd import procedural as P
         if (ngf, wseed) not in _sds:
             _sds[(ngf, wseed)] = P.sean_state_dict(wseed, ngf)
-        _gens[key] = _gen(_sds[(ngf, wseed)], 4 if ngf == 64 else 8, 512 if ngf == 64 else 128, f16x3=path != 'f32')
+        _gens[key] = _gen(_sds[(ngf, wseed)], 4 if ngf == 64 else 8, 512 if ngf == 64 else 128, f16x3={'f32': 0, 'f16': 2}.get(path, 1))
         if path in ('f16x3ws', 'f16x3nows'):
             _gens[key].handle.set_option('sean.dbg', 64 if path == 'f16x3ws' else 128)
     return _gens[key]
@@ -74,14 +75,16 @@ def test_stagewise_tiny_vs_oracle(hip_lib, path):
     assert np.abs(out - ref).max() <= TOL
 
 
-@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('path', PATHS + ['f16'])
 @pytest.mark.parametrize('name', SEAN_CASES)
 def test_golden(hip_lib, name, path):
     c = Case(name)
     gen = gen_for(c.ngf, c.wseed, path)
     img = _run(gen, c.labels, c.codes, c.noise)
     assert np.isfinite(img).all()
-    assert c.max_abs_diff(img) <= TOL
+    d = c.max_abs_diff(img)
+    print(f'{name} {path}: max |delta| vs reference fixture = {d:.3e}')
+    assert d <= PATH_TOL.get(path, TOL)
 
 
 @pytest.mark.parametrize('path', PATHS)
