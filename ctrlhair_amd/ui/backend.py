@@ -125,6 +125,79 @@ class Backend(HairEditor):
                                                   blending=self.blending, blender=self.blender)
         return output_img
 
+    # ---- batched rendering -------------------------------------------------------------------------
+    def copy_latent(self, latent=None):
+        """Deep copy of a LatentRepresentation (default: the current one); the face code is shared, like interpolate()."""
+        latent = self.cur_latent if latent is None else latent
+        out = LatentRepresentation()
+        for att in ('curliness', 'shape', 'texture'):
+            out.__setattr__(att, latent.__getattribute__(att).clone())
+        out.color = {k: v.clone() for k, v in latent.color.items()}
+        out.face = latent.face
+        return out
+
+    def outputs(self, latents, noise=None):
+        """Batched output(): renders a list of LatentRepresentation with ONE shape-decoder, ONE colour-generator and ONE SEAN
+        generator call (the reference offers only batch-1 output() and loops over it: shape_branch/validation_in_train.py:
+        114-121, color_texture_branch/solver.py:270-299, README "Editing with Batch").  Image i equals what
+        `output(latents[i])` returns for the same noise; cur_latent / cur_mask are left untouched.  Returns (list of uint8
+        RGB images, uint8 label maps [N,256,256])."""
+        latents = list(latents)
+        n = len(latents)
+        if n == 0:
+            return [], np.zeros((0, 256, 256), dtype=np.uint8)
+        shape = torch.cat([l.shape for l in latents], dim=0)
+        face = torch.cat([l.face for l in latents], dim=0)
+        masks = self.mask_generator.decode_labels(shape, face)                       # [N,256,256] uint8 on device
+        rgb = torch.cat([l.color['rgb_mean'] if 'rgb_mean' in l.color else self.tensor_hsv_to_rgb(l.color['hsv'])
+                         for l in latents], dim=0)
+        data = {'noise': torch.cat([l.texture for l in latents], dim=0),
+                'noise_curliness': torch.cat([l.curliness for l in latents], dim=0),
+                'rgb_mean': rgb, 'pca_std': torch.cat([l.color['pca_std'] for l in latents], dim=0)}
+        feature = self.feature_generator(data)['code']                               # [N,512]
+        codes = self.input_sean_code.expand(n, -1, -1).clone()
+        codes[:, HAIR_IDX] = feature
+        masks_np = masks.cpu().numpy()
+        lab = np.stack([self._mask_for_sean(m) for m in masks_np])
+        if noise is None and self.noise is not None:                                 # pinned planes: same draw for every image
+            noise = self.noise.expand(n, -1).contiguous() if self.noise.shape[0] == 1 else self.noise
+        imgs = self.gen_imgs(codes, lab, noise=noise)
+        out = [self.postprocess_blending(self.input_img, imgs[i], self.input_mask, masks_np[i], blending=self.blending,
+                                         blender=self.blender)[0] for i in range(n)]
+        return out, masks_np
+
+    def sweep(self, att_name, idx, values, noise=None):
+        """Slider sweep: the images output() would give after change_<att_name>(v, idx) for each v in `values`, rendered as
+        one batch (att_name in 'curliness' | 'color' | 'shape' | 'texture'; idx ignored for curliness).  The current
+        latent is restored afterwards."""
+        saved, saved_mask = self.cur_latent, self.cur_mask
+        latents = []
+        try:
+            for v in values:
+                self.cur_latent = self.copy_latent(saved)
+                if att_name == 'curliness':
+                    self.change_curliness(v)
+                elif att_name == 'color':
+                    self.change_color(v, idx)
+                elif att_name == 'texture':
+                    self.change_texture(v, idx)
+                elif att_name == 'shape':          # change_shape() would also decode a mask per value; outputs() batches that
+                    self.cur_latent.shape = self.cur_latent.shape + \
+                        (v - torch.dot(self.cur_latent.shape[0], self.shape_dirs[idx])) * self.shape_dirs[idx]
+                else:
+                    raise ValueError(f'unknown attribute {att_name!r}')
+                latents.append(self.cur_latent)
+        finally:
+            self.cur_latent, self.cur_mask = saved, saved_mask
+        return self.outputs(latents, noise=noise)
+
+    def interpolate_grid(self, latent1, latent2, alphas, att_name=None, noise=None):
+        """Images along latent1 -> latent2 for every alpha, one batch: interpolate() (all attributes) or
+        interpolate_each_att(att_name) per alpha (ui/backend.py:323-395)."""
+        lat = [self.interpolate(latent1, latent2, a) if att_name is None else
+               self.interpolate_each_att(latent1, latent2, a, att_name) for a in alphas]
+        return self.outputs(lat, noise=noise)
+
     # ---- sliders (ui/backend.py:177-264) ---------------------------------------------------------------------
     def change_curliness(self, val):
         self.cur_latent.curliness[0] = val

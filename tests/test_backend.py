@@ -125,3 +125,54 @@ def test_batched_gen_imgs_equals_per_sample(hip_lib):
     for b in range(B):
         one = he.gen_img(codes[b:b + 1], labels[b][None, None], noise=noise[b:b + 1])
         assert float((one - batched[b]).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_batched_outputs_sweep_and_grid(hip_lib):
+    """N1: Backend.outputs / sweep / interpolate_grid render whole slider sweeps as one batch and reproduce the batch-1
+    output() of the reference API image by image (same pinned noise); the editing state is left untouched."""
+    torch.manual_seed(0)
+    be = Backend(2.5, blending=False, weights=weights(), device=0, max_batch=4)
+    be.noise = torch.from_numpy(P.noise_planes(1, 256, NGF, seed=77)).cuda()
+    be.set_input_img(portrait(3))
+    be.set_target_img(portrait(4))
+    be.transfer_latent_representation('texture')
+    be.change_color(0.7, 1)
+    base_shape = be.cur_latent.shape.clone()
+    base_mask = be.cur_mask.copy()
+
+    def same(a, b):
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        return d.max() <= 1 and (d > 0).mean() < 1e-3
+
+    # shape sweep (5 values > max_batch 4: exercises chunking) vs the sequential reference calls
+    values = [-1.5, -0.5, 0.0, 0.5, 1.5]
+    imgs, masks = be.sweep('shape', 0, values)
+    assert len(imgs) == 5 and masks.shape == (5, 256, 256)
+    assert torch.equal(be.cur_latent.shape, base_shape) and np.array_equal(be.cur_mask, base_mask)
+    saved = be.copy_latent()
+    for v, img, m in zip(values, imgs, masks):
+        be.cur_latent = be.copy_latent(saved)
+        be.change_shape(v, 0)
+        assert np.array_equal(be.cur_mask, m)
+        assert same(be.output(), img)
+    be.cur_latent = saved
+    be.refresh_cur_mask()
+
+    # colour + curliness sweeps
+    for att, idx, vals in (('color', 2, [-1.0, 1.0]), ('curliness', 0, [0.0, 1.0, 2.0]), ('texture', 1, [-1.0, 1.0])):
+        imgs, _ = be.sweep(att, idx, vals)
+        for v, img in zip(vals, imgs):
+            be.cur_latent = be.copy_latent(saved)
+            {'color': lambda: be.change_color(v, idx), 'curliness': lambda: be.change_curliness(v),
+             'texture': lambda: be.change_texture(v, idx)}[att]()
+            assert same(be.output(), img)
+        be.cur_latent = saved
+
+    # interpolation grid towards the target latent == output(interpolate(..)) per alpha
+    alphas = [0.0, 0.5, 1.0]
+    tl = be.copy_latent(be.target_latent)
+    imgs, _ = be.interpolate_grid(saved, tl, alphas, att_name='color')
+    for a, img in zip(alphas, imgs):
+        assert same(be.output(be.interpolate_each_att(saved, tl, a, 'color')), img)
+    assert len({im.tobytes() for im in imgs}) == 3          # the sweep actually changes the picture
