@@ -47,6 +47,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
                                f'g.build()"` or `make -C ctrlhair_amd/csrc` (no CPU fallback exists)')
+        # PyTorch ships its own libamdhip64; the callers of this module hand us torch device pointers and streams, so both
+        # must live in ONE HIP runtime.  Importing torch first makes the dynamic loader resolve our DT_NEEDED libamdhip64
+        # to the copy torch already mapped (loading /opt/rocm's first leaves torch with "No HIP GPUs are available").
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
