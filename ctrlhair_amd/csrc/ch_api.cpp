@@ -9,6 +9,7 @@
 
 #include "aux_models.h"
 #include "sean_model.h"
+#include "kernels.h"
 
 struct ch_handle {
     int device = 0;
@@ -19,6 +20,8 @@ struct ch_handle {
     chk::ShapeModel shape;
     chk::ColorModel color;
     chk::BiSeNetModel bisenet;
+    void* blend_ws = nullptr;        // Poisson CG workspace, grown on demand
+    size_t blend_ws_bytes = 0;
 };
 
 namespace {
@@ -61,6 +64,7 @@ void ch_destroy(ch_handle* h) {
     h->shape.destroy();
     h->color.destroy();
     h->bisenet.destroy();
+    if (h->blend_ws) (void)hipFree(h->blend_ws);
     delete h;
 }
 
@@ -198,6 +202,34 @@ int ch_bisenet_parse(ch_handle* h, const float* img, uint8_t* labels, float* log
                      ch_stream_t stream) {
     if (h && (!img || !labels || B < 1)) return fail(h, CH_ERR_ARG, "ch_bisenet_parse: bad argument");
     CH_CALL("ch_bisenet_parse", h->bisenet.parse(img, labels, logits, B, H, W, static_cast<hipStream_t>(stream)))
+}
+
+int ch_blend_mask(ch_handle* h, const uint8_t* target_parsing, const uint8_t* face_parsing, uint8_t* out, int H, int W,
+                  ch_stream_t stream) {
+    if (!h) return CH_ERR_ARG;
+    if (!target_parsing || !face_parsing || !out || H < 1 || W < 1) return fail(h, CH_ERR_ARG, "ch_blend_mask: bad argument");
+    (void)hipSetDevice(h->device);
+    hipError_t e = chk::blend_mask(target_parsing, face_parsing, out, H, W, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? CH_OK : fail(h, CH_ERR_HIP, std::string("ch_blend_mask: ") + hipGetErrorString(e));
+}
+
+int ch_poisson_blend(ch_handle* h, const uint8_t* source, const uint8_t* target, const uint8_t* mask, uint8_t* out, int H, int W,
+                     int with_gamma, int max_iters, double rel_tol, int* iters, ch_stream_t stream) {
+    if (!h) return CH_ERR_ARG;
+    if (!source || !target || !mask || !out || H < 3 || W < 3 || max_iters < 0 || !(rel_tol >= 0.0))
+        return fail(h, CH_ERR_ARG, "ch_poisson_blend: bad argument (images need H, W >= 3)");
+    (void)hipSetDevice(h->device);
+    const size_t need = chk::poisson_workspace_bytes(H, W);
+    if (need > h->blend_ws_bytes) {
+        if (h->blend_ws) (void)hipFree(h->blend_ws);
+        h->blend_ws = nullptr;
+        h->blend_ws_bytes = 0;
+        if (hipMalloc(&h->blend_ws, need) != hipSuccess) return fail(h, CH_ERR_HIP, "ch_poisson_blend: workspace allocation failed");
+        h->blend_ws_bytes = need;
+    }
+    hipError_t e = chk::poisson_blend(source, target, mask, out, H, W, with_gamma, max_iters, rel_tol, h->blend_ws, iters,
+                                      static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? CH_OK : fail(h, CH_ERR_HIP, std::string("ch_poisson_blend: ") + hipGetErrorString(e));
 }
 
 int ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr) {

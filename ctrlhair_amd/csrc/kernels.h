@@ -36,4 +36,10 @@ hipError_t linear(const float* x, const float* W, const float* bias, const float
                   int B, int K, int O, int ldx, int ldo, int act, hipStream_t s);
 hipError_t subspace_add(float* h, const float* z, int zld, const float* U, const float* L, const float* mu, int B, int D,
                         int Z, hipStream_t s);
+// poisson_kernels.hip: blending step after the generator (hair_editor.py:285-310, poisson_blending.py:29-87)
+size_t poisson_workspace_bytes(int H, int W);
+hipError_t poisson_blend(const uint8_t* src_hwc, const uint8_t* tgt_hwc, const uint8_t* mask, uint8_t* out_hwc, int H, int W,
+                         int with_gamma, int max_iters, double rel_tol, void* ws, int* iters_out, hipStream_t s);
+hipError_t blend_mask(const uint8_t* target_parsing, const uint8_t* face_parsing, uint8_t* out, int H, int W, hipStream_t s);
+
 }  // namespace chk

@@ -67,6 +67,8 @@ class HipModels:
                                                                           weights['color_rgb'], max_batch=max(max_batch, 16))
         self.mask_generator = ShapeGenerator(h, dev).load_state_dict(weights['shape'], max_batch=max(max_batch, 1))
         self.face_parsing = FaceParsing(h, dev).load_state_dict(weights['bisenet'], max_batch=max(max_batch, 1), max_size=512)
+        from .blending import PoissonBlender
+        self.blender = PoissonBlender(h, dev)       # blending step after the generator (Backend(blending=True))
 
 
 class HairEditor:
@@ -221,15 +223,28 @@ class HairEditor:
         res_img = from_tensor_order_to_cv2(res_img).astype('uint8')
         if not blending:
             return res_img, None
-        # Poisson blending (poisson_blending.py:29-87) is a CPU post-process outside the GPU path; a
-        # caller that wants it injects the reference function (`blender=poisson_blending`) and needs cv2 for the dilations.
-        cv2 = U._cv2()
-        if blender is None or cv2 is None:
-            raise RuntimeError('blending=True needs cv2 and a Poisson blender (poisson_blending.poisson_blending); '
-                               'construct Backend(..., blending=False) or pass blender=')
         target_parsing = from_tensor_order_to_cv2(target_parsing, is_mask=True)
         face_img = from_tensor_order_to_cv2(face_img).astype('uint8')
         face_parsing = from_tensor_order_to_cv2(face_parsing, is_mask=True)
+        if blender is None:
+            blender = getattr(self.models, 'blender', None)
+        from .blending import PoissonBlender
+        if isinstance(blender, PoissonBlender):
+            # HIP path: mask construction (hair_editor.py:297-305) and the Poisson solve
+            # (poisson_blending.py:29-87) both on the library; no cv2, no scipy
+            def at_image_size(m):        # [H,W,1] label map -> [H,W] at the image's size (512 mode: masks live at 256)
+                m = np.asarray(m).reshape(m.shape[0], m.shape[1]).astype('uint8')
+                return m if m.shape == res_img.shape[:2] else U.resize_nearest(m, res_img.shape[:2])
+            res_mask_dilated = blender.blend_mask(at_image_size(target_parsing), at_image_size(face_parsing))
+            if face_img.shape[:2] != res_img.shape[:2]:
+                face_img = U.resize_bilinear(face_img, res_img.shape[:2])
+            out = blender(face_img, res_img, 1 - res_mask_dilated, with_gamma=True)
+            return out, res_mask_dilated.cpu().numpy()[..., None]
+        # injected reference blender (`blender=poisson_blending.poisson_blending`): needs cv2 for the dilations
+        cv2 = U._cv2()
+        if blender is None or cv2 is None:
+            raise RuntimeError('blending=True needs the HIP models (HipModels.blender) or cv2 plus an injected Poisson '
+                               'blender; construct Backend(..., blending=False) or pass blender=')
         res_mask = np.logical_or(target_parsing == HAIR_IDX, face_parsing == HAIR_IDX).astype('uint8')
         k13 = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ksize=(13, 13))
         k5 = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ksize=(5, 5))

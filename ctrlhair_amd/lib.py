@@ -32,6 +32,8 @@ SYMBOLS = {
     'ch_shape_decode': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     'ch_shape_combine': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     'ch_bisenet_parse': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    'ch_blend_mask': (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
+    'ch_poisson_blend': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _D, C.POINTER(_I), _VP]),
     'ch_sean_set_tap': (_I, [_VP, C.c_char_p, _VP]),
     'ch_profile_enable': (_I, [_VP, _I]),
     'ch_profile_read': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),

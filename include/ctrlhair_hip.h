@@ -133,6 +133,23 @@ int  ch_shape_combine(ch_handle* h, const float* hair_logit, const float* face_l
 int  ch_bisenet_parse(ch_handle* h, const float* img, uint8_t* labels, float* logits, int B, int H, int W,
                       ch_stream_t stream);
 
+/* ---- Blending after the generator (the step that follows the hot path when Backend(blending=True)) ------------------
+ * ch_blend_mask replaces hair_editor.py:297-305: hair = (target_parsing == 13) | (face_parsing == 13); out = cv2.dilate of
+ *   hair with the 13x13 MORPH_ELLIPSE element, except on the target's background (label 0) where the 5x5 element is used.
+ *   target_parsing, face_parsing, out: uint8 [H,W] device pointers (CelebAMask-HQ ids in, 0/1 out).
+ * ch_poisson_blend replaces poisson_blending.poisson_blending (poisson_blending.py:29-87): same linear system (5-point
+ *   Laplacian incl. the reference's border rows, identity rows for interior pixels with mask == 0), same gamma-2.2 round
+ *   trip and uint8 truncation, solved matrix-free by conjugate gradients in f64 instead of three sparse direct solves.
+ *   source, target, out: uint8 [H,W,3] (cv2 layout); mask uint8 [H,W], non-zero = keep the SOURCE gradients (solve), zero =
+ *   keep the target pixel; H, W >= 3.  Stops when ||r|| <= rel_tol * ||r0|| per channel or after max_iters iterations
+ *   (recommended 1e-7 / 4000); *iters (host pointer, optional) receives the iteration count.  Output agrees with the
+ *   reference to +-1 grey level (the floor() after the gamma power amplifies last-bit differences of pow() and of the
+ *   solve wherever the result sits on an integer boundary, e.g. every kept target pixel).  Run-to-run deterministic. */
+int  ch_blend_mask(ch_handle* h, const uint8_t* target_parsing, const uint8_t* face_parsing, uint8_t* out, int H, int W,
+                   ch_stream_t stream);
+int  ch_poisson_blend(ch_handle* h, const uint8_t* source, const uint8_t* target, const uint8_t* mask, uint8_t* out, int H,
+                      int W, int with_gamma, int max_iters, double rel_tol, int* iters, ch_stream_t stream);
+
 /* Test hook: after the next ch_sean_generate calls, the activation produced at stage `name` ("fc", "<block>",
  * "<block>.ace_0" = tensor before leaky_relu, "<block>.conv_0", "<block>.shortcut") is also copied
  * (device-to-device, same stream) to `dev_ptr` (caller-sized: [B,C,r,r] floats).  dev_ptr NULL removes the tap. */

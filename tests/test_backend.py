@@ -176,3 +176,28 @@ def test_batched_outputs_sweep_and_grid(hip_lib):
     for a, img in zip(alphas, imgs):
         assert same(be.output(be.interpolate_each_att(saved, tl, a, 'color')), img)
     assert len({im.tobytes() for im in imgs}) == 3          # the sweep actually changes the picture
+
+
+@pytest.mark.gpu
+def test_blending_output_on_hip_matches_cpu_oracle_composition(hip_lib):
+    """N3: Backend(blending=True) runs the mask construction and the Poisson solve on the library; the result equals the
+    reference composition (hair_editor.py:285-310) evaluated by the CPU oracle on the same generated image, to +-1 level."""
+    from oracle import poisson_oracle as PO
+    torch.manual_seed(0)
+    be = Backend(2.5, blending=True, weights=weights(), device=0)
+    be.noise = torch.from_numpy(P.noise_planes(1, 256, NGF, seed=77)).cuda()
+    be.set_input_img(portrait(3))
+    be.set_target_img(portrait(4))
+    be.transfer_latent_representation('texture')
+    be.change_shape(-1.0, 0)
+    blended = be.output()
+    be.blending = False
+    plain = be.output()
+    assert blended.shape == plain.shape == (256, 256, 3) and blended.dtype == np.uint8
+    face = np.asarray(be.input_img).astype('uint8')               # set_input_img keeps the resized uint8 portrait (:127-135)
+    m = PO.blend_mask(be.cur_mask, np.asarray(be.input_mask).reshape(256, 256))
+    ref = PO.poisson_blending(face, plain, 1 - m, with_gamma=True)
+    d = np.abs(blended.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1, d.max()
+    if m.any() and not m.all():
+        assert not np.array_equal(blended, plain)

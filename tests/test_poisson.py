@@ -1,0 +1,147 @@
+"""Blending after the generator: oracle vs the reference's golden outputs on CPU; HIP (through the C ABI)
+vs oracle / golden on the GPU.  Bar: every uint8 output pixel within +-1 grey level of the reference; masks bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import poisson_oracle as O
+
+
+def golden():
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'poisson_golden.npz'))
+    names = sorted({k.split('/')[0] for k in d.files})
+    return {n: {f: d[f'{n}/{f}'] for f in ('src', 'tgt', 'mask', 'out', 'gamma')} for n in names}
+
+
+def close_u8(a, b, frac=1.0):
+    """The bar of this step: every pixel within one grey level of the reference.  The output is floor(x^2.2) of a value
+    that, wherever the result equals an input image (kept target pixels, or source == target), sits EXACTLY on an integer
+    boundary; there the last ulp of pow() decides between t and t-1 (the reference itself returns t-1 for many kept
+    pixels), so equality of those pixels is not a meaningful criterion -- `frac` bounds the differing fraction only where
+    the caller knows the solution is generic."""
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    return d.max() <= 1 and (d > 0).mean() <= frac
+
+
+def solved_region(mask):
+    """Pixels that are unknowns of the linear system: mask != 0 plus the image border (the reference's border rows)."""
+    m = (np.asarray(mask).reshape(mask.shape[0], mask.shape[1]) != 0).copy()
+    m[0, :] = m[-1, :] = m[:, 0] = m[:, -1] = True
+    return m
+
+
+def test_oracle_matches_reference_golden():
+    for name, c in golden().items():
+        out = O.poisson_blending(c['src'], c['tgt'], c['mask'], with_gamma=bool(c['gamma']))
+        assert close_u8(out, c['out'], frac=0.05), name          # same solver, same pow: near-identical
+        if name.startswith('all_zero'):
+            # nothing to solve in the interior (the gamma round trip may still drop a level); the border rows are the
+            # reference's quirk: Laplacian rows with the target value as right-hand side
+            assert close_u8(out[1:-1, 1:-1], c['tgt'][1:-1, 1:-1])
+            assert np.abs(out.astype(int) - c['tgt'].astype(int)).max() > 1
+
+
+def test_ellipse_kernels_and_dilate():
+    k5 = O.ellipse_kernel(5)
+    assert k5.tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]   # cv2's 5x5 ellipse
+    k13 = O.ellipse_kernel(13)
+    assert k13.shape == (13, 13) and np.array_equal(k13, k13[::-1]) and np.array_equal(k13, k13[:, ::-1])
+    assert k13.sum(axis=1).tolist() == [1, 7, 9, 11, 13, 13, 13, 13, 13, 11, 9, 7, 1]
+    img = np.zeros((9, 9), np.uint8)
+    img[4, 4] = 1
+    assert np.array_equal(O.dilate(img, k5)[2:7, 2:7], k5)    # dilating a point stamps the (symmetric) element
+    img[:] = 0
+    img[0, 0] = 1                                             # at the corner: outside pixels are ignored
+    assert O.dilate(img, k5)[:3, :3].tolist() == [[1, 1, 1], [1, 1, 1], [1, 0, 0]]    # lower-right quadrant of the element
+
+
+def _inputs(S, seed):
+    from ctrlhair_amd import procedural as P
+    rng = np.random.default_rng(seed)
+    src = ((P.synthetic_images(1, S, seed=seed)[0].transpose(1, 2, 0) * 0.5 + 0.5) * 247 + 4).astype(np.uint8)
+    tgt = np.clip(src.astype(np.int32) + rng.integers(-25, 26, src.shape), 4, 251).astype(np.uint8)
+    ys, xs = np.mgrid[0:S, 0:S]
+    hair = ((ys - 0.3 * S) ** 2 / (0.28 * S) ** 2 + (xs - 0.5 * S) ** 2 / (0.33 * S) ** 2 <= 1).astype(np.uint8)
+    return src, tgt, hair
+
+
+def _blender(**kw):
+    import torch
+    from ctrlhair_amd import lib
+    from ctrlhair_amd.blending import PoissonBlender
+    return PoissonBlender(lib.Handle(0), torch.device('cuda', 0), **kw)
+
+
+@pytest.fixture(scope='module')
+def blender(hip_lib):
+    return _blender()
+
+
+@pytest.mark.gpu
+def test_hip_poisson_matches_reference_golden(blender):
+    for name, c in golden().items():
+        out = blender(c['src'], c['tgt'], c['mask'], with_gamma=bool(c['gamma']))
+        assert out.shape == c['out'].shape and out.dtype == np.uint8
+        assert close_u8(out, c['out']), (name, np.abs(out.astype(int) - c['out'].astype(int)).max())
+
+
+@pytest.mark.gpu
+def test_hip_poisson_tight_tolerance_converges_onto_reference(hip_lib):
+    """With the CG driven to 1e-13 the solved pixels agree with the reference's direct solve almost everywhere."""
+    tight = _blender(max_iters=20000, rel_tol=1e-13)
+    for name, c in golden().items():
+        if name.startswith('all_'):
+            continue                       # degenerate: every pixel on a floor() boundary (see close_u8)
+        out = tight(c['src'], c['tgt'], c['mask'], with_gamma=bool(c['gamma']))
+        u = solved_region(c['mask'])
+        assert close_u8(out, c['out']), name
+        assert (out[u] != c['out'][u]).mean() <= 0.02, (name, (out[u] != c['out'][u]).mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S', [64, 128])
+def test_hip_poisson_matches_oracle(blender, S):
+    src, tgt, hair = _inputs(S, 5 + S)
+    ref = O.poisson_blending(src, tgt, 1 - hair)
+    out = blender(src, tgt, 1 - hair)
+    assert close_u8(out, ref), np.abs(out.astype(int) - ref.astype(int)).max()
+    u = solved_region(1 - hair)
+    assert (out[u] != ref[u]).mean() <= 0.05
+    assert 0 < blender.last_iters < blender.max_iters       # converged, did not hit the cap
+
+
+@pytest.mark.gpu
+def test_hip_blend_mask_bit_exact(blender):
+    rng = np.random.default_rng(3)
+    for S in (64, 256):
+        tp = rng.integers(0, 19, (S, S)).astype(np.uint8)
+        tp[rng.random((S, S)) < 0.9] = 0                    # mostly background, sparse other labels
+        fp = np.zeros((S, S), np.uint8)
+        _, _, hair = _inputs(S, 9)
+        tp[hair == 1] = 13
+        fp[np.roll(hair, S // 10, axis=1) == 1] = 13
+        tp[:, :3] = 4                                        # non-background strip -> 13x13 element there
+        got = blender.blend_mask(tp, fp).cpu().numpy()
+        assert np.array_equal(got, O.blend_mask(tp, fp))
+
+
+@pytest.mark.gpu
+def test_full_size_properties(blender):
+    """512x512 (BASELINE image size; the oracle's direct solve would take minutes): interior pixels outside the solve region
+    keep the target (up to the gamma round trip's floor); source == target is a fixed point for any mask."""
+    S = 512
+    src, tgt, hair = _inputs(S, 77)
+    out = blender(src, tgt, 1 - hair)
+    inner = np.zeros((S, S), bool)
+    inner[1:-1, 1:-1] = True
+    keep = (hair == 1) & inner
+    assert close_u8(out[keep], tgt[keep])
+    assert 0 < blender.last_iters < blender.max_iters
+    assert close_u8(blender(src, src, 1 - hair), src)
+    # the solved region follows the SOURCE gradients: its gamma-space Laplacian matches the source's away from the seam
+    g = lambda a: np.power(a.astype(np.float64), 1 / 2.2)
+    far = np.zeros((S, S), bool)
+    far[S // 2 + 40:S - 8, 8:S - 8] = True                    # well below the hair ellipse
+    lap_o, lap_s = O.laplacian_apply(g(out)[:, :, 0].copy()), O.laplacian_apply(g(src)[:, :, 0].copy())
+    assert np.abs(lap_o - lap_s)[far].mean() < 0.05          # uint8 quantisation of the output bounds this, not the solver

@@ -87,6 +87,24 @@ def main():
     t = timeit(pipeline, warm=1, it=5)
     out['pipeline_config3_f16x3_ms'] = t
     out['pipeline_config3_images_per_s'] = B / t * 1e3
+    # blending step after the generator (8f N3): mask construction + Poisson CG, one image
+    import time
+    from ctrlhair_amd.blending import PoissonBlender
+    from oracle import poisson_oracle as PO         # CPU baseline leg only
+    blender = PoissonBlender(m.generator.handle, m.device)
+    for s_ in (256, 512):
+        ys, xs = np.mgrid[0:s_, 0:s_]
+        hair = ((ys - 0.3 * s_) ** 2 / (0.28 * s_) ** 2 + (xs - 0.5 * s_) ** 2 / (0.33 * s_) ** 2 <= 1).astype(np.uint8)
+        src = ((P.synthetic_images(1, s_, seed=5)[0].transpose(1, 2, 0) * 0.5 + 0.5) * 247 + 4).astype(np.uint8)
+        tgt = np.clip(src.astype(np.int32) + 17, 4, 251).astype(np.uint8)
+        st, tt = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+        mt = torch.from_numpy(1 - hair).cuda()
+        out[f'poisson_blend_{s_}_ms'] = timeit(lambda: blender(st, tt, mt), warm=2, it=5)
+        out[f'poisson_blend_{s_}_cg_iterations'] = blender.last_iters
+        if s_ == 256:
+            t0 = time.time()
+            PO.poisson_blending(src, tgt, 1 - hair)
+            out['poisson_blend_256_cpu_oracle_ms'] = (time.time() - t0) * 1e3
     print(json.dumps(out, indent=1))
 
 
