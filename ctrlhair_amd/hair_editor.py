@@ -35,21 +35,7 @@ def procedural_weights(seed: int = 0, ngf: int = 64) -> Dict[str, dict]:
             'color_dis': cs['dis'], 'color_rgb': cs['rgb'], 'bisenet': P.bisenet_state_dict(seed)}
 
 
-def reference_checkpoints(root: str = '.') -> Dict[str, dict]:
-    """Load the reference's own checkpoint files (hair_editor.py:45-108, util/util.py:202-208,
-    my_torchlib/utils.py:25-36, my_parsing_util.py:42-43) when a user has them."""
-    def latest(d):
-        with open(os.path.join(d, 'latest_checkpoint')) as f:
-            return torch.load(os.path.join(d, f.read().strip()), map_location='cpu')
-    strip = lambda sd: {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
-    ct = latest(os.path.join(root, 'model_trained/color_texture/045__color_texture_final/checkpoints'))
-    sh = latest(os.path.join(root, 'model_trained/shape/054__shape_final/checkpoints'))
-    rgb = latest(os.path.join(root, 'model_trained/color_encoder/p004___pca_std/checkpoints'))
-    return {'sean': torch.load(os.path.join(root, 'external_model_params/sean_checkpoints/CelebA-HQ_pretrained/latest_net_G.pth'),
-                               map_location='cpu'),
-            'shape': strip(sh['Model_G']), 'color_gen': strip(ct['Model_G']), 'color_dis': strip(ct['Model_D']),
-            'color_rgb': strip(rgb['Predictor']),
-            'bisenet': torch.load(os.path.join(root, 'external_model_params/face_parsing_79999_iter.pth'), map_location='cpu')}
+from .checkpoints import reference_checkpoints      # noqa: E402,F401  (reference checkpoint tree reader)
 
 
 class HipModels:
@@ -79,8 +65,13 @@ class HairEditor:
         if models is None:
             if weights == 'procedural':
                 weights = procedural_weights()
-            elif weights == 'reference':
-                weights = reference_checkpoints()
+            elif weights == 'reference' or (isinstance(weights, str) and os.path.isdir(weights)):
+                # the reference's checkpoint tree ('reference' = the current directory, like the reference itself)
+                weights = reference_checkpoints('.' if weights == 'reference' else weights)
+                if texture_dirs is None and weights.get('texture_dirs'):
+                    texture_dirs = weights['texture_dirs']          # hair_editor.py:82-91
+                if shape_dirs is None and weights.get('shape_dirs'):
+                    shape_dirs = weights['shape_dirs']              # hair_editor.py:110-119
             models = HipModels(weights, device=device, img_size=img_size, max_batch=max_batch)
         self.models = models
         self.sean_model = models.sean_model
