@@ -72,6 +72,9 @@ struct ConvParams {
     int cps;                // chunks per split
     float* partial;         // [splitk][B][Mrows][H*W] scratch (then splitk_reduce_kernel applies bias/res/act)
     long long partial_cap;  // floats available in `partial` (0 = split-K disabled)
+    const void* in2;        // f16x3 plain 3x3 conv: optional second input (SH16, Cin2 channels) whose 1x1 conv with wpk2 is added
+    const float* wpk2;      //   into the same accumulators (ResBlock shortcut conv_s folded into conv_1); null = none
+    int Cin2;
     int terms;              // f16 MFMA path: 0/3 = three-term split operands (f32-class), 1 = hi halves only (f16 operands)
     int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over the persistent kernel)
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop

@@ -252,7 +252,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 // in : SH16 [B][Cin/8][2][H][W][8]   (Cin % 16 == 0; padding channels hold zeros)
 // EPI_PLAIN -> out f32 NCHW [B][Mrows][H][W] (bias / residual / act as conv_mfma)
 // EPI_ACE   -> out SH16 [B][ceil(C/8)][2][H][W][8]  (the fused ACE epilogue of conv_mfma.h, re-split for the next conv)
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, NLOAD = Cfg::NLOAD, HALO = Cfg::HALO;
@@ -328,12 +328,31 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
 
     // A fragments: [mtile][chunk][tap][msub][hl][lane] units of 16 B
     const uint4* Ap = reinterpret_cast<const uint4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NT * 4 * 64) + lane;
+    // FUSE: second operand (see the loop after the main loop); its first chunk is staged during the last 3x3 chunk
+    const int nch2 = FUSE ? (p.Cin2 + 15) >> 4 : 0;
+    const uint4* gin2 = reinterpret_cast<const uint4*>(p.in2) + (FUSE ? (long long)b0 * ((p.Cin2 >> 3) - G) * 2 * HW : 0);
+    const uint4* Ap2 = reinterpret_cast<const uint4*>(p.wpk2) + ((long long)mtile64 * nch2) * (4 * 64) + lane;
+    auto stage2 = [&](int chunk, int buf) {
+        uint4 stg[NLOAD];
+        const uint4* src = gin2 + (long long)chunk * 4 * HW;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+        uint4* dst = smem_u + buf * UNITS;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = tid + i * 256;
+            if (u < UNITS) dst[u] = stg[i];
+        }
+    };
 
     if (!(p.dbg & 8)) stage(c_lo, 0);
     __syncthreads();
 
     for (int ch = c_lo; ch < c_hi; ++ch) {
         if (ch + 1 < c_hi && !(p.dbg & 1)) stage(ch + 1, (ch + 1 - c_lo) & 1);
+        if constexpr (FUSE) {
+            if (ch + 1 == c_hi) stage2(0, (ch + 1 - c_lo) & 1);
+        }
         const uint4* sb = smem_u + ((ch - c_lo) & 1) * UNITS;
         if (p.dbg & 2) { __syncthreads(); continue; }
         const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
@@ -376,6 +395,43 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
         }
         __syncthreads();
+    }
+
+    if constexpr (FUSE) {
+        // Fused 1x1 operand (ResBlock shortcut conv_s folded into conv_1: out = W1 (3x3) h1 + Ws (1x1) hs + b): the same
+        // pixel patch of the SECOND input, 16 channels per chunk, centre tap only, into the same accumulators -- saves the
+        // shortcut's own kernel, its C4 write and the residual read.  TB == 1 (one sample per block), no split-K.
+        for (int c2 = 0; c2 < nch2; ++c2) {
+            const int v = p.nchunks + c2;                      // virtual chunk index: LDS stage parity continues
+            if (c2 + 1 < nch2) stage2(c2 + 1, (v + 1) & 1);
+            const uint4* sb = smem_u + (v & 1) * UNITS;
+            const uint4* Ac2 = Ap2 + (long long)c2 * (4 * 64);
+            uint4 a2[4], bh[4], bl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a2[q] = Ac2[q * 64];
+            constexpr int kc = HALO * PW + HALO;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bh[n] = sb[ub[n] + kc];
+                bl[n] = sb[ub[n] + kc + PLANE];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const half8 ah = __builtin_bit_cast(half8, a2[m * 2 + 0]);
+                const half8 al = __builtin_bit_cast(half8, a2[m * 2 + 1]);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const half8 xh = __builtin_bit_cast(half8, bh[n]);
+                    const half8 xl = __builtin_bit_cast(half8, bl[n]);
+                    if (TERMS == 3) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m][n], 0, 0, 0);
+                    }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m][n], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
     }
 
     if (p.dbg & 4) return;
@@ -774,10 +830,10 @@ __global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
     }
 }
 
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false>
 hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
-    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS>;
+    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -793,7 +849,7 @@ hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     const int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
     p.splitk = 1;
     p.cps = p.nchunks;
-    if (EPI == EPI_PLAIN && p.partial && grid < 192 && p.nchunks >= 8) {
+    if (EPI == EPI_PLAIN && p.partial && grid < 192 && p.nchunks >= 8 && !FUSE) {
         // few tiles, long reduction (low-resolution 1024-channel layers, small batches): split K over more blocks
         const long long slab = (long long)p.B * ((p.Mrows + 3) / 4 * 4) * p.H * p.W;
         int sk = (512 + grid - 1) / grid;
@@ -834,8 +890,14 @@ template <int KS, int TERMS>
 hipError_t dispatch_sh16_plain(const ConvParams& p, hipStream_t s) {
     // dbg bit 64: wave-specialised persistent kernel (measured slower than the 2-blocks-per-CU kernel for the plain
     // epilogue, whose residual loads it cannot hide; kept selectable for profiling)
-    if ((p.dbg & 64) && p.W >= 32 && !(p.partial && p.mtiles_hint_small))
+    if ((p.dbg & 64) && p.W >= 32 && !(p.partial && p.mtiles_hint_small) && !p.in2)
         return launch_sh16_ws<KS, 32, 16, 1, EPI_PLAIN, TERMS>(p, p.Mrows, s);
+    if (p.in2) {        // 3x3 conv with a fused 1x1 second operand (ResBlock shortcut): 32x16 tiles only
+        if constexpr (KS == 3) {
+            if (p.W >= 32) return launch_sh16<3, 32, 16, 1, EPI_PLAIN, TERMS, true>(p, p.Mrows, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (p.W >= 32) return launch_sh16<KS, 32, 16, 1, EPI_PLAIN, TERMS>(p, p.Mrows, s);
     if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN, TERMS>(p, p.Mrows, s);
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, TERMS>(p, p.Mrows, s);

@@ -461,8 +461,19 @@ struct Runner {
               4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
     }
 
-    void conv(const ConvW& w, const float* in, float* out, int r, const float* res, int res_up) {
+    // fuse: optional (weights, input) of a 1x1 conv added into this 3x3 conv's accumulators (f16x3 path, W >= 32, no split-K)
+    bool can_fuse_1x1(const ConvW& w, int r) const {
+        return m.use_sh16 && !(m.dbg & 32) && w.KS == 3 && r >= 32 &&
+               !(((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192);
+    }
+    void conv(const ConvW& w, const float* in, float* out, int r, const float* res, int res_up, const ConvW* w2 = nullptr,
+              const float* in2 = nullptr) {
         ConvParams p{};
+        if (w2) {
+            p.in2 = in2;
+            p.wpk2 = w2->wpk;
+            p.Cin2 = w2->Cin;
+        }
         p.in = in;
         p.wpk = w.wpk;
         p.out = out;
@@ -481,9 +492,9 @@ struct Runner {
         p.partial = m.splitk_ws;
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
-        const double npix = (double)B * r * r, k2 = w.KS * w.KS;
-        timed(0, 2.0 * w.Cout * w.Cin * k2 * npix,
-              4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * k2), [&] {
+        const double npix = (double)B * r * r, k2 = w.KS * w.KS, cin2 = w2 ? w2->Cin : 0;
+        timed(0, 2.0 * w.Cout * (w.Cin * k2 + cin2) * npix,
+              4.0 * (npix * (w.Cin + cin2) + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * (w.Cin * k2 + cin2)), [&] {
                   if (m.use_sh16) check(conv_sh16_plain(p, w.KS, st), "conv");
                   else check(w.KS == 3 ? conv_plain3(p, st) : conv_plain1(p, st), "conv");
               });
@@ -526,13 +537,18 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             const float* xsrc = x;   // block input (at r/2 when up_before)
             const float* shortcut;
             int sc_up;
+            bool fuse_s = false;
             if (b.learned) {
                 R.ace(b.ace_s, lab, cd, nz, nf, noff, xsrc, up, ACT_NONE, hs);
                 noff += rr;
                 R.tap_sh16(b.name + ".hs", hs, b.fin, rr);
-                R.conv(b.conv_s, hs, xs, r, nullptr, 0);
-                R.tap_c4(b.name + ".xs", xs, b.fout, rr);
-                shortcut = xs;
+                // the 1x1 shortcut conv is folded into conv_1 (extra K chunks on a second input) unless a test taps its output
+                fuse_s = R.can_fuse_1x1(b.conv_1, r) && !taps.count(b.name + ".xs");
+                if (!fuse_s) {
+                    R.conv(b.conv_s, hs, xs, r, nullptr, 0);
+                    R.tap_c4(b.name + ".xs", xs, b.fout, rr);
+                }
+                shortcut = fuse_s ? nullptr : xs;
                 sc_up = 0;
             } else {
                 shortcut = xsrc;
@@ -546,7 +562,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             R.ace(b.ace_1, lab, cd, nz, nf, noff, dx, 0, ACT_LRELU, h1);
             noff += rr;
             R.tap_sh16(b.name + ".h1", h1, b.fmid, rr);
-            R.conv(b.conv_1, h1, y, r, shortcut, sc_up);
+            R.conv(b.conv_1, h1, y, r, shortcut, sc_up, fuse_s ? &b.conv_s : nullptr, fuse_s ? hs : nullptr);
             R.tap_c4(b.name, y, b.fout, rr);
             std::swap(x, y);
         }
