@@ -86,12 +86,16 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
                                                                   const float* __restrict__ table,
                                                                   const float* __restrict__ bias, uint4* __restrict__ out,
                                                                   int B, int H, int W, int K, int relu) {
-    __shared__ float T[19 * 9 * OH_KC];
-    __shared__ float bs[OH_KC];
+    // Table slice in LDS with a padded row pitch (36 floats: consecutive (label, tap) rows start 4 banks apart, so lanes
+    // that hold different labels do not collide on the same banks) and one extra all-zero row that taps outside the image
+    // point at -- every lane then issues the same 9 x 2 ds_read_b128 per 8 channels, no predication.
+    constexpr int RS = OH_KC + 4, ZROW = 19 * 9;
+    __shared__ __attribute__((aligned(16))) float T[(ZROW + 1) * RS];
+    __shared__ __attribute__((aligned(16))) float bs[OH_KC];
     const int k0 = blockIdx.y * OH_KC;
-    for (int i = threadIdx.x; i < 19 * 9 * OH_KC; i += 256) {
+    for (int i = threadIdx.x; i < (ZROW + 1) * OH_KC; i += 256) {
         const int jt = i / OH_KC, kk = i % OH_KC;
-        T[i] = (k0 + kk < K) ? table[(long long)jt * K + k0 + kk] : 0.f;
+        T[jt * RS + kk] = (jt < ZROW && k0 + kk < K) ? table[(long long)jt * K + k0 + kk] : 0.f;
     }
     if (threadIdx.x < OH_KC) bs[threadIdx.x] = (k0 + threadIdx.x < K) ? bias[k0 + threadIdx.x] : 0.f;
     __syncthreads();
@@ -104,25 +108,30 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        jt[t] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    ? (lab[b * HW + (long long)yy * W + xx] * 9 + t) * OH_KC
-                    : -1;
+        const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const int j = lab[b * HW + (in ? (long long)yy * W + xx : 0)];
+        jt[t] = (in ? j * 9 + t : ZROW) * RS;
     }
     const int G = (K + 7) / 8;
 #pragma unroll
     for (int gq = 0; gq < OH_KC / 8; ++gq) {
         const int g = k0 / 8 + gq;
         if (g >= G) break;
+        float4 a0 = *reinterpret_cast<const float4*>(bs + gq * 8), a1 = *reinterpret_cast<const float4*>(bs + gq * 8 + 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                       // same summation order as the f32 kernel (+0.f for outside taps)
+            const float4* r = reinterpret_cast<const float4*>(T + jt[t] + gq * 8);
+            const float4 r0 = r[0], r1 = r[1];
+            a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
+            a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
+        }
+        const float v8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         h8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int kk = gq * 8 + e;
-            float v = bs[kk];
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                if (jt[t] >= 0) v += T[jt[t] + kk];
+            float v = v8[e];
             if (relu) v = v > 0.f ? v : 0.f;
-            if (k0 + kk >= K) v = 0.f;
+            if (k0 + gq * 8 + e >= K) v = 0.f;
             const _Float16 h = (_Float16)v;
             vh[e] = h;
             vl[e] = (_Float16)(v - (float)h);
