@@ -146,13 +146,14 @@ def main():
             executed, peak = alg, PEAK_F32_MFMA_TFLOPS
             kname = 'conv_mfma_kernel<KS=3,...,EPI_ACE> (SPADE gamma/beta conv, exact-f32 MFMA, fused ACE epilogue)'
             dtype = 'f32'
-        traffic = None
+        traffic = traffic_detail = None
         tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
         if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
             try:
-                traffic = json.load(open(tpath)).get(args.path)
+                traffic_detail = json.load(open(tpath)).get(args.path)
+                traffic = traffic_detail and round(float(traffic_detail['hbm_bytes']))
             except Exception:
-                traffic = None
+                traffic = traffic_detail = None
         res = {
             'metric': '512x512 edited images/sec (SEAN generator forward), whole job',
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -165,7 +166,8 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': kname,
                 'achieved': round(executed, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(executed / peak, 4), 'traffic': traffic,
+                'frac': round(executed / peak, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)',
+                'traffic_detail': traffic_detail,
                 'algorithmic_f32_tflops': round(alg, 2),
                 'launches': prof_ace['launches'], 'avg_launch_ms': round(prof_ace['ms'] / max(prof_ace['launches'], 1), 4),
                 'flops_per_launch_avg': prof_ace['flops'] / max(prof_ace['launches'], 1),
