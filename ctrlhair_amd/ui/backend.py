@@ -3,7 +3,6 @@ Every public method of ui/backend.py:67-462 is present with the same name, argum
 references are given per method.  Shape transfer by photo (`transfer_latent_representation('shape')`) needs the
 reference's ARAP warping tool chain (wrap_codes/, dlib) and accepts an injected `warper` instead.
 """
-import copy
 import os
 
 import numpy as np
@@ -70,60 +69,53 @@ class Backend(HairEditor):
         mask256 = U.resize_nearest(mask, (256, 256)) if mask.shape[0] != 256 else mask
         mask_batch = self.preprocess_mask(mask)
         mask_tensor = torch.tensor(mask256[None], dtype=torch.uint8, device=self.device)
-        hair_code, face_code = self.mask_generator.encode_labels(mask_tensor)   # == one-hot, split, two encoders (:81-86)
-        lr.shape = hair_code
-        lr.face = face_code
-        out_mask = self.mask_generator.decode_labels(hair_code, face_code).cpu().numpy()[0]   # :87-90
-        # infer feature (:93-105)
-        input_code = self.get_code(self.preprocess_img(img_rgb), mask_batch)
-        hair_feature = input_code[:, HAIR_IDX]
-        out_color = self.feature_rgb_predictor({'code': hair_feature})
-        c = out_color['rgb_mean'].detach().cpu().numpy()
-        c_hsv = U.rgb_to_hsv_u8(np.clip(c, 0, 255)[None, ...].astype('uint8'))
-        lr.color = {'hsv': torch.tensor(c_hsv).to(self.device)[0], 'pca_std': out_color['pca_std']}
-        out_enc = self.feature_encoder({'code': hair_feature})
-        lr.curliness = out_enc['noise_curliness']
-        lr.texture = out_enc['noise']
-        return img_ts, out_mask, lr, mask, input_code, hair_feature
+        lr.shape, lr.face = self.mask_generator.encode_labels(mask_tensor)   # == one-hot, split, two encoders (:81-86)
+        decoded = self.mask_generator.decode_labels(lr.shape, lr.face).cpu().numpy()[0]      # :87-90
+        # hair appearance: Zencoder code of the hair region -> colour statistics and texture / curliness latents (:93-105)
+        codes = self.get_code(self.preprocess_img(img_rgb), mask_batch)
+        hair = codes[:, HAIR_IDX]
+        stats = self.feature_rgb_predictor({'code': hair})
+        rgb_u8 = np.clip(stats['rgb_mean'].detach().cpu().numpy(), 0, 255).astype('uint8')
+        lr.color = {'hsv': torch.tensor(U.rgb_to_hsv_u8(rgb_u8[None, ...])).to(self.device)[0], 'pca_std': stats['pca_std']}
+        latents = self.feature_encoder({'code': hair})
+        lr.curliness, lr.texture = latents['noise_curliness'], latents['noise']
+        return img_ts, decoded, lr, mask, codes, hair
+
+    def _convert_u8(self, t, fn):
+        arr = t.detach().cpu().numpy().astype('uint8')            # the reference truncates to uint8 before cv2.cvtColor
+        return torch.tensor(fn(arr[None, ...])).to(self.device)[0]
 
     def tensor_hsv_to_rgb(self, hsv):             # :108-115
-        c = hsv.detach().cpu().numpy()
-        return torch.tensor(U.hsv_to_rgb_u8(c[None, ...].astype('uint8'))).to(self.device)[0]
+        return self._convert_u8(hsv, U.hsv_to_rgb_u8)
 
     def tensor_rgb_to_hsv(self, rgb):             # :117-125
-        c = rgb.detach().cpu().numpy()
-        return torch.tensor(U.rgb_to_hsv_u8(c[None, ...].astype('uint8'))).to(self.device)[0]
+        return self._convert_u8(rgb, U.rgb_to_hsv_u8)
 
     def set_input_img(self, img_rgb):             # :127-135
-        self.input_img, self.cur_mask, self.cur_latent, \
-            self.input_mask, self.input_sean_code, self.input_hair_feature = self.parse_img(img_rgb)
+        parsed = self.parse_img(img_rgb)
+        (self.input_img, self.cur_mask, self.cur_latent, self.input_mask, self.input_sean_code,
+         self.input_hair_feature) = parsed
         return self.input_img, mask_to_rgb(self.cur_mask, draw_type=1)
 
     def set_target_img(self, img_rgb):            # :137-145
-        self.target_img, _, self.target_latent, \
-            self.target_mask, _, self.target_hair_feature = self.parse_img(img_rgb)
+        parsed = self.parse_img(img_rgb)
+        self.target_img, self.target_latent, self.target_mask, self.target_hair_feature = (parsed[0], parsed[2], parsed[3],
+                                                                                          parsed[5])
         return self.target_img, mask_to_rgb(self.target_mask, draw_type=1)
 
     # ---- render (ui/backend.py:147-175) ----------------------------------------------------------------------
     def output(self, target_latent=None, feature=None):
-        if target_latent is None:
-            target_latent = self.cur_latent
-            target_mask = self.cur_mask
-        else:
-            target_mask = self.refresh_cur_mask(target_latent)[0]
-        if 'rgb_mean' in target_latent.color:
-            target_color_rgb = self.target_latent.color['rgb_mean']
-        else:
-            target_color_rgb = self.tensor_hsv_to_rgb(target_latent.color['hsv'])
+        lat = self.cur_latent if target_latent is None else target_latent
+        mask = self.cur_mask if target_latent is None else self.refresh_cur_mask(lat)[0]
         if feature is None:
-            data = {'noise': target_latent.texture, 'noise_curliness': target_latent.curliness,
-                    'rgb_mean': target_color_rgb, 'pca_std': target_latent.color['pca_std']}
-            feature = self.feature_generator(data)['code']
+            # colour: an explicit mean RGB wins -- and, as in the reference (:157), it is read from self.target_latent
+            rgb = self.target_latent.color['rgb_mean'] if 'rgb_mean' in lat.color else self.tensor_hsv_to_rgb(lat.color['hsv'])
+            feature = self.feature_generator({'noise': lat.texture, 'noise_curliness': lat.curliness, 'rgb_mean': rgb,
+                                              'pca_std': lat.color['pca_std']})['code']
         self.input_sean_code[:, HAIR_IDX] = feature                      # in-place, like :170
-        edit_img = self.gen_img(self.input_sean_code, self._mask_for_sean(target_mask)[None, None, ...], noise=self.noise)
-        output_img, _ = self.postprocess_blending(self.input_img, edit_img, self.input_mask, target_mask,
-                                                  blending=self.blending, blender=self.blender)
-        return output_img
+        rendered = self.gen_img(self.input_sean_code, self._mask_for_sean(mask)[None, None, ...], noise=self.noise)
+        return self.postprocess_blending(self.input_img, rendered, self.input_mask, mask, blending=self.blending,
+                                         blender=self.blender)[0]
 
     # ---- batched rendering -------------------------------------------------------------------------
     def copy_latent(self, latent=None):
@@ -203,12 +195,11 @@ class Backend(HairEditor):
         self.cur_latent.curliness[0] = val
 
     def change_color(self, val, idx):
-        if idx == 3:
-            val = (val + self.maximum_value_fe) / 2 / self.maximum_value_fe
-            self.cur_latent.color['pca_std'][0] = val * 100 + 20
-        else:
-            val = self.dist_translation.gaussian_to_val(idx, val)
-            self.cur_latent.color['hsv'][0][idx] = val
+        color = self.cur_latent.color
+        if idx == 3:      # slider in [-max, max] -> colour variance (pca_std) in [20, 120]
+            color['pca_std'][0] = 20 + 100 * (val + self.maximum_value_fe) / 2 / self.maximum_value_fe
+        else:             # h / s / v sliders live in the dataset's Gaussianised space
+            color['hsv'][0][idx] = self.dist_translation.gaussian_to_val(idx, val)
 
     def change_shape(self, val, idx):
         self.continue_change_with_direction('shape', self.shape_dirs[idx], val)
@@ -221,12 +212,10 @@ class Backend(HairEditor):
         return self.cur_latent.curliness[0]
 
     def get_color_be2fe(self):
-        c_hsv = self.cur_latent.color['hsv'].detach().cpu().numpy()[0]
-        color0 = self.dist_translation.val_to_gaussian(0, c_hsv[0])
-        color1 = self.dist_translation.val_to_gaussian(1, c_hsv[1])
-        color2 = self.dist_translation.val_to_gaussian(2, c_hsv[2])
-        var_fe = (self.cur_latent.color['pca_std'][0] - 20) / 100 * 2 * self.maximum_value_fe - self.maximum_value_fe
-        return color0, color1, color2, var_fe
+        hsv = self.cur_latent.color['hsv'].detach().cpu().numpy()[0]
+        sliders = [self.dist_translation.val_to_gaussian(i, hsv[i]) for i in range(3)]
+        spread = (self.cur_latent.color['pca_std'][0] - 20) / 100            # inverse of change_color(.., 3)
+        return (*sliders, spread * 2 * self.maximum_value_fe - self.maximum_value_fe)
 
     def get_shape_be2fe(self):
         return [torch.dot(self.cur_latent.shape[0], self.shape_dirs[idx]) for idx in range(4)]
@@ -250,67 +239,55 @@ class Backend(HairEditor):
             self.target_latent.shape = hair_code
             self.target_latent.face = face_code
             self.refresh_cur_mask()
-        target_att = self.target_latent.__getattribute__(flag)
-        if isinstance(target_att, torch.Tensor):
-            self.cur_latent.__setattr__(flag, target_att.clone())
-        else:
-            cp_dict = copy.copy(target_att)
-            for ke in cp_dict:
-                cp_dict[ke] = cp_dict[ke].clone()
-            self.cur_latent.__setattr__(flag, cp_dict)
+        src = getattr(self.target_latent, flag)          # tensors are cloned, the colour dict entry by entry
+        setattr(self.cur_latent, flag, src.clone() if isinstance(src, torch.Tensor) else {k: v.clone() for k, v in src.items()})
         if flag == 'shape' and refresh:
             self.refresh_cur_mask()
-        if flag == 'texture':
+        if flag == 'texture':                            # texture and curliness travel together (:300-302)
             self.transfer_latent_representation('curliness')
 
     def refresh_cur_mask(self, target_latent=None):      # :304-315
-        if target_latent is None:
-            target_latent = self.cur_latent
-        out_mask = self.mask_generator.decode_labels(target_latent.shape, target_latent.face).cpu().numpy()[0]
-        self.cur_mask = out_mask
-        return out_mask, mask_to_rgb(out_mask, draw_type=1)
+        lat = self.cur_latent if target_latent is None else target_latent
+        self.cur_mask = self.mask_generator.decode_labels(lat.shape, lat.face).cpu().numpy()[0]
+        return self.cur_mask, mask_to_rgb(self.cur_mask, draw_type=1)
 
     def get_cur_mask(self):
         return mask_to_rgb(self.cur_mask, draw_type=1)
 
     # ---- interpolation (ui/backend.py:323-395) ------------------------------------------------------------------
     def interpolate_hsv(self, hsv1, hsv2, alpha):
-        rgb1 = self.tensor_hsv_to_rgb(hsv1)
-        rgb2 = self.tensor_hsv_to_rgb(hsv2)
-        return self.tensor_rgb_to_hsv(rgb1 * (1 - alpha) + rgb2 * alpha)
+        mix = self.tensor_hsv_to_rgb(hsv1) * (1 - alpha) + self.tensor_hsv_to_rgb(hsv2) * alpha     # blend in RGB, not in hue
+        return self.tensor_rgb_to_hsv(mix)
 
     def interpolate_triple(self, latent1, latent2, latent3, alpha1, alpha2, alpha3):
-        latent12 = self.interpolate(latent1, latent2, alpha2 / (alpha1 + alpha2))
-        return self.interpolate(latent12, latent3, alpha3)
+        return self.interpolate(self.interpolate(latent1, latent2, alpha2 / (alpha1 + alpha2)), latent3, alpha3)
+    @staticmethod
+    def _lerp(a, b, alpha):
+        return a * (1 - alpha) + b * alpha
+
+    def _lerp_color(self, c1, c2, alpha):
+        return {'pca_std': self._lerp(c1['pca_std'], c2['pca_std'], alpha), 'hsv': self.interpolate_hsv(c1['hsv'], c2['hsv'], alpha)}
 
     def interpolate(self, latent1, latent2, alpha):
-        result_latent = LatentRepresentation()
-        for att in ['curliness', 'shape', 'texture']:
-            result_latent.__setattr__(att, latent1.__getattribute__(att) * (1 - alpha) + latent2.__getattribute__(att) * alpha)
-        color_dic = {'pca_std': latent1.color['pca_std'] * (1 - alpha) + latent2.color['pca_std'] * alpha,
-                     'hsv': self.interpolate_hsv(latent1.color['hsv'], latent2.color['hsv'], alpha)}
-        result_latent.color = color_dic
-        result_latent.face = self.cur_latent.face
-        return result_latent
+        out = LatentRepresentation()
+        for name in ('curliness', 'shape', 'texture'):
+            setattr(out, name, self._lerp(getattr(latent1, name), getattr(latent2, name), alpha))
+        out.color = self._lerp_color(latent1.color, latent2.color, alpha)
+        out.face = self.cur_latent.face
+        return out
 
     def interpolate_each_att(self, latent1, latent2, alpha, att_name):
-        result_latent = LatentRepresentation()
-        for att in ['curliness', 'shape', 'texture']:
-            result_latent.__setattr__(att, self.cur_latent.__getattribute__(att).clone())
-        if att_name == 'shape':
-            color_dic = {s: self.cur_latent.color[s].clone() for s in ['hsv', 'pca_std']}
-            result_latent.__setattr__(att_name, latent1.__getattribute__(att_name) * (1 - alpha) +
-                                      latent2.__getattribute__(att_name) * alpha)
-        elif att_name in ['curliness', 'texture']:
-            color_dic = {s: self.cur_latent.color[s].clone() for s in ['hsv', 'pca_std']}
-            for a in ('curliness', 'texture'):
-                result_latent.__setattr__(a, latent1.__getattribute__(a) * (1 - alpha) + latent2.__getattribute__(a) * alpha)
+        """Start from the current latent and move only one attribute family along latent1 -> latent2: 'shape'; 'curliness'
+        or 'texture' (always both); anything else = colour."""
+        out = self.copy_latent()
+        moved = {'shape': ('shape',), 'curliness': ('curliness', 'texture'), 'texture': ('curliness', 'texture')}.get(att_name)
+        if moved is None:
+            out.color = self._lerp_color(latent1.color, latent2.color, alpha)
         else:
-            color_dic = {'pca_std': latent1.color['pca_std'] * (1 - alpha) + latent2.color['pca_std'] * alpha,
-                         'hsv': self.interpolate_hsv(latent1.color['hsv'], latent2.color['hsv'], alpha)}
-        result_latent.color = color_dic
-        result_latent.face = self.cur_latent.face
-        return result_latent
+            for name in moved:
+                setattr(out, name, self._lerp(getattr(latent1, name), getattr(latent2, name), alpha))
+            out.color = {k: self.cur_latent.color[k].clone() for k in ('hsv', 'pca_std')}
+        return out
 
     @staticmethod
     def show_hair_region(mask, non_hair_value=0):
@@ -319,12 +296,12 @@ class Backend(HairEditor):
         return mask_rgb
 
     def directly_change_hair_mask(self, hair_mask):      # :410-422
-        hair_mask = hair_mask == HAIR_IDX
-        face_logit = self.mask_generator.forward_face_decoder(self.cur_latent.face)
-        hair_logit = torch.tensor(hair_mask)[None, None, ...].type_as(face_logit).to(self.device)
-        hair_logit = hair_logit * (face_logit.max() - face_logit.min() + 2) + face_logit.min() - 1
-        mask = self.mask_generator.forward_decoder(hair_logit, face_logit)
-        self.cur_mask = mask_one_hot_to_label(mask).cpu().numpy()[0]
+        face = self.mask_generator.forward_face_decoder(self.cur_latent.face)
+        lo, hi = face.min(), face.max()
+        # a hair "logit" that beats every face logit inside the drawn region (hi + 1) and loses everywhere else (lo - 1)
+        drawn = torch.tensor(hair_mask == HAIR_IDX)[None, None, ...].type_as(face).to(self.device)
+        hair = drawn * (hi - lo + 2) + lo - 1
+        self.cur_mask = mask_one_hot_to_label(self.mask_generator.forward_decoder(hair, face)).cpu().numpy()[0]
 
     def get_random_texture(self):
         self.cur_latent.texture = generate_noise(1, 8).to(self.device)
@@ -337,8 +314,7 @@ class Backend(HairEditor):
         self.cur_latent.curliness = generate_noise(1, 1).to(self.device)
 
     def continue_change_with_direction(self, att_name, direction, val):     # :450-462
-        att = self.cur_latent.__getattribute__(att_name)
-        att = att + (val - torch.dot(att[0], direction)) * direction
-        self.cur_latent.__setattr__(att_name, att)
+        cur = getattr(self.cur_latent, att_name)          # move along `direction` until the projection equals `val`
+        setattr(self.cur_latent, att_name, cur + (val - torch.dot(cur[0], direction)) * direction)
         if att_name == 'shape':
             self.refresh_cur_mask()
