@@ -6,7 +6,7 @@ synthetic 512x512 blocky label maps + tanh(N(0,1)) style codes + explicit N(0,1)
 (random, calibrated) weights of the real ngf=64 architecture, fp32 end to end.  One "step" = one generator
 pass over one batch already resident in HBM.  With N>1 (one process per GPU, torch.distributed/RCCL) every
 rank runs its own batch (weak scaling) and the per-rank output shards are all-gathered over xGMI inside the
-timed region, as north_star asks.
+timed region, as north_star asks (on a side stream, under the next step's generator pass; --sync-gather serialises it).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--size 512] [--no-cpu-baseline]
 
@@ -65,6 +65,9 @@ def main():
                          '(default; max |delta| vs the exact path 1.5e-5); f32 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32); '
                          'f16 = single-term f16 operands (reduced precision, BASELINE configs[4]; informational)')
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--sync-gather', action='store_true',
+                    help='N > 1: all-gather each step on the compute stream instead of overlapping it with the next step')
+    ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)   # 1-rank process group: exercises the N > 1 code
     args = ap.parse_args()
 
     import torch
@@ -78,9 +81,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from ctrlhair_amd import procedural as P
@@ -94,16 +98,37 @@ def main():
     labels = torch.from_numpy(P.blocky_labels(B, S, first=first)).to(dev)
     codes = torch.from_numpy(P.style_codes(B, first=first)).to(dev)
     noise = torch.from_numpy(P.noise_planes(B, S, ngf, first=first)).to(dev)
-    out = torch.empty(B, 3, S, S, dtype=torch.float32, device=dev)
-    gathered = torch.empty(world * B, 3, S, S, dtype=torch.float32, device=dev) if world > 1 else None
+    # Two output / gather buffers: the RCCL all-gather of step i (side stream, over xGMI) runs under the generator pass of
+    # step i+1; the timed region ends after the last gather has completed (device-wide synchronize).
+    outs = [torch.empty(B, 3, S, S, dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty(world * B, 3, S, S, dtype=torch.float32, device=dev) for _ in range(2)] if dist else None
+    comm = torch.cuda.Stream(dev) if dist else None
+    gather_done = [None, None]
+    counter = [0]
 
     def step():
-        gen.generate(labels, codes, noise, out=out)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+        j = counter[0] & 1
+        counter[0] += 1
+        main = torch.cuda.current_stream(dev)
+        if gather_done[j] is not None:
+            main.wait_event(gather_done[j])          # the gather that read outs[j] two steps ago
+        gen.generate(labels, codes, noise, out=outs[j])
+        if dist is None:
+            return
+        if args.sync_gather:
+            dist.all_gather_into_tensor(gathered[j], outs[j])
+            return
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            dist.all_gather_into_tensor(gathered[j], outs[j])
+            done = torch.cuda.Event()
+            done.record(comm)
+        gather_done[j] = done
 
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -117,6 +142,10 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     gen.handle.profile_enable(False)
+    out = outs[(counter[0] - 1) & 1]
+    if dist is not None and args.steps > 0:        # the gathered buffer holds every rank's shard, this rank's at its slot
+        g = gathered[(counter[0] - 1) & 1]
+        assert torch.equal(g[rank * B:(rank + 1) * B], out), 'all-gather result does not contain this rank\'s shard'
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -127,6 +156,7 @@ def main():
     prof_all = gen.handle.profile_read(-1)
     assert args.dbg or torch.isfinite(out).all()
 
+    res = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -162,7 +192,7 @@ def main():
                                     'procedural calibrated weights, no checkpoint ships with the reference)',
             'config': {'workload': f'SEAN generator forward only, batch {B}/GPU, {S}x{S}, ngf={ngf}, fp32 '
                                    f'(BASELINE.json configs[1])', 'global_batch': world * B, 'conv_path': args.path,
-                       'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of outputs' if world > 1 else '')},
+                       'parallelism': f'batch-sharded x{world}' + ((' + RCCL all-gather of outputs' + ('' if args.sync_gather else ' overlapped with the next step')) if dist is not None else '')},
             'roofline': {
                 'bound': 'mfma', 'kernel': kname,
                 'achieved': round(executed, 2), 'peak': peak, 'unit': 'TFLOP/s',
@@ -179,10 +209,17 @@ def main():
         }
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(ngf, S, sd)
-        print(json.dumps(res))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:                      # the ONE JSON line, after every library banner (RCCL prints its version through C stdio)
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':
