@@ -8,8 +8,8 @@
 //      4 x_k - sum_{n in N4(k), in image, n in U} x_n  =  base_k + sum_{n in N4(k), n in K} target_n
 //      base_k = (L source)_k  if mask_k != 0  else target_k,      (L s)_k = 4 s_k - sum_{n in N4(k), in image} s_n
 // Symmetric positive definite -> CG; all vectors in f64 (condition number ~ (2N/pi)^2 ~ 1e5 at 512 px: an f32 CG stalls at
-// ~1e-2 relative error, more than one uint8 level after the gamma power).  HBM/L2-bound streaming kernels, 3 launches per
-// iteration, scalars (alpha, beta, convergence flag) stay on the device.  Dot products are two-level and
+// ~1e-2 relative error, more than one uint8 level after the gamma power).  L2-resident streaming kernels, 2 launches per iteration
+// (Chronopoulos-Gear CG), scalars (alpha, beta, convergence) stay on the device.  Dot products are two-level and
 // deterministic: per-block partial sums, re-reduced in a fixed order by every block that needs the scalar (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,11 +17,6 @@
 #include "kernels.h"
 
 namespace chk {
-
-struct PoissonScalars {
-    double rs_old[3], rs0[3];
-    int done, iters;
-};
 
 // sum of v over the 256-thread block, returned to every thread (fixed order -> run-to-run deterministic)
 __device__ __forceinline__ double pb_block_sum(double v, double* sh) {
@@ -43,15 +38,14 @@ __device__ __forceinline__ bool pb_unknown(const uint8_t* m, int y, int x, int H
     return m[y * W + x] != 0 || y == 0 || x == 0 || y == H - 1 || x == W - 1;
 }
 
-// gamma transform, right-hand side, initial guess x0 = target, r0 = p0 = b - A x0, rs_old = r0.r0
+// gamma transform, right-hand side, initial guess x0 = target, r0 = b - A x0, p = s = 0
 __global__ __launch_bounds__(256) void pb_setup_kernel(const uint8_t* __restrict__ src, const uint8_t* __restrict__ tgt,
                                                        const uint8_t* __restrict__ mask, double* __restrict__ X,
                                                        double* __restrict__ R, double* __restrict__ P,
-                                                       double* __restrict__ T, uint8_t* __restrict__ U,
-                                                       double* __restrict__ partB, int H, int W, float inv_gamma) {
+                                                       double* __restrict__ S, uint8_t* __restrict__ U, int H, int W,
+                                                       float inv_gamma) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int HW = H * W;
-    double acc[3] = {0.0, 0.0, 0.0};
     if (k < HW) {
         const int y = k / W, x = k % W;
         const bool unk = pb_unknown(mask, y, x, H, W);
@@ -60,7 +54,6 @@ __global__ __launch_bounds__(256) void pb_setup_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double t = pow((double)tgt[k * 3 + c], (double)inv_gamma);
-            T[c * HW + k] = t;
             X[c * HW + k] = t;
             double r = 0.0;
             if (unk) {
@@ -81,121 +74,122 @@ __global__ __launch_bounds__(256) void pb_setup_kernel(const uint8_t* __restrict
                         r += pow((double)tgt[(ny[q] * W + nx[q]) * 3 + c], (double)inv_gamma);
             }
             R[c * HW + k] = r;
-            P[c * HW + k] = r;
-            acc[c] = r * r;
+            P[c * HW + k] = 0.0;
+            S[c * HW + k] = 0.0;
         }
     }
-    __shared__ double sh[4];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double t = pb_block_sum(acc[c], sh);
-        if (threadIdx.x == 0) partB[c * gridDim.x + blockIdx.x] = t;
-    }
 }
 
-__global__ void pb_init_scalars_kernel(PoissonScalars* sc) {
-    for (int c = 0; c < 3; ++c) sc->rs_old[c] = sc->rs0[c] = 0.0;
-    sc->done = 0;
-    sc->iters = 0;
+// ---- CG in the Chronopoulos-Gear form: one matvec and ONE fused pair of dot products per iteration, hence two kernel
+// launches per iteration (the solver is launch-bound: the vectors of a 512x512 image live in L2):
+//      w = A r,  gamma = r.r,  delta = r.w                                        (pb_matvec_kernel)
+//      beta = gamma / gamma_prev,  alpha = gamma / (delta - beta gamma / alpha_prev)   [beta = 0, alpha = gamma/delta at i = 0]
+//      p = r + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s              (pb_update_kernel)
+// Every block re-reduces the per-block partials in the same order, so all blocks agree bit for bit on the scalars and on
+// convergence (no flag race); the previous iteration's scalars sit in a ping-pong slot written by block 0.
+constexpr int PB_MAXBLK = 512;      // CG kernels: grid-stride over at most this many blocks (2 per CU)
+
+struct PoissonCG {
+    double gamma[2][3], alpha[2][3], gamma0[3];
+    int done, iters;
+};
+
+__global__ void pb_init_cg_kernel(PoissonCG* cg) {
+    for (int q = 0; q < 2; ++q)
+        for (int c = 0; c < 3; ++c) cg->gamma[q][c] = cg->alpha[q][c] = 0.0;
+    for (int c = 0; c < 3; ++c) cg->gamma0[c] = 0.0;
+    cg->done = 0;
+    cg->iters = 0;
 }
 
-// Ap = A p on the unknowns; partA[c][block] = partial p.Ap
-__global__ __launch_bounds__(256) void pb_matvec_kernel(const double* __restrict__ P, double* __restrict__ AP,
-                                                        const uint8_t* __restrict__ U, const PoissonScalars* sc,
-                                                        double* __restrict__ partA, int H, int W) {
-    if (sc->done) return;
+// w = A r on the unknowns; partG[c][block] = partial r.r, partD[c][block] = partial r.w
+__global__ __launch_bounds__(256) void pb_matvec_kernel(const double* __restrict__ R, double* __restrict__ Wv,
+                                                        const uint8_t* __restrict__ U, const PoissonCG* cg,
+                                                        double* __restrict__ partG, double* __restrict__ partD, int H, int W) {
+    if (cg->done) return;
     __shared__ double sh[4];
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int HW = H * W;
-    double acc[3] = {0.0, 0.0, 0.0};
-    if (k < HW && U[k]) {
+    double g[3] = {0.0, 0.0, 0.0}, d[3] = {0.0, 0.0, 0.0};
+    // grid-stride: at most PB_MAXBLK blocks, so that the per-block partials every block re-reduces stay a few KiB
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < HW; k += gridDim.x * blockDim.x) {
+        if (!U[k]) continue;
         const int y = k / W, x = k % W;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double* p = P + c * HW;
-            double v = 4.0 * p[k];
-            if (x + 1 < W && U[k + 1]) v -= p[k + 1];
-            if (x > 0 && U[k - 1]) v -= p[k - 1];
-            if (y + 1 < H && U[k + W]) v -= p[k + W];
-            if (y > 0 && U[k - W]) v -= p[k - W];
-            AP[c * HW + k] = v;
-            acc[c] = v * p[k];
+            const double* r = R + c * HW;
+            double v = 4.0 * r[k];
+            if (x + 1 < W && U[k + 1]) v -= r[k + 1];
+            if (x > 0 && U[k - 1]) v -= r[k - 1];
+            if (y + 1 < H && U[k + W]) v -= r[k + W];
+            if (y > 0 && U[k - W]) v -= r[k - W];
+            Wv[c * HW + k] = v;
+            g[c] += r[k] * r[k];
+            d[c] += r[k] * v;
         }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double t = pb_block_sum(acc[c], sh);
-        if (threadIdx.x == 0) partA[c * gridDim.x + blockIdx.x] = t;
+        const double tg = pb_block_sum(g[c], sh), td = pb_block_sum(d[c], sh);
+        if (threadIdx.x == 0) {
+            partG[c * gridDim.x + blockIdx.x] = tg;
+            partD[c * gridDim.x + blockIdx.x] = td;
+        }
     }
 }
 
-// x += alpha p; r -= alpha Ap (alpha = rs_old / sum(partA)); partB[c][block] = partial r.r
-__global__ __launch_bounds__(256) void pb_update_kernel(double* __restrict__ X, double* __restrict__ R,
-                                                        const double* __restrict__ P, const double* __restrict__ AP,
-                                                        const uint8_t* __restrict__ U, const PoissonScalars* sc,
-                                                        const double* __restrict__ partA, double* __restrict__ partB, int HW) {
-    if (sc->done) return;
+__global__ __launch_bounds__(256) void pb_update_kernel(double* __restrict__ X, double* __restrict__ R, double* __restrict__ P,
+                                                        double* __restrict__ S, const double* __restrict__ Wv,
+                                                        const uint8_t* __restrict__ U, PoissonCG* cg,
+                                                        const double* __restrict__ partG, const double* __restrict__ partD,
+                                                        int HW, int iter, double rel_tol2) {
+    if (cg->done) return;
     __shared__ double sh[4];
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    double alpha[3];
+    const int q = iter & 1;
+    double alpha[3], beta[3], gam[3];
+    bool live[3], any = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double pap = pb_total(partA + c * gridDim.x, gridDim.x, sh);
-        alpha[c] = pap > 0.0 ? sc->rs_old[c] / pap : 0.0;
+        gam[c] = pb_total(partG + c * gridDim.x, gridDim.x, sh);
+        const double del = pb_total(partD + c * gridDim.x, gridDim.x, sh);
+        const double g0 = iter == 0 ? gam[c] : cg->gamma0[c];
+        live[c] = gam[c] > rel_tol2 * g0 && gam[c] > 1e-24;      // channel not yet converged
+        if (iter == 0) {
+            beta[c] = 0.0;
+            alpha[c] = del > 0.0 ? gam[c] / del : 0.0;
+        } else {
+            const double gp = cg->gamma[q ^ 1][c], ap = cg->alpha[q ^ 1][c];
+            beta[c] = gp > 0.0 ? gam[c] / gp : 0.0;
+            const double den = del - (ap != 0.0 ? beta[c] * gam[c] / ap : 0.0);
+            alpha[c] = den > 0.0 ? gam[c] / den : 0.0;
+        }
+        if (!live[c]) alpha[c] = beta[c] = 0.0;
+        any = any || live[c];
     }
-    double acc[3] = {0.0, 0.0, 0.0};
-    if (k < HW && U[k]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                     // bookkeeping for the next iteration / the host
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            X[c * HW + k] += alpha[c] * P[c * HW + k];
-            const double r = R[c * HW + k] - alpha[c] * AP[c * HW + k];
-            R[c * HW + k] = r;
-            acc[c] = r * r;
+            cg->gamma[q][c] = live[c] ? gam[c] : cg->gamma[q ^ 1][c];
+            cg->alpha[q][c] = live[c] ? alpha[c] : cg->alpha[q ^ 1][c];
+            if (iter == 0) cg->gamma0[c] = gam[c];
+        }
+        if (any) cg->iters = iter + 1;
+        else cg->done = 1;
+    }
+    if (!any) return;                                              // same decision in every block
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < HW; k += gridDim.x * blockDim.x) {
+        if (!U[k]) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (!live[c]) continue;                                // a converged channel keeps its solution
+            const int i = c * HW + k;
+            const double p = R[i] + beta[c] * P[i];
+            const double s = Wv[i] + beta[c] * S[i];
+            P[i] = p;
+            S[i] = s;
+            X[i] += alpha[c] * p;
+            R[i] -= alpha[c] * s;
         }
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double t = pb_block_sum(acc[c], sh);
-        if (threadIdx.x == 0) partB[c * gridDim.x + blockIdx.x] = t;
-    }
-}
-
-// p = r + beta p (beta = sum(partB) / rs_old)
-__global__ __launch_bounds__(256) void pb_direction_kernel(double* __restrict__ P, const double* __restrict__ R,
-                                                           const uint8_t* __restrict__ U, const PoissonScalars* sc,
-                                                           const double* __restrict__ partB, int HW) {
-    if (sc->done) return;
-    __shared__ double sh[4];
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    double beta[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double rs_new = pb_total(partB + c * gridDim.x, gridDim.x, sh);
-        beta[c] = sc->rs_old[c] > 0.0 ? rs_new / sc->rs_old[c] : 0.0;
-    }
-    if (k < HW && U[k]) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) P[c * HW + k] = R[c * HW + k] + beta[c] * P[c * HW + k];
-    }
-}
-
-// one block, between iterations: rs_old <- sum(partB) (= r.r after the update), convergence test ||r||^2 <= tol^2 ||r0||^2
-__global__ __launch_bounds__(256) void pb_roll_kernel(PoissonScalars* sc, const double* __restrict__ partB, int nblocks,
-                                                      double rel_tol2, int first) {
-    if (sc->done) return;
-    __shared__ double sh[4];
-    double rs[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rs[c] = pb_total(partB + c * nblocks, nblocks, sh);
-    if (threadIdx.x != 0) return;
-    bool conv = true;
-    for (int c = 0; c < 3; ++c) {
-        sc->rs_old[c] = rs[c];
-        if (first) sc->rs0[c] = rs[c];
-        if (rs[c] > rel_tol2 * sc->rs0[c] && rs[c] > 1e-24) conv = false;
-    }
-    if (!first) sc->iters += 1;
-    if (conv) sc->done = 1;
 }
 
 // out = clamp(x^gamma) truncated to uint8 (poisson_blending.py:81-86); NaN (negative base) -> 0
@@ -213,32 +207,28 @@ __global__ void pb_finish_kernel(const double* __restrict__ X, uint8_t* __restri
 
 size_t poisson_workspace_bytes(int H, int W) {
     const size_t HW = (size_t)H * W;
-    const size_t nb = (HW + 255) / 256;
-    return 5 * 3 * HW * sizeof(double) + 2 * 3 * nb * sizeof(double) + HW + 512 + sizeof(PoissonScalars);
+    return 5 * 3 * HW * sizeof(double) + 2 * 3 * PB_MAXBLK * sizeof(double) + HW + 512 + sizeof(PoissonCG);
 }
 
 hipError_t poisson_blend(const uint8_t* src, const uint8_t* tgt, const uint8_t* mask, uint8_t* out, int H, int W,
                          int with_gamma, int max_iters, double rel_tol, void* ws, int* iters_out, hipStream_t s) {
     const int HW = H * W;
     double* X = static_cast<double*>(ws);
-    double *R = X + 3 * (size_t)HW, *P = R + 3 * (size_t)HW, *AP = P + 3 * (size_t)HW, *T = AP + 3 * (size_t)HW;
-    const int nb = (HW + 255) / 256;
-    double *partA = T + 3 * (size_t)HW, *partB = partA + 3 * (size_t)nb;
-    uint8_t* U = reinterpret_cast<uint8_t*>(partB + 3 * (size_t)nb);
-    PoissonScalars* sc = reinterpret_cast<PoissonScalars*>(U + (((size_t)HW + 255) / 256) * 256);
+    double *R = X + 3 * (size_t)HW, *P = R + 3 * (size_t)HW, *S = P + 3 * (size_t)HW, *Wv = S + 3 * (size_t)HW;
+    const int nb = (HW + 255) / 256, ncg = nb < PB_MAXBLK ? nb : PB_MAXBLK;
+    double *partG = Wv + 3 * (size_t)HW, *partD = partG + 3 * (size_t)PB_MAXBLK;
+    uint8_t* U = reinterpret_cast<uint8_t*>(partD + 3 * (size_t)PB_MAXBLK);
+    PoissonCG* cg = reinterpret_cast<PoissonCG*>(U + (((size_t)HW + 255) / 256) * 256);
     const float gamma = with_gamma ? 2.2f : 1.0f;
-    const dim3 g(nb), b(256);
-    hipLaunchKernelGGL(pb_init_scalars_kernel, dim3(1), dim3(1), 0, s, sc);
-    hipLaunchKernelGGL(pb_setup_kernel, g, b, 0, s, src, tgt, mask, X, R, P, T, U, partB, H, W, 1.0f / gamma);
-    hipLaunchKernelGGL(pb_roll_kernel, dim3(1), b, 0, s, sc, partB, nb, rel_tol * rel_tol, 1);
+    const dim3 g(nb), gc(ncg), b(256);
+    hipLaunchKernelGGL(pb_init_cg_kernel, dim3(1), dim3(1), 0, s, cg);
+    hipLaunchKernelGGL(pb_setup_kernel, g, b, 0, s, src, tgt, mask, X, R, P, S, U, H, W, 1.0f / gamma);
     int done = 0;
     for (int it = 0; it < max_iters && !done; ++it) {
-        hipLaunchKernelGGL(pb_matvec_kernel, g, b, 0, s, P, AP, U, sc, partA, H, W);
-        hipLaunchKernelGGL(pb_update_kernel, g, b, 0, s, X, R, P, AP, U, sc, partA, partB, HW);
-        hipLaunchKernelGGL(pb_direction_kernel, g, b, 0, s, P, R, U, sc, partB, HW);
-        hipLaunchKernelGGL(pb_roll_kernel, dim3(1), b, 0, s, sc, partB, nb, rel_tol * rel_tol, 0);
+        hipLaunchKernelGGL(pb_matvec_kernel, gc, b, 0, s, R, Wv, U, cg, partG, partD, H, W);
+        hipLaunchKernelGGL(pb_update_kernel, gc, b, 0, s, X, R, P, S, Wv, U, cg, partG, partD, HW, it, rel_tol * rel_tol);
         if ((it & 63) == 63) {        // poll the device flag every 64 iterations (converged runs stop launching)
-            hipError_t e = hipMemcpyAsync(&done, &sc->done, sizeof(int), hipMemcpyDeviceToHost, s);
+            hipError_t e = hipMemcpyAsync(&done, &cg->done, sizeof(int), hipMemcpyDeviceToHost, s);
             if (e != hipSuccess) return e;
             e = hipStreamSynchronize(s);
             if (e != hipSuccess) return e;
@@ -246,7 +236,7 @@ hipError_t poisson_blend(const uint8_t* src, const uint8_t* tgt, const uint8_t* 
     }
     hipLaunchKernelGGL(pb_finish_kernel, g, b, 0, s, X, out, HW, gamma);
     if (iters_out) {
-        hipError_t e = hipMemcpyAsync(iters_out, &sc->iters, sizeof(int), hipMemcpyDeviceToHost, s);
+        hipError_t e = hipMemcpyAsync(iters_out, &cg->iters, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return e;

@@ -139,7 +139,7 @@ int  ch_bisenet_parse(ch_handle* h, const float* img, uint8_t* labels, float* lo
  *   target_parsing, face_parsing, out: uint8 [H,W] device pointers (CelebAMask-HQ ids in, 0/1 out).
  * ch_poisson_blend replaces poisson_blending.poisson_blending (poisson_blending.py:29-87): same linear system (5-point
  *   Laplacian incl. the reference's border rows, identity rows for interior pixels with mask == 0), same gamma-2.2 round
- *   trip and uint8 truncation, solved matrix-free by conjugate gradients in f64 instead of three sparse direct solves.
+ *   trip and uint8 truncation, solved matrix-free by conjugate gradients (Chronopoulos-Gear form, f64) instead of three sparse direct solves.
  *   source, target, out: uint8 [H,W,3] (cv2 layout); mask uint8 [H,W], non-zero = keep the SOURCE gradients (solve), zero =
  *   keep the target pixel; H, W >= 3.  Stops when ||r|| <= rel_tol * ||r0|| per channel or after max_iters iterations
  *   (recommended 1e-7 / 4000); *iters (host pointer, optional) receives the iteration count.  Output agrees with the
