@@ -59,8 +59,119 @@ __global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x
     }
     for (int i = threadIdx.x; i < HW; i += 256) p[i] = act_fn((p[i] - mean) * rstd, act);
 }
+
+// Large planes (Zencoder at 256^2 / 512^2: one plane = 0.25-1 MB, there are only B*C = 256-2048 of them): 1024 threads per
+// plane and float4 accesses put 16x more bytes in flight per plane than the kernel above, which is what a one-block-per-plane
+// reduction needs to approach HBM speed; passes 2 and 3 re-read the plane from L2.
+__device__ __forceinline__ float block_sum1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void instnorm_act_wide_kernel(float* __restrict__ x, int HW, float eps, int act,
+                                                                 _Float16* __restrict__ sh16, int C) {
+    __shared__ float red[16];
+    float4* p4 = reinterpret_cast<float4*>(x + (long long)blockIdx.x * HW);
+    const int n4 = HW >> 2;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = p4[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = block_sum1024(s, red) / HW;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = p4[i];
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float var = block_sum1024(q, red) / HW;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (sh16) {
+        const int b = blockIdx.x / C, c = blockIdx.x % C;
+        _Float16* oh = sh16 + ((((long long)b * (C >> 3) + (c >> 3)) * 2) * HW) * 8 + (c & 7);
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const float4 v4 = p4[i];
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = act_fn((vv[e] - mean) * rstd, act);
+                const _Float16 h = (_Float16)v;
+                oh[(long long)(i * 4 + e) * 8] = h;
+                oh[((long long)HW + i * 4 + e) * 8] = (_Float16)(v - (float)h);
+            }
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        float4 v = p4[i];
+        v.x = act_fn((v.x - mean) * rstd, act); v.y = act_fn((v.y - mean) * rstd, act);
+        v.z = act_fn((v.z - mean) * rstd, act); v.w = act_fn((v.w - mean) * rstd, act);
+        p4[i] = v;
+    }
+}
+
+// SH16 output (feeds the f16x3 conv): one block per (sample, group of 8 channels) so that every lane writes whole 16-byte
+// units (8 channels of one pixel, hi plane and lo plane) instead of 2-byte elements 16 bytes apart from 8 different blocks.
+__global__ __launch_bounds__(1024) void instnorm_act_sh16_kernel(const float* __restrict__ x, int HW, float eps, int act,
+                                                                 uint4* __restrict__ sh16, int C) {
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    __shared__ float red[16];
+    __shared__ float mean_s[8], rstd_s[8];
+    const int G = C >> 3, b = blockIdx.x / G, g = blockIdx.x % G;
+    const float* base = x + ((long long)b * C + g * 8) * HW;
+    const int n4 = HW >> 2;
+    for (int c = 0; c < 8; ++c) {
+        const float4* p4 = reinterpret_cast<const float4*>(base + (long long)c * HW);
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const float4 v = p4[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        const float mean = block_sum1024(s, red) / HW;
+        float q = 0.f;
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const float4 v = p4[i];
+            const float a = v.x - mean, bb = v.y - mean, cc = v.z - mean, d = v.w - mean;
+            q += (a * a + bb * bb) + (cc * cc + d * d);
+        }
+        const float var = block_sum1024(q, red) / HW;
+        if (threadIdx.x == 0) {
+            mean_s[c] = mean;
+            rstd_s[c] = 1.f / sqrtf(var + eps);
+        }
+    }
+    __syncthreads();
+    uint4* oh = sh16 + ((long long)b * G + g) * 2 * HW;
+    for (int i = threadIdx.x; i < HW; i += 1024) {
+        half8v vh, vl;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = act_fn((base[(long long)c * HW + i] - mean_s[c]) * rstd_s[c], act);
+            const _Float16 h = (_Float16)v;
+            vh[c] = h;
+            vl[c] = (_Float16)(v - (float)h);
+        }
+        oh[i] = __builtin_bit_cast(uint4, vh);
+        oh[HW + i] = __builtin_bit_cast(uint4, vl);
+    }
+}
+
 hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16, int C) {
-    hipLaunchKernelGGL(instnorm_act_kernel, dim3(planes), dim3(256), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C);
+    if (sh16 && (C & 7) == 0 && (HW & 3) == 0 && HW >= 4096) {
+        hipLaunchKernelGGL(instnorm_act_sh16_kernel, dim3(planes / 8), dim3(1024), 0, s, x, HW, eps, act, static_cast<uint4*>(sh16), C);
+        return hipGetLastError();
+    }
+    if (HW >= 16384 && (HW & 3) == 0)
+        hipLaunchKernelGGL(instnorm_act_wide_kernel, dim3(planes), dim3(1024), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C);
+    else
+        hipLaunchKernelGGL(instnorm_act_kernel, dim3(planes), dim3(256), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C);
     return hipGetLastError();
 }
 
