@@ -290,6 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const uint4* gin = reinterpret_cast<const uint4*>(p.in);
+    // physical plane size of the input: ConvTranspose2d(k3,s2,p1,op1) runs as a conv over the zero-inserted x2 view
+    const int HWi = p.in_mode == IN_UP2_ZEROINS ? (p.H >> 1) * (p.W >> 1) : HW;
     // per-thread source offsets of its NLOAD patch units (chunk-invariant part), -1 = outside the image -> zeros.
     // Hoisted out of the chunk loop: the decode (3 div/mod per unit) was ~half of the kernel's VALU issue.
     int soff[NLOAD];
@@ -306,8 +308,13 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
                 y = y < 0 ? -y : (y >= p.H ? 2 * (p.H - 1) - y : y);
                 x = x < 0 ? -x : (x >= p.W ? 2 * (p.W - 1) - x : x);
             }
-            if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
+            if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                if (p.in_mode == IN_UP2_ZEROINS) {   // logical input = physical input with zeros between the samples
+                    if (!((y | x) & 1)) soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HWi + (y >> 1) * (p.W >> 1) + (x >> 1);
+                } else {
+                    soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
+                }
+            }
             if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
         }
     }
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         // No scheduling fence in here on purpose: the compiler issues these loads early and sinks the LDS writes
         // below the chunk's MFMAs as far as registers allow, which is what overlaps staging with compute.
         uint4 stg[NLOAD];
-        const uint4* src = gin + (long long)chunk * 4 * HW;       // 2 groups x (hi, lo) planes per chunk
+        const uint4* src = gin + (long long)chunk * 4 * HWi;      // 2 groups x (hi, lo) planes per chunk
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
         uint4* dst = smem_u + buf * UNITS;
@@ -767,6 +774,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
 template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
 hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
+    if (p.in_mode != IN_DIRECT) return hipErrorInvalidValue;     // input views are implemented in conv_sh16_kernel only
     auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;

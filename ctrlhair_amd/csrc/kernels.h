@@ -18,6 +18,7 @@ hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hi
 hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s);
 // misc_kernels.hip
 hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16 = nullptr, int C = 0);
+hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s);
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
                          int act, hipStream_t s);
 hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B, int F, int h, int w, int S,

@@ -163,6 +163,67 @@ __global__ __launch_bounds__(1024) void instnorm_act_sh16_kernel(const float* __
     }
 }
 
+// Same, input in the C4 layout [B][C/4][HW][4] (output of an f16x3 conv): a block's 8 channels are two float4 per pixel.
+__global__ __launch_bounds__(1024) void instnorm_c4_sh16_kernel(const float4* __restrict__ x, int HW, float eps, int act,
+                                                                uint4* __restrict__ sh16, int C) {
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    __shared__ float red[16];
+    __shared__ float mean_s[8], rstd_s[8];
+    const int G = C >> 3, b = blockIdx.x / G, g = blockIdx.x % G;
+    const float4* p0 = x + ((long long)b * (C >> 2) + g * 2) * HW;
+    const float4* p1 = p0 + HW;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < HW; i += 1024) {
+        const float4 a = p0[i], c = p1[i];
+        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+        s[4] += c.x; s[5] += c.y; s[6] += c.z; s[7] += c.w;
+    }
+    float mean[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mean[c] = block_sum1024(s[c], red) / HW;
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < HW; i += 1024) {
+        const float4 a = p0[i], c = p1[i];
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = v[e] - mean[e];
+            q[e] += d * d;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float var = block_sum1024(q[c], red) / HW;
+        if (threadIdx.x == 0) {
+            mean_s[c] = mean[c];
+            rstd_s[c] = 1.f / sqrtf(var + eps);
+        }
+    }
+    __syncthreads();
+    uint4* oh = sh16 + ((long long)b * G + g) * 2 * HW;
+    for (int i = threadIdx.x; i < HW; i += 1024) {
+        const float4 a = p0[i], c = p1[i];
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        half8v vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float o = act_fn((v[e] - mean_s[e]) * rstd_s[e], act);
+            const _Float16 h = (_Float16)o;
+            vh[e] = h;
+            vl[e] = (_Float16)(o - (float)h);
+        }
+        oh[i] = __builtin_bit_cast(uint4, vh);
+        oh[HW + i] = __builtin_bit_cast(uint4, vl);
+    }
+}
+
+hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s) {
+    if (C & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(instnorm_c4_sh16_kernel, dim3(B * (C >> 3)), dim3(1024), 0, s, reinterpret_cast<const float4*>(x_c4), HW,
+                       eps, act, static_cast<uint4*>(sh16), C);
+    return hipGetLastError();
+}
+
 hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16, int C) {
     if (sh16 && (C & 7) == 0 && (HW & 3) == 0 && HW >= 4096) {
         hipLaunchKernelGGL(instnorm_act_sh16_kernel, dim3(planes / 8), dim3(1024), 0, s, x, HW, eps, act, static_cast<uint4*>(sh16), C);

@@ -246,6 +246,10 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
             const float* wp = w14.data();
             z14_sh = B.upload(pack_A_sh16(512, 256, 3, [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; }));
+            // the ConvTranspose too (a 3x3 conv over the zero-inserted view, flipped taps as above)
+            auto wt10 = B.vec("Zencoder.model.10.weight", (size_t)128 * 256 * 9);
+            const float* w10 = wt10.data();
+            z10_sh = B.upload(pack_A_sh16(256, 128, 3, [&](int row, int ci, int t) { return w10[((size_t)ci * 256 + row) * 9 + (8 - t)]; }));
         }
         if (!B.err.empty()) return B.err;
         has_zencoder = true;
@@ -596,11 +600,30 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         ck(run_conv(z4, hs, dx, B, S, S, zero, st), "zenc conv2");
         ck(instnorm_act(dx, B * 64, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in2");
         ck(run_conv(z7, dx, h1, B, h2, h2, zero, st), "zenc conv3");
-        ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
-        ck(run_conv(z10, h1, hs, B, h4, h4, zins, st), "zenc convT");
+        if (use_sh16 && h4 * h4 >= 4096) {
+            // InstanceNorm + lrelu -> SH16 -> ConvTranspose as an f16x3 conv over the zero-inserted view -> C4 ->
+            // InstanceNorm + lrelu -> SH16 -> f16x3 conv (reflection pad, tanh) -> C4
+            ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st, dx, 128), "zenc in3");
+            ConvParams t{};
+            t.in = dx;
+            t.wpk = z10_sh;
+            t.out = hs;
+            t.B = B;
+            t.Cin = 128;
+            t.H = h2;
+            t.W = h2;
+            t.Mrows = 256;
+            t.bias = z10.bias;
+            t.act = ACT_NONE;
+            t.in_mode = IN_UP2_ZEROINS;
+            ck(conv_sh16_plain(t, 3, st), "zenc convT (f16x3)");
+            ck(instnorm_c4_to_sh16(hs, B, 256, h2 * h2, 1e-5f, ACT_LRELU, h1, st), "zenc in4");
+        } else {
+            ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
+            ck(run_conv(z10, h1, hs, B, h4, h4, zins, st), "zenc convT");
+            if (use_sh16) ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st, h1, 256), "zenc in4");
+        }
         if (use_sh16) {
-            // InstanceNorm + lrelu written straight into the SH16 layout -> f16x3 conv (reflection pad, tanh) -> C4
-            ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st, h1, 256), "zenc in4");
             ConvParams p{};
             p.in = h1;
             p.wpk = z14_sh;

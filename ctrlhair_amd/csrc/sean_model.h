@@ -57,7 +57,7 @@ struct SeanModel {
     float *img_w = nullptr, *img_b = nullptr;          // conv_img raw [3][ngf][3][3]
     bool has_zencoder = false;
     ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
-    float* z14_sh = nullptr;                           // z14 packed for the f16x3 kernel
+    float *z14_sh = nullptr, *z10_sh = nullptr;        // z14 / the ConvTranspose packed for the f16x3 kernel
     std::vector<void*> allocs;                         // everything to hipFree
     // workspace
     uint8_t* lab_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // res_div 32,16,8,4,2 (index by log2) ; [0] unused
