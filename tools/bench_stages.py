@@ -46,7 +46,7 @@ def main():
     out = {'device': torch.cuda.get_device_name(0), 'batch': B, 'size': S, 'unit': 'ms per batch'}
 
     out['zencoder_f32'] = timeit(lambda: m.generator.encode(img, lab512))
-    out['zencoder_f16x3_last_conv'] = timeit(lambda: gen16.encode(img, lab512))
+    out['zencoder_f16x3_ms'] = timeit(lambda: gen16.encode(img, lab512))
     out['bisenet_f32'] = timeit(lambda: m.face_parsing.parse_tensor(img))
     out['shape_encode_f32'] = timeit(lambda: m.mask_generator.encode_labels(lab256))
     hc, fc = m.mask_generator.encode_labels(lab256)
