@@ -28,6 +28,8 @@ hipError_t global_avg_pool(const float* in, float* out, int planes, int HW, hipS
 hipError_t chan_affine(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,
                        long long planes, int HW, hipStream_t s);
 hipError_t stem7x7(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+hipError_t conv3x3_c3_reflect(const float* in, const float* w, const float* bias, float* out, int B, int Cout, int H, int W,
+                              hipStream_t s);
 hipError_t bilinear_argmax(const float* lg, uint8_t* out, float* logits_out, const uint8_t* remap, int B, int h, int w,
                            int H, int W, hipStream_t s);
 hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW, hipStream_t s);

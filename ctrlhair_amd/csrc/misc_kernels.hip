@@ -334,8 +334,59 @@ __global__ __launch_bounds__(256) void region_mean_kernel(const float* __restric
         if (threadIdx.x == 0) out[((long long)b * 19 + j) * F + f] = cv > 0.f ? sv / cv : 0.f;
     }
 }
+// C4 input [B][F/4][h*w][4]: one block per (4-channel group, sample), float4 loads.  A thread walks down a column-ish
+// sequence of pixels (stride 256), where labels change rarely: it keeps a running (label, sum4, count) and flushes it to the
+// per-label LDS accumulators only when the label changes.  (LDS float atomics: the summation order, hence the last bits of a
+// code, can differ from run to run -- ~1e-7 relative, far inside the 1e-3 bar.)
+__global__ __launch_bounds__(256) void region_mean_c4_kernel(const float4* __restrict__ codes, const uint8_t* __restrict__ lab,
+                                                             float* __restrict__ out, int F, int h, int w, int S) {
+    __shared__ float acc[19][4];
+    __shared__ float cnt[19];
+    const int fg = blockIdx.x, b = blockIdx.y;
+    if (threadIdx.x < 19 * 4) acc[threadIdx.x >> 2][threadIdx.x & 3] = 0.f;
+    if (threadIdx.x < 19) cnt[threadIdx.x] = 0.f;
+    __syncthreads();
+    const float4* p = codes + ((long long)b * (F >> 2) + fg) * h * w;
+    const uint8_t* lb = lab + (long long)b * S * S;
+    const int fy = S / h, fx = S / w;
+    int cur = -1;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float n = 0.f;
+    auto flush = [&]() {
+        if (cur >= 0 && cur < 19) {
+            atomicAdd(&acc[cur][0], sum.x); atomicAdd(&acc[cur][1], sum.y);
+            atomicAdd(&acc[cur][2], sum.z); atomicAdd(&acc[cur][3], sum.w);
+            atomicAdd(&cnt[cur], n);
+        }
+    };
+    for (int i = threadIdx.x; i < h * w; i += 256) {
+        const int y = i / w, x = i % w;
+        const int l = lb[(long long)(y * fy) * S + x * fx];
+        const float4 v = p[i];
+        if (l != cur) {
+            flush();
+            cur = l;
+            sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            n = 0.f;
+        }
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        n += 1.f;
+    }
+    flush();
+    __syncthreads();
+    if (threadIdx.x < 19 * 4) {
+        const int j = threadIdx.x >> 2, c = threadIdx.x & 3;
+        out[((long long)b * 19 + j) * F + fg * 4 + c] = cnt[j] > 0.f ? acc[j][c] / cnt[j] : 0.f;
+    }
+}
+
 hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B, int F, int h, int w, int S,
                        hipStream_t s, int c4) {
+    if (c4 && (F & 3) == 0) {
+        hipLaunchKernelGGL(region_mean_c4_kernel, dim3(F >> 2, B), dim3(256), 0, s, reinterpret_cast<const float4*>(codes), lab,
+                           out, F, h, w, S);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(region_mean_kernel, dim3(F, B), dim3(256), 0, s, codes, lab, out, F, h, w, S, c4);
     return hipGetLastError();
 }
@@ -448,6 +499,44 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ 
         }
     }
 }
+// ReflectionPad2d(1) + Conv2d(3, Cout, 3) (Zencoder stem, architecture.py:158-160): three input channels are far too few
+// for the matrix cores (the MFMA kernel pads K from 27 to 144); direct VALU conv, one pixel per thread, the 27 inputs in
+// registers, weights through wave-uniform (scalar) loads.  HBM-write bound (Cout planes out, 3 planes in).
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_c3_reflect_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int B, int H, int W) {
+    const long long HW = (long long)H * W;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= B * HW) return;
+    const int b = (int)(i / HW), y = (int)((i % HW) / W), x = (int)(i % W);
+    float v[27];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+        xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c * 9 + t] = in[((long long)b * 3 + c) * HW + (long long)yy * W + xx];
+    }
+    float* o = out + (long long)b * COUT * HW + (long long)y * W + x;
+#pragma unroll 4
+    for (int k = 0; k < COUT; ++k) {
+        float a = bias[k];
+#pragma unroll
+        for (int j = 0; j < 27; ++j) a += w[k * 27 + j] * v[j];
+        o[(long long)k * HW] = a;
+    }
+}
+
+hipError_t conv3x3_c3_reflect(const float* in, const float* w, const float* bias, float* out, int B, int Cout, int H, int W,
+                              hipStream_t s) {
+    if (Cout != 32) return hipErrorInvalidValue;
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(conv3x3_c3_reflect_kernel<32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, w, bias, out, B, H, W);
+    return hipGetLastError();
+}
+
 hipError_t stem7x7(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     hipLaunchKernelGGL(stem7x7_kernel, dim3((Wo + 15) / 16, (Ho + 15) / 16, B), dim3(256), 0, s, in, w, bias, out, H, W,

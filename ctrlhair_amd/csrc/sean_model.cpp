@@ -230,6 +230,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             L = make_conv(B, B.vec(p + ".weight", (size_t)cout * cin * 9), B.vec(p + ".bias", cout), cout, cin, 3, stride, 1);
         };
         plain("Zencoder.model.1", 32, 3, 1, z1);
+        z1_w = B.upload(B.vec("Zencoder.model.1.weight", (size_t)32 * 3 * 9));      // raw [32][3][3][3] for the direct stem conv
         plain("Zencoder.model.4", 64, 32, 2, z4);
         plain("Zencoder.model.7", 128, 64, 2, z7);
         {   // ConvTranspose2d(128,256,k3,s2,p1,op1): weight [in=128][out=256][3][3] -> plain conv over the
@@ -595,7 +596,7 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         ConvOpts last = refl;
         last.act = ACT_TANH;
         const int h2 = S / 2, h4 = S / 4;
-        ck(run_conv(z1, x, hs, B, S, S, refl, st), "zenc conv1");
+        ck(conv3x3_c3_reflect(x, z1_w, z1.bias, hs, B, 32, S, S, st), "zenc conv1");
         ck(instnorm_act(hs, B * 32, S * S, 1e-5f, ACT_LRELU, st), "zenc in1");
         ck(run_conv(z4, hs, dx, B, S, S, zero, st), "zenc conv2");
         ck(instnorm_act(dx, B * 64, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in2");

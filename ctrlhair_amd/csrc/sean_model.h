@@ -56,6 +56,7 @@ struct SeanModel {
     float *fc_table = nullptr, *fc_bias = nullptr;     // fc conv as label LUT [19*9][16ngf]
     float *img_w = nullptr, *img_b = nullptr;          // conv_img raw [3][ngf][3][3]
     bool has_zencoder = false;
+    float* z1_w = nullptr;                             // Zencoder stem weights, unpacked (direct VALU conv)
     ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
     float *z14_sh = nullptr, *z10_sh = nullptr;        // z14 / the ConvTranspose packed for the f16x3 kernel
     std::vector<void*> allocs;                         // everything to hipFree
