@@ -408,6 +408,8 @@ struct Runner {
                 p.pad = -1;
                 p.act = ACT_NONE;
                 p.terms = m.terms;
+                p.partial = m.splitk_ws;           // K = 512 in 32 chunks on few tiles (C <= 512): split-K fills the chip
+                p.partial_cap = m.splitk_cap;
                 timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
                       [&] { check(conv_sh16_plain(p, 1, st), "lut gemm"); });
                 lut_rs = npad;
