@@ -41,11 +41,13 @@ from .checkpoints import reference_checkpoints      # noqa: E402,F401  (referenc
 class HipModels:
     """Builds every network of the path on one ch_handle (one GPU)."""
 
-    def __init__(self, weights: Dict[str, dict], device: int = 0, img_size: int = 256, max_batch: int = 1):
+    def __init__(self, weights: Dict[str, dict], device: int = 0, img_size: int = 256, max_batch: int = 1, f16x3=True):
+        """f16x3: arithmetic of the SEAN generator / Zencoder convs (see SeanGenerator): True = split-operand f16 MFMA,
+        f32-class results (default); False = exact-f32 MFMA; 2 = single-term f16 (reduced precision)."""
         from .models import ColorTextureModels, FaceParsing, ShapeGenerator
         from .sean.generator import SeanGenerator
         from .sean.pix2pix_model import Pix2PixModel
-        self.generator = SeanGenerator(device).load_state_dict(weights['sean'], max_batch=max_batch, max_size=img_size)
+        self.generator = SeanGenerator(device, f16x3=f16x3).load_state_dict(weights['sean'], max_batch=max_batch, max_size=img_size)
         h, dev = self.generator.handle, self.generator.device
         self.device = dev
         self.sean_model = Pix2PixModel(self.generator)
@@ -61,7 +63,7 @@ class HairEditor:
     """This is the basic module (hair_editor.py:40-43); ctrlhair_amd.ui.backend.Backend succeeds this class."""
 
     def __init__(self, load_feature_model=True, load_mask_model=True, *, weights='procedural', device: int = 0,
-                 img_size: int = 256, models=None, texture_dirs=None, shape_dirs=None, max_batch: int = 1):
+                 img_size: int = 256, models=None, texture_dirs=None, shape_dirs=None, max_batch: int = 1, f16x3=True):
         if models is None:
             if weights == 'procedural':
                 weights = procedural_weights()
@@ -72,7 +74,7 @@ class HairEditor:
                     texture_dirs = weights['texture_dirs']          # hair_editor.py:82-91
                 if shape_dirs is None and weights.get('shape_dirs'):
                     shape_dirs = weights['shape_dirs']              # hair_editor.py:110-119
-            models = HipModels(weights, device=device, img_size=img_size, max_batch=max_batch)
+            models = HipModels(weights, device=device, img_size=img_size, max_batch=max_batch, f16x3=f16x3)
         self.models = models
         self.sean_model = models.sean_model
         self.img_size = img_size                     # hair_editor.py:50 (256 in the reference)

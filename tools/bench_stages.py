@@ -35,7 +35,7 @@ def main():
     B, S = 8, 512
     dev = torch.device('cuda', 0)
     w = procedural_weights(0, 64)
-    m = HipModels(w, device=0, img_size=S, max_batch=B)          # exact-f32 SEAN path
+    m = HipModels(w, device=0, img_size=S, max_batch=B, f16x3=False)          # exact-f32 SEAN path
     from ctrlhair_amd.sean.generator import SeanGenerator
     gen16 = SeanGenerator(0, f16x3=1).load_state_dict(w['sean'], max_batch=B, max_size=S)
     img = torch.from_numpy(P.synthetic_images(B, S)).to(dev)
