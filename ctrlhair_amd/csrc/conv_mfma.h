@@ -76,6 +76,11 @@ struct ConvParams {
     const float* wpk2;      //   into the same accumulators (ResBlock shortcut conv_s folded into conv_1); null = none
     int Cin2;
     int terms;              // f16 MFMA path: 0/3 = three-term split operands (f32-class), 1 = hi halves only (f16 operands)
+    // f16 MFMA path scaling (sh16.h): accumulators hold sum (w * 2^k[row]) * (x * s_in); the epilogue multiplies them by
+    // wscale[row] * in_scale_inv = 2^-k[row] / s_in (exact powers of two) and writes SH16 outputs multiplied by out_scale
+    const float* wscale;    // [GEMM rows] 2^-k per packed weight row (null = 1)
+    float in_scale_inv;     // 1 / (scale of the SH16 input tensor(s)); 0 = 1
+    float out_scale;        // EPI_ACE: scale of the SH16 output tensor; 0 = 1
     int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over the persistent kernel)
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
     // EPI_NHWC
@@ -314,8 +319,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 for (int t = 0; t < 9; ++t) {
                     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
                     const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                    const int j = lb[in ? yy * p.W + xx : 0];
-                    const float w = in ? 1.f : 0.f;
+                    const int j0 = lb[in ? yy * p.W + xx : 0];
+                    const int j = j0 < 19 ? j0 : 0;                      // labels >= 19 ("no class"): no style term
+                    const float w = (in && j0 < 19) ? 1.f : 0.f;
                     const float* Lp = p.lut + ((long long)(b * 19 + j) * 9 + t) * (2 * C);
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {

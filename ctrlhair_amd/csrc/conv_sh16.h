@@ -19,6 +19,7 @@
 // block tile 64 rows x 512 px; 8 f32 accumulators (32x32) per wave; 24 MFMAs per k-step per wave.
 #pragma once
 #include "conv_mfma.h"
+#include "sh16.h"
 
 namespace chk {
 
@@ -42,11 +43,14 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // ACE modulation of 4 consecutive channels of one pixel, written on float2 pairs so that the arithmetic maps onto the
 // packed-f32 VALU ops (v_pk_add/mul/fma_f32) and v_cvt_pk_f16_f32: o = act((a*x + n*nz + d) * (1 + gamma) + beta) with
-// gamma = acc_g + (bias_g + style_g), beta likewise; act = max(o, slope*o) (slope 1 / 0.2 / 0 = none / leaky / relu).
-// Returns the f16 hi halves in .x/.y and the residual lo halves in .z/.w (two channels per dword).
+// gamma = acc_g * sc_g + (bias_g + style_g), beta likewise (sc = 2^-k[row] / s_in undoes the operand scaling, sh16.h);
+// act = max(o, slope*o) (slope 1 / 0.2 / 0 = none / leaky / relu).  The result is scaled by the output tensor's power of
+// two `osc`, clamped to the finite f16 range and split: returns the f16 hi halves in .x/.y and the residual lo halves in
+// .z/.w (two channels per dword).
 __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3, float b0, float b1, float b2, float b3,
                                           const float4& bg, const float4& bb, const float4& pa, const float4& pd,
-                                          const float4& pn, const float4& x4, float nz, float slope) {
+                                          const float4& pn, const float4& sg, const float4& sb, const float4& x4, float nz,
+                                          float slope_osc, float osc) {
     uint4 w;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -54,13 +58,15 @@ __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3
         const f32x2 vbg = h ? f32x2{bg.z, bg.w} : f32x2{bg.x, bg.y}, vbb = h ? f32x2{bb.z, bb.w} : f32x2{bb.x, bb.y};
         const f32x2 va = h ? f32x2{pa.z, pa.w} : f32x2{pa.x, pa.y}, vd = h ? f32x2{pd.z, pd.w} : f32x2{pd.x, pd.y};
         const f32x2 vn = h ? f32x2{pn.z, pn.w} : f32x2{pn.x, pn.y}, vx = h ? f32x2{x4.z, x4.w} : f32x2{x4.x, x4.y};
-        const f32x2 gam1 = (ag + vbg) + 1.f;
-        const f32x2 bet = ab + vbb;
+        const f32x2 vsg = h ? f32x2{sg.z, sg.w} : f32x2{sg.x, sg.y}, vsb = h ? f32x2{sb.z, sb.w} : f32x2{sb.x, sb.y};
+        const f32x2 gam1 = ag * vsg + (vbg + 1.f);
+        const f32x2 bet = ab * vsb + vbb;
         const f32x2 nrm = va * vx + (vn * nz + vd);
         f32x2 o = nrm * gam1 + bet;
-        const f32x2 os = o * slope;
-        o.x = fmaxf(o.x, os.x);
-        o.y = fmaxf(o.y, os.y);
+        const f32x2 os = o * slope_osc;
+        o = o * osc;
+        o.x = __builtin_amdgcn_fmed3f(fmaxf(o.x, os.x), -SH16_MAX, SH16_MAX);
+        o.y = __builtin_amdgcn_fmed3f(fmaxf(o.y, os.y), -SH16_MAX, SH16_MAX);
         const f16x2 hh = __builtin_convertvector(o, f16x2);
         const f32x2 lo = o - __builtin_convertvector(hh, f32x2);
         const f16x2 ll = __builtin_convertvector(lo, f16x2);
@@ -88,74 +94,79 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
     // Per-channel parameters are loaded ONCE per wave as float4 (a lane's 16 rows are 4 runs of 4 consecutive
     // channels), not per pixel: the per-(pixel,row) scalar loads were ~3/4 of the epilogue's VMEM instructions.
     const int hi = lane >> 5, col = lane & 31;
+    const float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
     if (EPI == EPI_PLAIN) {
-        float4 bias4[2][4];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
-                bias4[m][rq] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) {
-                    if (row0 + 3 < p.Mrows) bias4[m][rq] = *reinterpret_cast<const float4*>(p.bias + row0);
-                    else {
-                        float t[4] = {0.f, 0.f, 0.f, 0.f};
-                        for (int e = 0; e < 4; ++e) if (row0 + e < p.Mrows) t[e] = p.bias[row0 + e];
-                        bias4[m][rq] = make_float4(t[0], t[1], t[2], t[3]);
-                    }
-                }
-            }
         // f32 outputs of these convs use the "C4" layout [B][C/4][H][W][4]: a lane's 4 consecutive rows of one pixel are
         // one float4, lanes run along x -> 512 contiguous bytes per half-wave store (and per residual load).
+        // Loop order: channel run (m, rq) outer, so that only one run's bias / scale float4 pair is live.
         const int C4n = (p.Mrows + 3) >> 2;
         const float slope = act_slope(p.act);
+        const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
+        int pb_[4], pix_[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
             const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
             const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
-            if (b >= p.B || y >= p.H || x >= p.W) continue;
-            const long long pix = (long long)y * p.W + x;
-            const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
-            const long long rpix = (long long)(y >> p.res_up) * rW + (x >> p.res_up);
+            pb_[n] = (b < p.B && y < p.H && x < p.W) ? b : -1;
+            pix_[n] = y * p.W + x;
+        }
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
-                    if (row0 < p.Mrows && p.splitk > 1) {       // split-K: raw partial sums to this slice's C4 slab
+            for (int rq = 0; rq < 4; ++rq) {
+                const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
+                if (row0 >= p.Mrows) continue;                  // Mrows % 4 == 0
+                if (p.splitk > 1) {                              // split-K: raw partial sums to this slice's C4 slab
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (pb_[n] < 0) continue;
                         float4 v;
                         v.x = acc[m][n][rq * 4 + 0]; v.y = acc[m][n][rq * 4 + 1];
                         v.z = acc[m][n][rq * 4 + 2]; v.w = acc[m][n][rq * 4 + 3];
-                        reinterpret_cast<float4*>(p.partial)[(((long long)ks * p.B + b) * C4n + (row0 >> 2)) * HW + pix] = v;
-                    } else if (row0 < p.Mrows) {                // Mrows % 4 == 0
-                        const float4 b4 = bias4[m][rq];
-                        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (p.res) rv = reinterpret_cast<const float4*>(p.res)[((long long)b * C4n + (row0 >> 2)) * (rW * rH) + rpix];
-                        float4 v;
-                        v.x = acc[m][n][rq * 4 + 0] + b4.x; v.y = acc[m][n][rq * 4 + 1] + b4.y;
-                        v.z = acc[m][n][rq * 4 + 2] + b4.z; v.w = acc[m][n][rq * 4 + 3] + b4.w;
-                        // act = max(v, slope*v): none / leaky / relu without a per-element switch
-                        if (p.act > ACT_RELU) {                     // tanh / sigmoid (Zencoder head): rare, uniform branch
-                            if (p.res_after_act) {
-                                v.x = apply_act(v.x, p.act) + rv.x; v.y = apply_act(v.y, p.act) + rv.y;
-                                v.z = apply_act(v.z, p.act) + rv.z; v.w = apply_act(v.w, p.act) + rv.w;
-                            } else {
-                                v.x = apply_act(v.x + rv.x, p.act); v.y = apply_act(v.y + rv.y, p.act);
-                                v.z = apply_act(v.z + rv.z, p.act); v.w = apply_act(v.w + rv.w, p.act);
-                            }
-                        } else if (p.res_after_act) {
-                            v.x = fmaxf(v.x, slope * v.x) + rv.x; v.y = fmaxf(v.y, slope * v.y) + rv.y;
-                            v.z = fmaxf(v.z, slope * v.z) + rv.z; v.w = fmaxf(v.w, slope * v.w) + rv.w;
-                        } else {
-                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                            v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
-                            v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
-                        }
-                        reinterpret_cast<float4*>(p.out)[((long long)b * C4n + (row0 >> 2)) * HW + pix] = v;
+                        reinterpret_cast<float4*>(p.partial)[(((long long)ks * p.B + pb_[n]) * C4n + (row0 >> 2)) * HW + pix_[n]] = v;
                     }
+                    continue;
                 }
-        }
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(isi, isi, isi, isi);
+                if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + row0);
+                if (p.wscale) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.wscale + row0);
+                    s4 = make_float4(t.x * isi, t.y * isi, t.z * isi, t.w * isi);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (pb_[n] < 0) continue;
+                    const int b = pb_[n];
+                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.res) {
+                        const int yy = pix_[n] / p.W, xx = pix_[n] - yy * p.W;
+                        rv = reinterpret_cast<const float4*>(p.res)[((long long)b * C4n + (row0 >> 2)) * (rW * rH) +
+                                                                    (yy >> p.res_up) * rW + (xx >> p.res_up)];
+                    }
+                    float4 v;
+                    v.x = acc[m][n][rq * 4 + 0] * s4.x + b4.x; v.y = acc[m][n][rq * 4 + 1] * s4.y + b4.y;
+                    v.z = acc[m][n][rq * 4 + 2] * s4.z + b4.z; v.w = acc[m][n][rq * 4 + 3] * s4.w + b4.w;
+                    // act = max(v, slope*v): none / leaky / relu without a per-element switch
+                    if (p.act > ACT_RELU) {                     // tanh / sigmoid (Zencoder head): rare, uniform branch
+                        if (p.res_after_act) {
+                            v.x = apply_act(v.x, p.act) + rv.x; v.y = apply_act(v.y, p.act) + rv.y;
+                            v.z = apply_act(v.z, p.act) + rv.z; v.w = apply_act(v.w, p.act) + rv.w;
+                        } else {
+                            v.x = apply_act(v.x + rv.x, p.act); v.y = apply_act(v.y + rv.y, p.act);
+                            v.z = apply_act(v.z + rv.z, p.act); v.w = apply_act(v.w + rv.w, p.act);
+                        }
+                    } else if (p.res_after_act) {
+                        v.x = fmaxf(v.x, slope * v.x) + rv.x; v.y = fmaxf(v.y, slope * v.y) + rv.y;
+                        v.z = fmaxf(v.z, slope * v.z) + rv.z; v.w = fmaxf(v.w, slope * v.w) + rv.w;
+                    } else {
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+                        v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+                    }
+                    reinterpret_cast<float4*>(p.out)[((long long)b * C4n + (row0 >> 2)) * HW + pix_[n]] = v;
+                }
+            }
     } else {  // EPI_ACE -> SH16 output.  Loop order: channel-run (rq) outer so that only one run's parameters
               // (5 float4) are live; pixel coordinates / noise / packed 3x3 label neighbourhoods are kept per n.
         const int C = p.C;
@@ -182,13 +193,13 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
                     const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
                     const unsigned jv = lb[in ? yy * p.W + xx : 0];       // unconditional load, select after
-                    lv |= (unsigned long long)(in ? jv : 19u) << (5 * t);
+                    lv |= (unsigned long long)((in && jv < 19u) ? jv : 19u) << (5 * t);   // >= 19: "no class" -> zero column
                 }
             }
             labs[n] = lv;
         }
         // Addressing: wave-uniform 64-bit bases (sample b0) + 32-bit per-lane byte offsets.
-        const float slope = act_slope(p.act);
+        const float osc = p.out_scale != 0.f ? p.out_scale : 1.f, slope_osc = act_slope(p.act) * osc;
         const int xHW = xW * xH;
         const char* xbase = reinterpret_cast<const char*>(p.x) + (long long)b0 * (C >> 2) * xHW * 16;
         char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
@@ -214,6 +225,14 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
             const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + cc);
             const float4 pd = *reinterpret_cast<const float4*>(p.bn_d + cc);
             const float4 pn = *reinterpret_cast<const float4*>(p.nv + cc);
+            // GEMM rows of channel c: gamma at (c/32)*64 + c%32, beta 32 rows further
+            float4 wsg = make_float4(isi, isi, isi, isi), wsb = wsg;
+            if (p.wscale) {
+                const float* wr = p.wscale + (cc >> 5) * 64 + (cc & 31);
+                const float4 tg = *reinterpret_cast<const float4*>(wr), tb4 = *reinterpret_cast<const float4*>(wr + 32);
+                wsg = make_float4(tg.x * isi, tg.y * isi, tg.z * isi, tg.w * isi);
+                wsb = make_float4(tb4.x * isi, tb4.y * isi, tb4.z * isi, tb4.w * isi);
+            }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 if (pb_[n] < 0) continue;
@@ -240,7 +259,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                 const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
                 uint4 w = ace_quad(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
                                    acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
-                                   bg, bb, pa, pd, pn, x4, nzv[n], slope);
+                                   bg, bb, pa, pd, pn, wsg, wsb, x4, nzv[n], slope_osc, osc);
                 if (!cok) w = make_uint4(0, 0, 0, 0);            // padding channels of the last group hold zeros
                 *reinterpret_cast<uint4*>(obase + (oo_[n] + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
             }
@@ -464,11 +483,12 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     constexpr int NLD = (UNITS + 255) / 256;                 // units per loader thread per chunk
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
     // LDS map (16-byte units): 2 stages of [input patch UNITS | A fragments AUNITS], then (ACE) the epilogue's small
-    // operands [par: 8 runs x 5 float4][nz: 512 f32][lab: TB*(TH+2)*(TW+2) bytes].  The A fragments of a chunk are one
+    // operands [par: 8 runs x 7 float4][nz: 512 f32][lab: TB*(TH+2)*(TW+2) bytes].  The A fragments of a chunk are one
     // contiguous, already lane-ordered block in global memory: the loaders move it with LDS-DMA (global_load_lds, 16 B
     // per lane, no VGPR round trip), so the consumers' MFMA stream never waits on an L2 round trip.
     constexpr int AUNITS = NT * 4 * 64, STAGE = UNITS + AUNITS;
-    constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + 8 * 5, LAB0 = NZ0 + 128;
+    constexpr int NPAR = 7;                                  // float4 per channel run: bias_g, bias_b, bn_a, bn_d, nv, sc_g, sc_b
+    constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + 8 * NPAR, LAB0 = NZ0 + 128;
     constexpr int NDA = AUNITS / 256;                        // A DMA instructions per loader thread per chunk
     constexpr int LW = TW + 2, LH = TH + 2;
     constexpr bool pre = EPI == EPI_ACE;    /* host guarantees nchunks >= 3 */       // epilogue operands prefetched through LDS
@@ -515,8 +535,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     }
                     if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                         soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
-                    if (TERMS == 1 && (gh & 1)) soff[i] = -1;
-            if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
+                    if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
                 }
             }
             cur_tile = k;
@@ -561,11 +580,20 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             int mt, x0, y0, b0;
             tile_coords(k, mt, x0, y0, b0);
             const int C = p.C;
-            if (ltid < 40) {                                              // par[run][which]: bias_g, bias_b, bn_a, bn_d, nv
-                const int run = ltid / 5, which = ltid % 5;
-                const int c0 = (mt * 8 + run) * 4;
-                const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
-                parr = *reinterpret_cast<const float4*>(src + (c0 < C ? c0 : 0));
+            if (ltid < 8 * NPAR) {                                        // par[run][which]
+                const int run = ltid / NPAR, which = ltid % NPAR;
+                const int c0 = (mt * 8 + run) * 4, cc = c0 < C ? c0 : 0;
+                if (which < 5) {
+                    const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
+                    parr = *reinterpret_cast<const float4*>(src + cc);
+                } else {                                                  // operand-scaling undo: 2^-k[row] / s_in (sh16.h)
+                    const float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
+                    parr = make_float4(isi, isi, isi, isi);
+                    if (p.wscale) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.wscale + (cc >> 5) * 64 + (which - 5) * 32 + (cc & 31));
+                        parr = make_float4(t.x * isi, t.y * isi, t.z * isi, t.w * isi);
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -591,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             }
         };
         auto epi_store = [&]() {
-            if (ltid < 40) reinterpret_cast<float4*>(smem_u + PAR0)[ltid] = parr;
+            if (ltid < 8 * NPAR) reinterpret_cast<float4*>(smem_u + PAR0)[ltid] = parr;
 #pragma unroll
             for (int i = 0; i < 2; ++i) reinterpret_cast<float*>(smem_u + NZ0)[ltid + i * 256] = nzr[i];
             if (p.lut) {
@@ -715,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0);
             const float* nzs = reinterpret_cast<const float*>(smem_u + NZ0);
             const uint8_t* labs8 = reinterpret_cast<const uint8_t*>(smem_u + LAB0);
-            const float slope = act_slope(p.act);
+            const float osc = p.out_scale != 0.f ? p.out_scale : 1.f, slope_osc = act_slope(p.act) * osc;
             char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
             const unsigned lrs = (unsigned)p.lut_rs * 4u, lns = (unsigned)p.lut_ns * 4u;
             const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * p.lut_bs * lns;
@@ -744,8 +772,9 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     if (g >= Go) continue;
                     const bool cok = c0 < C;
                     const unsigned cc = cok ? c0 : 0;
-                    const float4 pg = par[run * 5 + 0], pb = par[run * 5 + 1], pa = par[run * 5 + 2], pd = par[run * 5 + 3],
-                                 pn = par[run * 5 + 4];
+                    const float4 pg = par[run * NPAR + 0], pb = par[run * NPAR + 1], pa = par[run * NPAR + 2],
+                                 pd = par[run * NPAR + 3], pn = par[run * NPAR + 4], wsg = par[run * NPAR + 5],
+                                 wsb = par[run * NPAR + 6];
                     const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo + (cc >> 2) * (unsigned)xHW * 16u));
                     float4 sg = z4, sb = z4;
                     if (p.lut) {
@@ -762,7 +791,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
                     uint4 w = ace_quad(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
                                        acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
-                                       bg, bb, pa, pd, pn, x4, nz, slope);
+                                       bg, bb, pa, pd, pn, wsg, wsb, x4, nz, slope_osc, osc);
                     if (!cok) w = make_uint4(0, 0, 0, 0);
                     *reinterpret_cast<uint4*>(obase + (oo + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
                 }
@@ -778,7 +807,7 @@ hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
-    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
+    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 56 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
                                           : 2 * V3_STAGE * 16;
     static bool attr_set = false;
     static int ncu = 256;
@@ -817,6 +846,15 @@ __global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
         const int cg = (int)((i / HW) % C4n);
+        {   // undo the operand scaling (sh16.h): 2^-k[row] / s_in
+            const float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
+            float4 s4 = make_float4(isi, isi, isi, isi);
+            if (p.wscale) {
+                const float4 t = *reinterpret_cast<const float4*>(p.wscale + cg * 4);
+                s4 = make_float4(t.x * isi, t.y * isi, t.z * isi, t.w * isi);
+            }
+            v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+        }
         if (p.bias) {
             const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cg * 4);
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;

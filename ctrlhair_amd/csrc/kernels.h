@@ -7,16 +7,19 @@ namespace chk {
 hipError_t label_downsample(const uint8_t* in, uint8_t* out, int B, int S, int r, hipStream_t s);
 hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* bias, float* out, int B, int H, int W,
                           int K, int relu, hipStream_t s, int c4 = 0);
+// `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
-                               int K, int relu, hipStream_t s);
-hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, hipStream_t s);
+                               int K, int relu, float scale, hipStream_t s);
+hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, hipStream_t s);
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad, hipStream_t s,
-                 float* mu_rows = nullptr, int sh16 = 0, int bs = 19);
+                 float* mu_rows = nullptr, int sh16 = 0, int bs = 19, float scale = 1.f);
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                          hipStream_t s, int c4 = 0);
 hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hipStream_t s);
 hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s);
 // misc_kernels.hip
+// instance-norm outputs are bounded by sqrt(HW): their SH16 scale is instnorm_sh16_scale(HW), no saturation possible
+float instnorm_sh16_scale(int HW);
 hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16 = nullptr, int C = 0);
 hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s);
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,

@@ -1,6 +1,7 @@
 // misc_kernels.hip -- HBM/latency-bound kernels of the Zencoder, shape branch, BiSeNet and colour MLPs:
 // wave64 shuffle reductions for the normalisation statistics, pooling, up-sampling/argmax epilogues, GEMV.
 #include "kernels.h"
+#include "sh16.h"
 
 namespace chk {
 
@@ -33,7 +34,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // sh16 != nullptr: the normalised plane is written (instead of in place) as f16 hi/lo in the SH16 layout
 // [B][C/8][2][HW][8] of conv_sh16.h (plane index = b*C + c), feeding the f16x3 conv directly.
 __global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x, int HW, float eps, int act,
-                                                           _Float16* __restrict__ sh16, int C) {
+                                                           _Float16* __restrict__ sh16, int C, float scale) {
     __shared__ float red[4];
     float* p = x + (long long)blockIdx.x * HW;
     float s = 0.f;
@@ -51,9 +52,10 @@ __global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x
         _Float16* oh = sh16 + ((((long long)b * (C >> 3) + (c >> 3)) * 2) * HW) * 8 + (c & 7);
         for (int i = threadIdx.x; i < HW; i += 256) {
             const float v = act_fn((p[i] - mean) * rstd, act);
-            const _Float16 h = (_Float16)v;
+            _Float16 h, l;
+            sh16_split(v, scale, h, l);
             oh[(long long)i * 8] = h;
-            oh[((long long)HW + i) * 8] = (_Float16)(v - (float)h);
+            oh[((long long)HW + i) * 8] = l;
         }
         return;
     }
@@ -75,7 +77,7 @@ __device__ __forceinline__ float block_sum1024(float v, float* red) {
 }
 
 __global__ __launch_bounds__(1024) void instnorm_act_wide_kernel(float* __restrict__ x, int HW, float eps, int act,
-                                                                 _Float16* __restrict__ sh16, int C) {
+                                                                 _Float16* __restrict__ sh16, int C, float scale) {
     __shared__ float red[16];
     float4* p4 = reinterpret_cast<float4*>(x + (long long)blockIdx.x * HW);
     const int n4 = HW >> 2;
@@ -102,9 +104,10 @@ __global__ __launch_bounds__(1024) void instnorm_act_wide_kernel(float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = act_fn((vv[e] - mean) * rstd, act);
-                const _Float16 h = (_Float16)v;
+                _Float16 h, l;
+                sh16_split(v, scale, h, l);
                 oh[(long long)(i * 4 + e) * 8] = h;
-                oh[((long long)HW + i * 4 + e) * 8] = (_Float16)(v - (float)h);
+                oh[((long long)HW + i * 4 + e) * 8] = l;
             }
         }
         return;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(1024) void instnorm_act_wide_kernel(float* __restri
 // SH16 output (feeds the f16x3 conv): one block per (sample, group of 8 channels) so that every lane writes whole 16-byte
 // units (8 channels of one pixel, hi plane and lo plane) instead of 2-byte elements 16 bytes apart from 8 different blocks.
 __global__ __launch_bounds__(1024) void instnorm_act_sh16_kernel(const float* __restrict__ x, int HW, float eps, int act,
-                                                                 uint4* __restrict__ sh16, int C) {
+                                                                 uint4* __restrict__ sh16, int C, float scale) {
     typedef _Float16 half8v __attribute__((ext_vector_type(8)));
     __shared__ float red[16];
     __shared__ float mean_s[8], rstd_s[8];
@@ -154,9 +157,10 @@ __global__ __launch_bounds__(1024) void instnorm_act_sh16_kernel(const float* __
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float v = act_fn((base[(long long)c * HW + i] - mean_s[c]) * rstd_s[c], act);
-            const _Float16 h = (_Float16)v;
+            _Float16 h, l;
+            sh16_split(v, scale, h, l);
             vh[c] = h;
-            vl[c] = (_Float16)(v - (float)h);
+            vl[c] = l;
         }
         oh[i] = __builtin_bit_cast(uint4, vh);
         oh[HW + i] = __builtin_bit_cast(uint4, vl);
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(1024) void instnorm_act_sh16_kernel(const float* __
 
 // Same, input in the C4 layout [B][C/4][HW][4] (output of an f16x3 conv): a block's 8 channels are two float4 per pixel.
 __global__ __launch_bounds__(1024) void instnorm_c4_sh16_kernel(const float4* __restrict__ x, int HW, float eps, int act,
-                                                                uint4* __restrict__ sh16, int C) {
+                                                                uint4* __restrict__ sh16, int C, float scale) {
     typedef _Float16 half8v __attribute__((ext_vector_type(8)));
     __shared__ float red[16];
     __shared__ float mean_s[8], rstd_s[8];
@@ -208,31 +212,37 @@ __global__ __launch_bounds__(1024) void instnorm_c4_sh16_kernel(const float4* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float o = act_fn((v[e] - mean_s[e]) * rstd_s[e], act);
-            const _Float16 h = (_Float16)o;
+            _Float16 h, l;
+            sh16_split(o, scale, h, l);
             vh[e] = h;
-            vl[e] = (_Float16)(o - (float)h);
+            vl[e] = l;
         }
         oh[i] = __builtin_bit_cast(uint4, vh);
         oh[HW + i] = __builtin_bit_cast(uint4, vl);
     }
 }
 
+// |(x - mean) / sqrt(var + eps)| <= sqrt(HW - 1) for any plane, and the activations used here (none / leaky / relu) do not
+// increase magnitudes: the scale below can never saturate
+float instnorm_sh16_scale(int HW) { return sh16_scale_for_bound(sqrtf((float)HW)); }
+
 hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s) {
     if (C & 7) return hipErrorInvalidValue;
     hipLaunchKernelGGL(instnorm_c4_sh16_kernel, dim3(B * (C >> 3)), dim3(1024), 0, s, reinterpret_cast<const float4*>(x_c4), HW,
-                       eps, act, static_cast<uint4*>(sh16), C);
+                       eps, act, static_cast<uint4*>(sh16), C, instnorm_sh16_scale(HW));
     return hipGetLastError();
 }
 
 hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16, int C) {
+    const float sc = instnorm_sh16_scale(HW);
     if (sh16 && (C & 7) == 0 && (HW & 3) == 0 && HW >= 4096) {
-        hipLaunchKernelGGL(instnorm_act_sh16_kernel, dim3(planes / 8), dim3(1024), 0, s, x, HW, eps, act, static_cast<uint4*>(sh16), C);
+        hipLaunchKernelGGL(instnorm_act_sh16_kernel, dim3(planes / 8), dim3(1024), 0, s, x, HW, eps, act, static_cast<uint4*>(sh16), C, sc);
         return hipGetLastError();
     }
     if (HW >= 16384 && (HW & 3) == 0)
-        hipLaunchKernelGGL(instnorm_act_wide_kernel, dim3(planes), dim3(1024), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C);
+        hipLaunchKernelGGL(instnorm_act_wide_kernel, dim3(planes), dim3(1024), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C, sc);
     else
-        hipLaunchKernelGGL(instnorm_act_kernel, dim3(planes), dim3(256), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C);
+        hipLaunchKernelGGL(instnorm_act_kernel, dim3(planes), dim3(256), 0, s, x, HW, eps, act, static_cast<_Float16*>(sh16), C, sc);
     return hipGetLastError();
 }
 

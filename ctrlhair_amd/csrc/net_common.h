@@ -105,8 +105,29 @@ std::vector<float> pack_A(int rows, int Cin, int KS, int CK, F get) {
 
 // f16x3 split-operand packing for conv_sh16_kernel:
 //   [wave tile 64 rows][chunk 16 ch][tap][M-subtile][hi|lo][lane][8 halfs]; lane l: row (l&31), channels 8*(l>>5)+e
+// Every row is scaled by its own power of two 2^k[row] before the hi/lo split so that max|row| * 2^k lies in [2^14, 2^15)
+// (sh16.h: an element 2^18 times smaller than the row maximum still keeps 22 significand bits); `wscale[row]` receives the
+// exact inverse 2^-k[row], which the consuming epilogue multiplies the accumulator by.  `kmax` (optional, per row) caps
+// the exponent (two operands sharing an accumulator must share 2^k * s_in: see sh16_row_exponents).
+inline int sh16_row_exponent(float rowmax) {
+    if (!(rowmax > 0.f) || !std::isfinite(rowmax)) return 0;
+    int e;
+    (void)std::frexp(rowmax, &e);          // rowmax = m * 2^e, m in [0.5, 1)
+    return 15 - e;                         // rowmax * 2^k in [2^14, 2^15)
+}
 template <class F>
-std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get) {
+std::vector<int> sh16_row_exponents(int rows, int Cin, int KS, F get) {
+    std::vector<int> k(rows);
+    for (int r = 0; r < rows; ++r) {
+        float mx = 0.f;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < KS * KS; ++t) mx = std::max(mx, std::fabs(get(r, ci, t)));
+        k[r] = sh16_row_exponent(mx);
+    }
+    return k;
+}
+template <class F>
+std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get, const std::vector<int>& kexp) {
     const int mt64 = (rows + 63) / 64, nch = (Cin + 15) / 16, nt = KS * KS;
     std::vector<_Float16> dst((size_t)mt64 * nch * nt * 2 * 2 * 64 * 8, (_Float16)0.f);
     size_t o = 0;
@@ -120,7 +141,7 @@ std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get) {
                                 const int row = mt * 64 + ms * 32 + (lane & 31);
                                 const int ci = ch * 16 + (lane >> 5) * 8 + e;
                                 if (row < rows && ci < Cin) {
-                                    const float w = get(row, ci, t);
+                                    const float w = std::ldexp(get(row, ci, t), kexp[row]);
                                     const _Float16 h = (_Float16)w;
                                     dst[o] = hl == 0 ? h : (_Float16)(w - (float)h);
                                 }
@@ -129,6 +150,12 @@ std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get) {
     std::vector<float> out(dst.size() / 2);
     std::memcpy(out.data(), dst.data(), dst.size() * 2);
     return out;
+}
+// inverse row scales 2^-k, padded to whole 64-row tiles (epilogues read float4 runs)
+inline std::vector<float> sh16_wscale(const std::vector<int>& kexp) {
+    std::vector<float> v(((kexp.size() + 63) / 64) * 64, 1.f);
+    for (size_t r = 0; r < kexp.size(); ++r) v[r] = std::ldexp(1.f, -kexp[r]);
+    return v;
 }
 
 // ---- generic conv layer on the MFMA kernel ------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // sean_kernels.hip -- the small HBM/LDS-bound kernels around the MFMA convs of the SEAN generator path.
 // gfx950 only (wave64).  Every kernel is predicated for arbitrary shapes.
 #include "kernels.h"
+#include "sh16.h"
 
 namespace chk {
 
@@ -53,9 +54,11 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        jt[t] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    ? (lab[b * HW + (long long)yy * W + xx] * 9 + t) * OH_KC
-                    : -1;
+        jt[t] = -1;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            const int j = lab[b * HW + (long long)yy * W + xx];
+            if (j < 19) jt[t] = (j * 9 + t) * OH_KC;           // labels >= 19 ("no class", e.g. 255): all-zero one-hot
+        }
     }
     const int kmax = (K - k0 < OH_KC) ? (K - k0) : OH_KC;
     for (int kk = 0; kk < kmax; ++kk) {
@@ -85,7 +88,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t* __restrict__ lab,
                                                                   const float* __restrict__ table,
                                                                   const float* __restrict__ bias, uint4* __restrict__ out,
-                                                                  int B, int H, int W, int K, int relu) {
+                                                                  int B, int H, int W, int K, int relu, float scale) {
     // Table slice in LDS with a padded row pitch (36 floats: consecutive (label, tap) rows start 4 banks apart, so lanes
     // that hold different labels do not collide on the same banks) and one extra all-zero row that taps outside the image
     // point at -- every lane then issues the same 9 x 2 ds_read_b128 per 8 channels, no predication.
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
         const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
         const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
         const int j = lab[b * HW + (in ? (long long)yy * W + xx : 0)];
-        jt[t] = (in ? j * 9 + t : ZROW) * RS;
+        jt[t] = (in && j < 19 ? j * 9 + t : ZROW) * RS;         // labels >= 19 ("no class"): all-zero one-hot
     }
     const int G = (K + 7) / 8;
 #pragma unroll
@@ -132,9 +135,10 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
             float v = v8[e];
             if (relu) v = v > 0.f ? v : 0.f;
             if (k0 + gq * 8 + e >= K) v = 0.f;
-            const _Float16 h = (_Float16)v;
+            _Float16 h, l;
+            sh16_split(v, scale, h, l);
             vh[e] = h;
-            vl[e] = (_Float16)(v - (float)h);
+            vl[e] = l;
         }
         const long long unit = (((long long)b * G + g) * 2) * HW + (pix % HW);
         // streaming stores: the planes are consumed by the next kernel from HBM/L2, never re-read here
@@ -145,27 +149,29 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
 }
 
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
-                               int K, int relu, hipStream_t s) {
+                               int K, int relu, float scale, hipStream_t s) {
     const long long npix = (long long)B * H * W;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
     hipLaunchKernelGGL(onehot_conv3x3_sh16_kernel, grid, dim3(256), 0, s, lab, table, bias, static_cast<uint4*>(out), B, H,
-                       W, K, relu);
+                       W, K, relu, scale);
     return hipGetLastError();
 }
 
 // SH16 -> f32 NCHW (test taps only)
-__global__ void sh16_decode_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int B, int C, long long HW) {
+__global__ void sh16_decode_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int B, int C, long long HW,
+                                   float inv_scale) {
     const long long n = (long long)B * C * HW;
     const int G = (C + 7) / 8;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long p = i % HW;
         const int c = (int)((i / HW) % C), b = (int)(i / (HW * C));
         const long long unit = (((long long)b * G + c / 8) * 2) * HW + p;
-        out[i] = (float)in[unit * 8 + (c & 7)] + (float)in[(unit + HW) * 8 + (c & 7)];
+        out[i] = ((float)in[unit * 8 + (c & 7)] + (float)in[(unit + HW) * 8 + (c & 7)]) * inv_scale;
     }
 }
-hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, hipStream_t s) {
-    hipLaunchKernelGGL(sh16_decode_kernel, dim3(4096), dim3(256), 0, s, static_cast<const _Float16*>(in), out, B, C, HW);
+hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(sh16_decode_kernel, dim3(4096), dim3(256), 0, s, static_cast<const _Float16*>(in), out, B, C, HW,
+                       1.f / scale);
     return hipGetLastError();
 }
 
@@ -192,7 +198,7 @@ constexpr int FCMU_BT = 8;
 
 __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ codes, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ mu_img, int B,
-                                                    int Npad, float* __restrict__ mu_rows, int sh16, int bs) {
+                                                    int Npad, float* __restrict__ mu_rows, int sh16, int bs, float scale) {
     const int j = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o0 = (blockIdx.x * 4 + wave) * 4;           // 4 output features per wave
@@ -250,9 +256,10 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
                         if (mu_rows) mu_rows[(long long)n * 512 + o] = r;   // [N][512] for the GEMV path
                         else if (sh16) {   // split-operand image [512/8][hi|lo][Npad][8] for the f16x3 LUT GEMM
                             _Float16* mh = reinterpret_cast<_Float16*>(mu_img);
-                            const _Float16 h = (_Float16)r;
+                            _Float16 h, l;
+                            sh16_split(r, scale, h, l);
                             mh[(((long long)(o >> 3) * 2 + 0) * Npad + n) * 8 + (o & 7)] = h;
-                            mh[(((long long)(o >> 3) * 2 + 1) * Npad + n) * 8 + (o & 7)] = (_Float16)(r - (float)h);
+                            mh[(((long long)(o >> 3) * 2 + 1) * Npad + n) * 8 + (o & 7)] = l;
                         } else mu_img[(long long)o * Npad + n] = r;
                     }
         }
@@ -260,8 +267,9 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
 }
 
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad,
-                 hipStream_t s, float* mu_rows, int sh16, int bs) {
-    hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad, mu_rows, sh16, bs);
+                 hipStream_t s, float* mu_rows, int sh16, int bs, float scale) {
+    hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad, mu_rows, sh16, bs,
+                       scale);
     return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 #include "conv_mfma.h"
 #include "conv_sh16.h"
 #include "kernels.h"
+#include "sh16.h"
 
 namespace chk {
 
@@ -83,12 +84,15 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         bw.styled = s.styled;
         bw.learned = bw.fin != bw.fout;
 
-        auto spectral = [&](const std::string& p, int cout, int cin, int ks, bool bias, ConvW& cw) {
+        // spectral norm folded at load (torch eval semantics W / (u . W_mat v)); f16x3 path: per-row power-of-two scaling
+        struct SN { const float* w = nullptr; double sigma = 1.0; int cout = 0, cin = 0, ks = 0; };
+        auto sn_read = [&](const std::string& p, int cout, int cin, int ks) {
+            SN r;
             const size_t kk = (size_t)cin * ks * ks;
             auto w = B.get(p + ".weight_orig", (size_t)cout * kk);
             auto u = B.get(p + ".weight_u", cout);
             auto v = B.get(p + ".weight_v", kk);
-            if (!w || !u || !v) return;
+            if (!w || !u || !v) return r;
             double sigma = 0.0;   // u . (W_mat v)
             for (int o = 0; o < cout; ++o) {
                 double acc = 0.0;
@@ -96,24 +100,51 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 for (size_t i = 0; i < kk; ++i) acc += (double)wr[i] * v->f32()[i];
                 sigma += acc * u->f32()[o];
             }
-            const float inv = (float)(1.0 / sigma);
-            const float* wp = w->f32();
-            const int ck = ks == 3 ? CK_KS3 : CK_KS1;
-            auto getw = [&](int row, int ci, int t) { return wp[((size_t)row * cin + ci) * ks * ks + t] / (float)sigma; };
-            auto pk = use_sh16 ? pack_A_sh16(cout, cin, ks, getw) : pack_A(cout, cin, ks, ck, getw);
-            (void)inv;
-            cw.wpk = B.upload(pk);
-            cw.Cout = cout;
-            cw.Cin = cin;
-            cw.KS = ks;
+            r.w = w->f32();
+            r.sigma = sigma;
+            r.cout = cout; r.cin = cin; r.ks = ks;
+            return r;
+        };
+        auto sn_get = [](const SN& r) {
+            return [r](int row, int ci, int t) { return r.w[((size_t)row * r.cin + ci) * r.ks * r.ks + t] / (float)r.sigma; };
+        };
+        auto sn_pack = [&](const SN& r, const std::string& p, bool bias, const std::vector<int>* kexp, ConvW& cw) {
+            if (!r.w) return;
+            auto getw = sn_get(r);
+            if (use_sh16) {
+                cw.wpk = B.upload(pack_A_sh16(r.cout, r.cin, r.ks, getw, *kexp));
+                cw.wscale = B.upload(sh16_wscale(*kexp));
+            } else {
+                cw.wpk = B.upload(pack_A(r.cout, r.cin, r.ks, r.ks == 3 ? CK_KS3 : CK_KS1, getw));
+            }
+            cw.Cout = r.cout;
+            cw.Cin = r.cin;
+            cw.KS = r.ks;
             if (bias) {
-                auto bb = B.get(p + ".bias", cout);
-                if (bb) cw.bias = B.upload(std::vector<float>(bb->f32(), bb->f32() + cout));
+                auto bb = B.get(p + ".bias", r.cout);
+                if (bb) cw.bias = B.upload(std::vector<float>(bb->f32(), bb->f32() + r.cout));
             }
         };
-        spectral(bw.name + ".conv_0", bw.fmid, bw.fin, 3, true, bw.conv_0);
-        spectral(bw.name + ".conv_1", bw.fout, bw.fmid, 3, true, bw.conv_1);
-        if (bw.learned) spectral(bw.name + ".conv_s", bw.fout, bw.fin, 1, false, bw.conv_s);
+        {
+            const SN c0 = sn_read(bw.name + ".conv_0", bw.fmid, bw.fin, 3), c1 = sn_read(bw.name + ".conv_1", bw.fout, bw.fmid, 3);
+            SN cs;
+            if (bw.learned) cs = sn_read(bw.name + ".conv_s", bw.fout, bw.fin, 1);
+            if (!B.err.empty()) return B.err;
+            std::vector<int> k0, k1, ks_;
+            if (use_sh16) {
+                k0 = sh16_row_exponents(c0.cout, c0.cin, 3, sn_get(c0));
+                k1 = sh16_row_exponents(c1.cout, c1.cin, 3, sn_get(c1));
+                if (bw.learned) {
+                    // conv_s is folded into conv_1 as extra K chunks on the same accumulators (both inputs are ACE outputs
+                    // with the same activation scale): the two weight rows must share their power of two
+                    ks_ = sh16_row_exponents(cs.cout, cs.cin, 1, sn_get(cs));
+                    for (int r = 0; r < c1.cout; ++r) k1[r] = ks_[r] = std::min(k1[r], ks_[r]);
+                }
+            }
+            sn_pack(c0, bw.name + ".conv_0", true, &k0, bw.conv_0);
+            sn_pack(c1, bw.name + ".conv_1", true, &k1, bw.conv_1);
+            if (bw.learned) sn_pack(cs, bw.name + ".conv_s", false, &ks_, bw.conv_s);
+        }
         if (!B.err.empty()) return B.err;
 
         auto ace = [&](const std::string& p, int C, AceW& a) {
@@ -157,6 +188,20 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                         T[((size_t)j * 9 + t) * HID + k] = ws->f32()[((size_t)k * LABEL_NC + j) * 9 + t];
             a.actv_table = B.upload(T);
             a.actv_bias = B.upload(std::vector<float>(bs->f32(), bs->f32() + HID));
+            {   // relu(bias + sum of one table entry per tap) <= bias + sum_t max(0, max_j T[j][t][k]): a bound that holds for
+                // every label map, so the SH16 scale of the hidden activations can never saturate
+                float bound = 0.f;
+                for (int k = 0; k < HID; ++k) {
+                    float v = bs->f32()[k];
+                    for (int t = 0; t < 9; ++t) {
+                        float mx = 0.f;
+                        for (int j = 0; j < LABEL_NC; ++j) mx = std::max(mx, T[((size_t)j * 9 + t) * HID + k]);
+                        v += mx;
+                    }
+                    bound = std::max(bound, v);
+                }
+                a.actv_scale = sh16_scale_for_bound(bound);
+            }
             // SPADE gamma/beta rows: 64-row tiles = (gamma of 32 channels | beta of the same 32 channels)
             const int tiles = (C + 31) / 32;
             const float* wgp = wg->f32();
@@ -169,8 +214,13 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 const float w = (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t];
                 return w * (beta ? sb : sg);
             };
-            auto pk = use_sh16 ? pack_A_sh16(tiles * 64, HID, 3, getsp) : pack_A(tiles * 64, HID, 3, CK_KS3, getsp);
-            a.spade_wpk = B.upload(pk);
+            if (use_sh16) {
+                const auto kexp = sh16_row_exponents(tiles * 64, HID, 3, getsp);
+                a.spade_wpk = B.upload(pack_A_sh16(tiles * 64, HID, 3, getsp, kexp));
+                a.spade_wscale = B.upload(sh16_wscale(kexp));
+            } else {
+                a.spade_wpk = B.upload(pack_A(tiles * 64, HID, 3, CK_KS3, getsp));
+            }
             if (a.styled) {
                 auto cg = B.get(p + ".conv_gamma.weight", (size_t)C * STYLE * 9);
                 auto cgb = B.get(p + ".conv_gamma.bias", C);
@@ -198,7 +248,13 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     const int t = row / (2 * C), gb = (row / C) & 1, c = row % C;
                     return gb ? ab * cbp[((size_t)c * STYLE + k) * 9 + t] : ag * cgp[((size_t)c * STYLE + k) * 9 + t];
                 };
-                a.lut_wpk = B.upload(use_sh16 ? pack_A_sh16(18 * C, STYLE, 1, getl) : pack_A(18 * C, STYLE, 1, CK_KS1, getl));
+                if (use_sh16) {
+                    const auto kexp = sh16_row_exponents(18 * C, STYLE, 1, getl);
+                    a.lut_wpk = B.upload(pack_A_sh16(18 * C, STYLE, 1, getl, kexp));
+                    a.lut_wscale = B.upload(sh16_wscale(kexp));
+                } else {
+                    a.lut_wpk = B.upload(pack_A(18 * C, STYLE, 1, CK_KS1, getl));
+                }
                 if (max_batch * (LABEL_NC + 1) <= 64) {   // small batches (interactive use): the LUT build is a weight-streaming GEMV
                     std::vector<float> rows((size_t)18 * C * STYLE);
                     for (int row = 0; row < 18 * C; ++row) {
@@ -246,11 +302,17 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         if (use_sh16) {   // the 256->512 conv is 91 % of the Zencoder FLOPs: run it on the f16x3 path too
             auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
             const float* wp = w14.data();
-            z14_sh = B.upload(pack_A_sh16(512, 256, 3, [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; }));
+            auto g14 = [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; };
+            const auto k14 = sh16_row_exponents(512, 256, 3, g14);
+            z14_sh = B.upload(pack_A_sh16(512, 256, 3, g14, k14));
+            z14_ws = B.upload(sh16_wscale(k14));
             // the ConvTranspose too (a 3x3 conv over the zero-inserted view, flipped taps as above)
             auto wt10 = B.vec("Zencoder.model.10.weight", (size_t)128 * 256 * 9);
             const float* w10 = wt10.data();
-            z10_sh = B.upload(pack_A_sh16(256, 128, 3, [&](int row, int ci, int t) { return w10[((size_t)ci * 256 + row) * 9 + (8 - t)]; }));
+            auto g10 = [&](int row, int ci, int t) { return w10[((size_t)ci * 256 + row) * 9 + (8 - t)]; };
+            const auto k10 = sh16_row_exponents(256, 128, 3, g10);
+            z10_sh = B.upload(pack_A_sh16(256, 128, 3, g10, k10));
+            z10_ws = B.upload(sh16_wscale(k10));
         }
         if (!B.err.empty()) return B.err;
         has_zencoder = true;
@@ -352,7 +414,7 @@ struct Runner {
     void tap_sh16(const std::string& name, const float* src, int C, size_t hw) {
         auto it = m.taps.find(name);
         if (it == m.taps.end() || !it->second) return;
-        if (m.use_sh16) check(sh16_decode(src, it->second, B, C, (long long)hw, st), "tap decode");
+        if (m.use_sh16) check(sh16_decode(src, it->second, B, C, (long long)hw, SH16_ACT_SCALE, st), "tap decode");
         else check(hipMemcpyAsync(it->second, src, (size_t)B * C * hw * 4, hipMemcpyDeviceToDevice, st), "tap copy");
     }
     // f32 tensors between kernels are NCHW on the exact-f32 path and C4 ([B][C/4][HW][4]) on the f16x3 path
@@ -395,7 +457,7 @@ struct Runner {
                 });
             } else if (m.use_sh16) {
                 // f16x3 LUT GEMM: 1x1 conv over the [npad/32 x 32] "image" of (sample, label) columns, C4 output
-                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs), "fc_mu");
+                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs, SH16_ACT_SCALE), "fc_mu");
                 ConvParams p{};
                 p.in = m.mu_img;
                 p.wpk = a.lut_wpk;
@@ -408,6 +470,8 @@ struct Runner {
                 p.pad = -1;
                 p.act = ACT_NONE;
                 p.terms = m.terms;
+                p.wscale = a.lut_wscale;
+                p.in_scale_inv = 1.f / SH16_ACT_SCALE;
                 p.partial = m.splitk_ws;           // K = 512 in 32 chunks on few tiles (C <= 512): split-K fills the chip
                 p.partial_cap = m.splitk_cap;
                 timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
@@ -432,7 +496,7 @@ struct Runner {
             }
         }
         if (m.use_sh16)
-            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
+            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, a.actv_scale, st), "mlp_shared");
         else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
         ConvParams p{};
@@ -463,6 +527,9 @@ struct Runner {
         p.pad = -1;
         p.dbg = m.dbg;
         p.terms = m.terms;
+        p.wscale = a.spade_wscale;
+        p.in_scale_inv = 1.f / a.actv_scale;
+        p.out_scale = SH16_ACT_SCALE;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
               4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
@@ -496,6 +563,8 @@ struct Runner {
         p.pad = -1;
         p.dbg = m.dbg;
         p.terms = m.terms;
+        p.wscale = w.wscale;                       // shared with w2's rows when a 1x1 operand is fused (build())
+        p.in_scale_inv = 1.f / SH16_ACT_SCALE;     // inputs are ACE outputs
         p.partial = m.splitk_ws;
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
@@ -617,6 +686,8 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             t.W = h2;
             t.Mrows = 256;
             t.bias = z10.bias;
+            t.wscale = z10_ws;
+            t.in_scale_inv = 1.f / instnorm_sh16_scale(h4 * h4);
             t.act = ACT_NONE;
             t.in_mode = IN_UP2_ZEROINS;
             ck(conv_sh16_plain(t, 3, st), "zenc convT (f16x3)");
@@ -637,6 +708,8 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             p.W = h2;
             p.Mrows = 512;
             p.bias = z14.bias;
+            p.wscale = z14_ws;
+            p.in_scale_inv = 1.f / instnorm_sh16_scale(h2 * h2);
             p.act = ACT_TANH;
             p.pad_mode = PAD_REFLECT;
             ck(conv_sh16_plain(p, 3, st), "zenc conv5 (f16x3)");

@@ -15,6 +15,7 @@ namespace chk {
 struct ConvW {
     float* wpk = nullptr;
     float* bias = nullptr;
+    float* wscale = nullptr;                    // f16x3 path: per-row 2^-k undoing the weight scaling (sh16.h)
     int Cout = 0, Cin = 0, KS = 0;
 };
 
@@ -29,6 +30,8 @@ struct AceW {
     float *fcmu_w = nullptr, *fcmu_b = nullptr;          // [19][512][512], [19][512]
     float* lut_wpk = nullptr;                   // rows (tap, gamma|beta, c) x K=512
     float* lut_rows = nullptr;                  // same rows, plain [18C][512] (GEMV path for batches <= 3)
+    float *spade_wscale = nullptr, *lut_wscale = nullptr;   // f16x3 path: per-row 2^-k of the packed rows (sh16.h)
+    float actv_scale = 1.f;                     // f16x3 path: SH16 scale of the SPADE hidden activations (from a table bound)
 };
 
 struct BlockW {
@@ -59,6 +62,7 @@ struct SeanModel {
     float* z1_w = nullptr;                             // Zencoder stem weights, unpacked (direct VALU conv)
     ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
     float *z14_sh = nullptr, *z10_sh = nullptr;        // z14 / the ConvTranspose packed for the f16x3 kernel
+    float *z14_ws = nullptr, *z10_ws = nullptr;        // their per-row inverse weight scales
     std::vector<void*> allocs;                         // everything to hipFree
     // workspace
     uint8_t* lab_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // res_div 32,16,8,4,2 (index by log2) ; [0] unused
