@@ -29,6 +29,18 @@ int fail(ch_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
     return code;
 }
+// Every entry point runs with the handle's device current and restores the caller's device on return (a process may own
+// handles on several GPUs, or keep torch's current device elsewhere).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -40,7 +52,6 @@ int ch_create(int device, ch_handle** out) {
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CH_ERR_HIP;
-    if (hipSetDevice(device) != hipSuccess) return CH_ERR_HIP;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CH_ERR_HIP;
     ch_handle* h = new (std::nothrow) ch_handle();
@@ -58,13 +69,16 @@ int ch_create(int device, ch_handle** out) {
 
 void ch_destroy(ch_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
-    (void)hipDeviceSynchronize();
-    h->sean.destroy();
-    h->shape.destroy();
-    h->color.destroy();
-    h->bisenet.destroy();
-    if (h->blend_ws) (void)hipFree(h->blend_ws);
+    {
+        DeviceGuard g(h->device);
+        (void)hipDeviceSynchronize();
+        h->sean.destroy();
+        h->shape.destroy();
+        h->color.destroy();
+        h->bisenet.destroy();
+        if (h->blend_ws) (void)hipFree(h->blend_ws);
+        h->blend_ws = nullptr;
+    }
     delete h;
 }
 
@@ -96,7 +110,7 @@ int ch_load_tensor(ch_handle* h, int model, const char* name, const void* host, 
 int ch_finalize(ch_handle* h, int model, int max_batch, int max_size) {
     if (!h) return CH_ERR_ARG;
     if (model < 0 || model > CH_MODEL_BISENET) return fail(h, CH_ERR_ARG, "unknown model id");
-    if (hipSetDevice(h->device) != hipSuccess) return fail(h, CH_ERR_HIP, "hipSetDevice failed");
+    DeviceGuard guard(h->device);
     if (model != CH_MODEL_SEAN) {
         try {
             std::string e;
@@ -136,6 +150,7 @@ int ch_sean_generate(ch_handle* h, const uint8_t* labels, const float* codes, co
     if (!h) return CH_ERR_ARG;
     if (!h->sean_ready) return fail(h, CH_ERR_STATE, "ch_sean_generate: SEAN weights not finalized");
     if (!labels || !codes || !out) return fail(h, CH_ERR_ARG, "ch_sean_generate: null pointer");
+    DeviceGuard guard(h->device);
     try {
         std::string e = h->sean.generate(labels, codes, noise, seed, out, B, S, static_cast<hipStream_t>(stream));
         if (!e.empty()) return fail(h, CH_ERR_HIP, "ch_sean_generate: " + e);
@@ -150,6 +165,7 @@ int ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float*
     if (!h) return CH_ERR_ARG;
     if (!h->sean_ready) return fail(h, CH_ERR_STATE, "ch_sean_encode: SEAN weights not finalized");
     if (!img || !labels || !codes || B < 1) return fail(h, CH_ERR_ARG, "ch_sean_encode: bad argument");
+    DeviceGuard guard(h->device);
     try {
         std::string e = h->sean.encode(img, labels, codes, B, S, static_cast<hipStream_t>(stream));
         if (!e.empty()) return fail(h, CH_ERR_HIP, "ch_sean_encode: " + e);
@@ -161,6 +177,7 @@ int ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float*
 
 #define CH_CALL(name, expr)                                                             \
     if (!h) return CH_ERR_ARG;                                                          \
+    DeviceGuard guard(h->device);                                                       \
     try {                                                                               \
         std::string e = (expr);                                                         \
         if (!e.empty()) return fail(h, e.find("not finalized") != std::string::npos ? CH_ERR_STATE : CH_ERR_HIP, \
@@ -208,7 +225,7 @@ int ch_blend_mask(ch_handle* h, const uint8_t* target_parsing, const uint8_t* fa
                   ch_stream_t stream) {
     if (!h) return CH_ERR_ARG;
     if (!target_parsing || !face_parsing || !out || H < 1 || W < 1) return fail(h, CH_ERR_ARG, "ch_blend_mask: bad argument");
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     hipError_t e = chk::blend_mask(target_parsing, face_parsing, out, H, W, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? CH_OK : fail(h, CH_ERR_HIP, std::string("ch_blend_mask: ") + hipGetErrorString(e));
 }
@@ -218,7 +235,7 @@ int ch_poisson_blend(ch_handle* h, const uint8_t* source, const uint8_t* target,
     if (!h) return CH_ERR_ARG;
     if (!source || !target || !mask || !out || H < 3 || W < 3 || max_iters < 0 || !(rel_tol >= 0.0))
         return fail(h, CH_ERR_ARG, "ch_poisson_blend: bad argument (images need H, W >= 3)");
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     const size_t need = chk::poisson_workspace_bytes(H, W);
     if (need > h->blend_ws_bytes) {
         if (h->blend_ws) (void)hipFree(h->blend_ws);
@@ -236,6 +253,22 @@ int ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr) {
     if (!h || !name) return CH_ERR_ARG;
     if (dev_ptr) h->sean.taps[name] = dev_ptr;
     else h->sean.taps.erase(name);
+    return CH_OK;
+}
+
+int ch_sean_scale_report(ch_handle* h, float* host_out, int n) {
+    if (!h || !host_out || n < 0) return CH_ERR_ARG;
+    if (!h->sean_ready || !h->sean.amax_slots) return fail(h, CH_ERR_STATE, "ch_sean_scale_report: SEAN weights not finalized");
+    DeviceGuard guard(h->device);
+    unsigned raw[64];
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(raw, h->sean.amax_slots, sizeof raw, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(h, CH_ERR_HIP, "ch_sean_scale_report: device read failed");
+    for (int i = 0; i < n; ++i) {
+        float v = 0.f;
+        if (i < 64) std::memcpy(&v, &raw[i], 4);
+        host_out[i] = v;
+    }
     return CH_OK;
 }
 

@@ -77,10 +77,17 @@ struct ConvParams {
     int Cin2;
     int terms;              // f16 MFMA path: 0/3 = three-term split operands (f32-class), 1 = hi halves only (f16 operands)
     // f16 MFMA path scaling (sh16.h): accumulators hold sum (w * 2^k[row]) * (x * s_in); the epilogue multiplies them by
-    // wscale[row] * in_scale_inv = 2^-k[row] / s_in (exact powers of two) and writes SH16 outputs multiplied by out_scale
-    const float* wscale;    // [GEMM rows] 2^-k per packed weight row (null = 1)
-    float in_scale_inv;     // 1 / (scale of the SH16 input tensor(s)); 0 = 1
-    float out_scale;        // EPI_ACE: scale of the SH16 output tensor; 0 = 1
+    // wscale[row] / s_in (exact powers of two).  s_in = 1 / in_scale_inv, times the dynamic factor of the input's slot.
+    const float* wscale;    // [GEMM rows] 2^-k per packed weight row (EPI_ACE: uniform per 64-row wave tile); null = 1
+    float in_scale_inv;     // 1 / (first-pass scale of the SH16 input tensor(s)); 0 = 1
+    float out_scale;        // EPI_ACE: first-pass scale of the SH16 output tensor; 0 = 1
+    float out_mul;          // EPI_PLAIN: extra power of two applied to the conv term (the style LUT is stored pre-multiplied
+                            // by the ACE output scale); 0 = 1
+    const unsigned* in_amax;    // device slot with the recorded max of `in` (sh16_dyn_extra), null = static scale
+    const unsigned* in2_amax;   // same for `in2`
+    unsigned* out_amax;     // EPI_ACE: slot receiving max |out * out_scale| (pass 0) / deciding the rescue (pass 1)
+    int pass;               // EPI_ACE: 0 = write with out_scale and record the maximum; 1 = return unless the recorded
+                            // maximum left the window, else rewrite with the corrected scale
     int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over the persistent kernel)
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
     // EPI_NHWC

@@ -18,6 +18,8 @@
 // Block = 256 threads = 4 waves, all on the same 64 GEMM rows (A fragments are shared through L1), each wave 128 px:
 // block tile 64 rows x 512 px; 8 f32 accumulators (32x32) per wave; 24 MFMAs per k-step per wave.
 #pragma once
+#include <type_traits>
+
 #include "conv_mfma.h"
 #include "sh16.h"
 
@@ -42,15 +44,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // ACE modulation of 4 consecutive channels of one pixel, written on float2 pairs so that the arithmetic maps onto the
-// packed-f32 VALU ops (v_pk_add/mul/fma_f32) and v_cvt_pk_f16_f32: o = act((a*x + n*nz + d) * (1 + gamma) + beta) with
-// gamma = acc_g * sc_g + (bias_g + style_g), beta likewise (sc = 2^-k[row] / s_in undoes the operand scaling, sh16.h);
-// act = max(o, slope*o) (slope 1 / 0.2 / 0 = none / leaky / relu).  The result is scaled by the output tensor's power of
-// two `osc`, clamped to the finite f16 range and split: returns the f16 hi halves in .x/.y and the residual lo halves in
-// .z/.w (two channels per dword).
+// packed-f32 VALU ops (v_pk_add/mul/fma_f32) and v_cvt_pk_f16_f32:
+//      o = s_out * act((a*x + n*nz + d) * (1 + gamma) + beta),   act = max(o, slope*o)  (slope 1 / 0.2 / 0)
+// The output scale s_out (sh16.h) costs nothing: the caller passes st = 2^-k / s_in * s_out (the accumulator scale, one
+// scalar per wave tile) and bg = s_out * (1 + bias_g + style_g), bb = s_out * (bias_b + style_b), so that
+// gamma' = acc_g * st + bg and beta' = acc_b * st + bb are already s_out * (1 + gamma) and s_out * beta.  RESC (second
+// pass of a tensor whose maximum left the f16 window): one more multiply by the corrective power of two.  !RESC: the
+// running max |o| is kept in `amax`.  f32 -> f16 conversions saturate (MODE.FP16_OVFL, set at kernel entry).
+// Returns the f16 hi halves in .x/.y and the residual lo halves in .z/.w (two channels per dword).
+template <bool RESC>
 __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3, float b0, float b1, float b2, float b3,
-                                          const float4& bg, const float4& bb, const float4& pa, const float4& pd,
-                                          const float4& pn, const float4& sg, const float4& sb, const float4& x4, float nz,
-                                          float slope_osc, float osc) {
+                                          float st, const float4& bg, const float4& bb, const float4& pa, const float4& pd,
+                                          const float4& pn, const float4& x4, float nz, float slope, float extra, float& amax) {
     uint4 w;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -58,15 +63,15 @@ __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3
         const f32x2 vbg = h ? f32x2{bg.z, bg.w} : f32x2{bg.x, bg.y}, vbb = h ? f32x2{bb.z, bb.w} : f32x2{bb.x, bb.y};
         const f32x2 va = h ? f32x2{pa.z, pa.w} : f32x2{pa.x, pa.y}, vd = h ? f32x2{pd.z, pd.w} : f32x2{pd.x, pd.y};
         const f32x2 vn = h ? f32x2{pn.z, pn.w} : f32x2{pn.x, pn.y}, vx = h ? f32x2{x4.z, x4.w} : f32x2{x4.x, x4.y};
-        const f32x2 vsg = h ? f32x2{sg.z, sg.w} : f32x2{sg.x, sg.y}, vsb = h ? f32x2{sb.z, sb.w} : f32x2{sb.x, sb.y};
-        const f32x2 gam1 = ag * vsg + (vbg + 1.f);
-        const f32x2 bet = ab * vsb + vbb;
+        const f32x2 gam1 = ag * st + vbg;
+        const f32x2 bet = ab * st + vbb;
         const f32x2 nrm = va * vx + (vn * nz + vd);
         f32x2 o = nrm * gam1 + bet;
-        const f32x2 os = o * slope_osc;
-        o = o * osc;
-        o.x = __builtin_amdgcn_fmed3f(fmaxf(o.x, os.x), -SH16_MAX, SH16_MAX);
-        o.y = __builtin_amdgcn_fmed3f(fmaxf(o.y, os.y), -SH16_MAX, SH16_MAX);
+        const f32x2 os = o * slope;
+        o.x = fmaxf(o.x, os.x);
+        o.y = fmaxf(o.y, os.y);
+        if (RESC) o = o * extra;
+        else amax = fmaxf(fmaxf(amax, fabsf(o.x)), fabsf(o.y));       // v_max3_f32 with |.| source modifiers
         const f16x2 hh = __builtin_convertvector(o, f16x2);
         const f32x2 lo = o - __builtin_convertvector(hh, f32x2);
         const f16x2 ll = __builtin_convertvector(lo, f16x2);
@@ -74,6 +79,17 @@ __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3
         else        { w.y = __builtin_bit_cast(unsigned, hh); w.w = __builtin_bit_cast(unsigned, ll); }
     }
     return w;
+}
+
+// scale of the accumulators of an SH16 conv: 1 / s_in, with s_in = first-pass scale x dynamic factor of the input's slot
+__device__ __forceinline__ float sh16_in_scale_inv(const ConvParams& p) {
+    float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
+    if (p.in_amax) {
+        float e = sh16_dyn_extra(*p.in_amax);
+        if (p.in2_amax) e = fminf(e, sh16_dyn_extra(*p.in2_amax));   // fused second operand: both are brought to the smaller scale
+        isi /= e;
+    }
+    return isi * (p.out_mul != 0.f ? p.out_mul : 1.f);
 }
 
 __device__ __forceinline__ float act_slope(int act) { return act == ACT_NONE ? 1.f : (act == ACT_LRELU ? 0.2f : 0.f); }
@@ -94,8 +110,8 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
     // Per-channel parameters are loaded ONCE per wave as float4 (a lane's 16 rows are 4 runs of 4 consecutive
     // channels), not per pixel: the per-(pixel,row) scalar loads were ~3/4 of the epilogue's VMEM instructions.
     const int hi = lane >> 5, col = lane & 31;
-    const float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
     if (EPI == EPI_PLAIN) {
+        const float isi = sh16_in_scale_inv(p);
         // f32 outputs of these convs use the "C4" layout [B][C/4][H][W][4]: a lane's 4 consecutive rows of one pixel are
         // one float4, lanes run along x -> 512 contiguous bytes per half-wave store (and per residual load).
         // Loop order: channel run (m, rq) outer, so that only one run's bias / scale float4 pair is live.
@@ -199,7 +215,10 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
             labs[n] = lv;
         }
         // Addressing: wave-uniform 64-bit bases (sample b0) + 32-bit per-lane byte offsets.
-        const float osc = p.out_scale != 0.f ? p.out_scale : 1.f, slope_osc = act_slope(p.act) * osc;
+        const float osc = p.out_scale != 0.f ? p.out_scale : 1.f, slope = act_slope(p.act);
+        const float st = (p.wscale ? p.wscale[mtile64 * 64] : 1.f) * (p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f) * osc;
+        const float extra = p.pass == 1 ? sh16_dyn_extra(*p.out_amax) : 1.f;
+        float amax = 0.f;
         const int xHW = xW * xH;
         const char* xbase = reinterpret_cast<const char*>(p.x) + (long long)b0 * (C >> 2) * xHW * 16;
         char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
@@ -213,57 +232,64 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
             oo_[n] = ((tb * Go * 2 + hi) * (unsigned)HW + (unsigned)py_[n] * p.W + (unsigned)px_[n]) * 16u;
         }
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto body = [&](auto resc) {
+            constexpr bool RESC = decltype(resc)::value;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int g = mtile64 * 4 + rq;                  // output channel group (8 channels)
-            const int c0 = g * 8 + 4 * hi;                   // this lane's 4 consecutive channels (C % 4 == 0)
-            if (g >= Go) continue;
-            const bool cok = c0 < C;
-            const int cc = cok ? c0 : 0;
-            const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + cc);
-            const float4 pb = *reinterpret_cast<const float4*>(p.bias_b + cc);
-            const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + cc);
-            const float4 pd = *reinterpret_cast<const float4*>(p.bn_d + cc);
-            const float4 pn = *reinterpret_cast<const float4*>(p.nv + cc);
-            // GEMM rows of channel c: gamma at (c/32)*64 + c%32, beta 32 rows further
-            float4 wsg = make_float4(isi, isi, isi, isi), wsb = wsg;
-            if (p.wscale) {
-                const float* wr = p.wscale + (cc >> 5) * 64 + (cc & 31);
-                const float4 tg = *reinterpret_cast<const float4*>(wr), tb4 = *reinterpret_cast<const float4*>(wr + 32);
-                wsg = make_float4(tg.x * isi, tg.y * isi, tg.z * isi, tg.w * isi);
-                wsb = make_float4(tb4.x * isi, tb4.y * isi, tb4.z * isi, tb4.w * isi);
-            }
+            for (int rq = 0; rq < 4; ++rq) {
+                const int g = mtile64 * 4 + rq;                  // output channel group (8 channels)
+                const int c0 = g * 8 + 4 * hi;                   // this lane's 4 consecutive channels (C % 4 == 0)
+                if (g >= Go) continue;
+                const bool cok = c0 < C;
+                const int cc = cok ? c0 : 0;
+                float4 pg = *reinterpret_cast<const float4*>(p.bias_g + cc);
+                float4 pb = *reinterpret_cast<const float4*>(p.bias_b + cc);
+                const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + cc);
+                const float4 pd = *reinterpret_cast<const float4*>(p.bn_d + cc);
+                const float4 pn = *reinterpret_cast<const float4*>(p.nv + cc);
+                // the output scale is folded into the constants (the style LUT is stored pre-multiplied by it)
+                pg = make_float4((pg.x + 1.f) * osc, (pg.y + 1.f) * osc, (pg.z + 1.f) * osc, (pg.w + 1.f) * osc);
+                pb = make_float4(pb.x * osc, pb.y * osc, pb.z * osc, pb.w * osc);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (pb_[n] < 0) continue;
-                const unsigned tb = (unsigned)(pb_[n] - b0);
-                float4 sg = z4, sb = z4;
-                if (p.lut) {
-                    // style term: sum over the 9 taps of LUT[(sample, label at the tap)][tap]; taps outside the image carry
-                    // label 19, the all-zero column.  32-bit offsets from a wave-uniform base.
-                    const unsigned cb = tb * (unsigned)p.lut_bs * lns + (unsigned)cc * lrs;
-                    const unsigned lo30 = (unsigned)labs[n], hi15 = (unsigned)(labs[n] >> 30);
+                for (int n = 0; n < 4; ++n) {
+                    if (pb_[n] < 0) continue;
+                    const unsigned tb = (unsigned)(pb_[n] - b0);
+                    float4 sg = z4, sb = z4;
+                    if (p.lut) {
+                        // style term: sum over the 9 taps of LUT[(sample, label at the tap)][tap]; taps outside the image
+                        // carry label 19, the all-zero column.  32-bit offsets from a wave-uniform base.
+                        const unsigned cb = tb * (unsigned)p.lut_bs * lns + (unsigned)cc * lrs;
+                        const unsigned lo30 = (unsigned)labs[n], hi15 = (unsigned)(labs[n] >> 30);
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const unsigned j = t < 6 ? (lo30 >> (5 * t)) & 31u : (hi15 >> (5 * (t - 6))) & 31u;
-                        const unsigned o1 = cb + j * lns + (unsigned)(t * 2 * C) * lrs;
-                        const float4 g4 = *reinterpret_cast<const float4*>(lbase + o1);
-                        const float4 b4 = *reinterpret_cast<const float4*>(lbase + (o1 + (unsigned)C * lrs));
-                        sg.x += g4.x; sg.y += g4.y; sg.z += g4.z; sg.w += g4.w;
-                        sb.x += b4.x; sb.y += b4.y; sb.z += b4.z; sb.w += b4.w;
+                        for (int t = 0; t < 9; ++t) {
+                            const unsigned j = t < 6 ? (lo30 >> (5 * t)) & 31u : (hi15 >> (5 * (t - 6))) & 31u;
+                            const unsigned o1 = cb + j * lns + (unsigned)(t * 2 * C) * lrs;
+                            const float4 g4 = *reinterpret_cast<const float4*>(lbase + o1);
+                            const float4 b4 = *reinterpret_cast<const float4*>(lbase + (o1 + (unsigned)C * lrs));
+                            sg.x += g4.x; sg.y += g4.y; sg.z += g4.z; sg.w += g4.w;
+                            sb.x += b4.x; sb.y += b4.y; sb.z += b4.z; sb.w += b4.w;
+                        }
                     }
+                    // x in the C4 layout [B][C/4][h][w][4]: this lane's 4 channels of the pixel are one float4
+                    const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo_[n] + (unsigned)(cc >> 2) * xHW * 16u));
+                    const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
+                    const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
+                    uint4 w = ace_quad<RESC>(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
+                                             acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
+                                             st, bg, bb, pa, pd, pn, x4, nzv[n], slope, extra, amax);
+                    if (!cok) w = make_uint4(0, 0, 0, 0);            // padding channels of the last group hold zeros
+                    *reinterpret_cast<uint4*>(obase + (oo_[n] + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
                 }
-                // x in the C4 layout [B][C/4][h][w][4]: this lane's 4 channels of the pixel are one float4
-                const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo_[n] + (unsigned)(cc >> 2) * xHW * 16u));
-                const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
-                const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
-                uint4 w = ace_quad(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
-                                   acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
-                                   bg, bb, pa, pd, pn, wsg, wsb, x4, nzv[n], slope_osc, osc);
-                if (!cok) w = make_uint4(0, 0, 0, 0);            // padding channels of the last group hold zeros
-                *reinterpret_cast<uint4*>(obase + (oo_[n] + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (p.pass == 1) {
+            body(std::true_type{});
+        } else {
+            body(std::false_type{});
+            if (p.out_amax) {
+                amax = sh16_wave_max(amax);
+                if (lane == 0) atomicMax(p.out_amax, __float_as_uint(amax));
+            }
         }
     }
 }
@@ -277,6 +303,10 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, NLOAD = Cfg::NLOAD, HALO = Cfg::HALO;
     constexpr int NT = KS * KS;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+    if constexpr (EPI == EPI_ACE) {
+        sh16_mode_on();                                      // saturating f32 -> f16 conversions in the epilogue
+        if (p.pass == 1 && sh16_dyn_extra(*p.out_amax) == 1.f) return;   // second pass: nothing to repair (the normal case)
+    }
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int mtile64 = L % p.mtiles;
@@ -337,6 +367,22 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
         }
     }
+    // FUSE: the two inputs share the accumulators, so they must carry the same scale.  Their first-pass scales are equal
+    // by construction; if a second pass changed one of them (sh16.h), the other operand's units are multiplied down to
+    // the smaller scale while they are staged (exact power of two; wave-uniform, false in the normal case).
+    float mul1 = 1.f, mul2 = 1.f;
+    if constexpr (FUSE) {
+        if (p.in_amax && p.in2_amax) {
+            const float e1 = sh16_dyn_extra(*p.in_amax), e2 = sh16_dyn_extra(*p.in2_amax), e = fminf(e1, e2);
+            mul1 = e / e1;
+            mul2 = e / e2;
+        }
+    }
+    auto rescale = [&](uint4 (&stg)[NLOAD], float f) {
+        const half8 fv = {(_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f};
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) stg[i] = __builtin_bit_cast(uint4, __builtin_bit_cast(half8, stg[i]) * fv);
+    };
     auto stage = [&](int chunk, int buf) {
         // No scheduling fence in here on purpose: the compiler issues these loads early and sinks the LDS writes
         // below the chunk's MFMAs as far as registers allow, which is what overlaps staging with compute.
@@ -344,6 +390,9 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         const uint4* src = gin + (long long)chunk * 4 * HWi;      // 2 groups x (hi, lo) planes per chunk
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+        if constexpr (FUSE) {
+            if (mul1 != 1.f) rescale(stg, mul1);
+        }
         uint4* dst = smem_u + buf * UNITS;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
@@ -363,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         const uint4* src = gin2 + (long long)chunk * 4 * HW;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+        if (mul2 != 1.f) rescale(stg, mul2);
         uint4* dst = smem_u + buf * UNITS;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
@@ -483,16 +533,20 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     constexpr int NLD = (UNITS + 255) / 256;                 // units per loader thread per chunk
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
     // LDS map (16-byte units): 2 stages of [input patch UNITS | A fragments AUNITS], then (ACE) the epilogue's small
-    // operands [par: 8 runs x 7 float4][nz: 512 f32][lab: TB*(TH+2)*(TW+2) bytes].  The A fragments of a chunk are one
+    // operands [par: 8 runs x 5 float4][nz: 512 f32][lab: TB*(TH+2)*(TW+2) bytes].  The A fragments of a chunk are one
     // contiguous, already lane-ordered block in global memory: the loaders move it with LDS-DMA (global_load_lds, 16 B
     // per lane, no VGPR round trip), so the consumers' MFMA stream never waits on an L2 round trip.
     constexpr int AUNITS = NT * 4 * 64, STAGE = UNITS + AUNITS;
-    constexpr int NPAR = 7;                                  // float4 per channel run: bias_g, bias_b, bn_a, bn_d, nv, sc_g, sc_b
+    constexpr int NPAR = 5;                                  // float4 per channel run: s(1+bias_g), s*bias_b, bn_a, bn_d, nv
     constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + 8 * NPAR, LAB0 = NZ0 + 128;
     constexpr int NDA = AUNITS / 256;                        // A DMA instructions per loader thread per chunk
     constexpr int LW = TW + 2, LH = TH + 2;
     constexpr bool pre = EPI == EPI_ACE;    /* host guarantees nchunks >= 3 */       // epilogue operands prefetched through LDS
 
+    if constexpr (EPI == EPI_ACE) {
+        sh16_mode_on();                                      // saturating f32 -> f16 conversions in the epilogue
+        if (p.pass == 1 && sh16_dyn_extra(*p.out_amax) == 1.f) return;   // second pass: nothing to repair (the normal case)
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave >= 4;
     const int wn = wave & 3, ltid = tid & 255;
@@ -582,18 +636,13 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             const int C = p.C;
             if (ltid < 8 * NPAR) {                                        // par[run][which]
                 const int run = ltid / NPAR, which = ltid % NPAR;
-                const int c0 = (mt * 8 + run) * 4, cc = c0 < C ? c0 : 0;
-                if (which < 5) {
-                    const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
-                    parr = *reinterpret_cast<const float4*>(src + cc);
-                } else {                                                  // operand-scaling undo: 2^-k[row] / s_in (sh16.h)
-                    const float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
-                    parr = make_float4(isi, isi, isi, isi);
-                    if (p.wscale) {
-                        const float4 t = *reinterpret_cast<const float4*>(p.wscale + (cc >> 5) * 64 + (which - 5) * 32 + (cc & 31));
-                        parr = make_float4(t.x * isi, t.y * isi, t.z * isi, t.w * isi);
-                    }
-                }
+                const int c0 = (mt * 8 + run) * 4;
+                const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
+                parr = *reinterpret_cast<const float4*>(src + (c0 < C ? c0 : 0));
+                // the output scale is folded into the constants: s * (1 + bias_g), s * bias_b (ace_quad)
+                const float osc = p.out_scale != 0.f ? p.out_scale : 1.f;
+                if (which == 0) parr = make_float4((parr.x + 1.f) * osc, (parr.y + 1.f) * osc, (parr.z + 1.f) * osc, (parr.w + 1.f) * osc);
+                if (which == 1) parr = make_float4(parr.x * osc, parr.y * osc, parr.z * osc, parr.w * osc);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -675,6 +724,8 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     }
     __syncthreads();                                          // stage 0 ready
     int q = 0;
+    float amax = 0.f;                                         // running max |out * out_scale| of this wave (ACE, pass 0)
+    const float extra = (pre && p.pass == 1) ? sh16_dyn_extra(*p.out_amax) : 1.f;
     for (int k = 0; k < my_tiles; ++k) {
         int mtile64, x0, y0, b0;
         tile_coords(k, mtile64, x0, y0, b0);
@@ -743,59 +794,71 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0);
             const float* nzs = reinterpret_cast<const float*>(smem_u + NZ0);
             const uint8_t* labs8 = reinterpret_cast<const uint8_t*>(smem_u + LAB0);
-            const float osc = p.out_scale != 0.f ? p.out_scale : 1.f, slope_osc = act_slope(p.act) * osc;
+            const float slope = act_slope(p.act);
+            const float st = (p.wscale ? p.wscale[mtile64 * 64] : 1.f) * (p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f) *
+                             (p.out_scale != 0.f ? p.out_scale : 1.f);
             char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
             const unsigned lrs = (unsigned)p.lut_rs * 4u, lns = (unsigned)p.lut_ns * 4u;
             const char* lbase = reinterpret_cast<const char*>(p.lut) + (long long)b0 * p.lut_bs * lns;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto body = [&](auto resc) {
+                constexpr bool RESC = decltype(resc)::value;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int idx = wn * 128 + n * 32 + col;
-                const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-                const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
-                if (b >= p.B || y >= p.H || x >= p.W) continue;
-                const float nz = nzs[idx];
-                const uint8_t* lp = labs8 + tb * (LH * LW) + ty * LW + tx;      // 3x3 neighbourhood origin
-                unsigned loff[9];                 // per-tap byte offset of (sample, label) column + tap row block
-                if (p.lut) {
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const unsigned j = lp[(t / 3) * LW + (t % 3)];          // 255 outside the image -> zero column 19
-                        loff[t] = ((unsigned)tb * (unsigned)p.lut_bs + (j < 19u ? j : 19u)) * lns + (unsigned)(t * 2 * C) * lrs;
-                    }
-                }
-                const unsigned oo = (((unsigned)tb * Go * 2 + hi) * (unsigned)HW + (unsigned)y * p.W + (unsigned)x) * 16u;
-                const unsigned xo = ((unsigned)tb * (unsigned)(C >> 2) * xHW + (unsigned)(y >> p.x_up) * xW + (unsigned)(x >> p.x_up)) * 16u;
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int g = mtile64 * 4 + rq, run = rq * 2 + hi, c0 = g * 8 + 4 * hi;
-                    if (g >= Go) continue;
-                    const bool cok = c0 < C;
-                    const unsigned cc = cok ? c0 : 0;
-                    const float4 pg = par[run * NPAR + 0], pb = par[run * NPAR + 1], pa = par[run * NPAR + 2],
-                                 pd = par[run * NPAR + 3], pn = par[run * NPAR + 4], wsg = par[run * NPAR + 5],
-                                 wsb = par[run * NPAR + 6];
-                    const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo + (cc >> 2) * (unsigned)xHW * 16u));
-                    float4 sg = z4, sb = z4;
+                for (int n = 0; n < 4; ++n) {
+                    const int idx = wn * 128 + n * 32 + col;
+                    const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+                    const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
+                    if (b >= p.B || y >= p.H || x >= p.W) continue;
+                    const float nz = nzs[idx];
+                    const uint8_t* lp = labs8 + tb * (LH * LW) + ty * LW + tx;      // 3x3 neighbourhood origin
+                    unsigned loff[9];                 // per-tap byte offset of (sample, label) column + tap row block
                     if (p.lut) {
 #pragma unroll
                         for (int t = 0; t < 9; ++t) {
-                            const unsigned o1 = loff[t] + cc * lrs;
-                            const float4 g4 = *reinterpret_cast<const float4*>(lbase + o1);
-                            const float4 b4 = *reinterpret_cast<const float4*>(lbase + (o1 + (unsigned)C * lrs));
-                            sg.x += g4.x; sg.y += g4.y; sg.z += g4.z; sg.w += g4.w;
-                            sb.x += b4.x; sb.y += b4.y; sb.z += b4.z; sb.w += b4.w;
+                            const unsigned j = lp[(t / 3) * LW + (t % 3)];          // >= 19 (255 outside the image) -> zero column 19
+                            loff[t] = ((unsigned)tb * (unsigned)p.lut_bs + (j < 19u ? j : 19u)) * lns + (unsigned)(t * 2 * C) * lrs;
                         }
                     }
-                    const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
-                    const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
-                    uint4 w = ace_quad(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
-                                       acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
-                                       bg, bb, pa, pd, pn, wsg, wsb, x4, nz, slope_osc, osc);
-                    if (!cok) w = make_uint4(0, 0, 0, 0);
-                    *reinterpret_cast<uint4*>(obase + (oo + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
+                    const unsigned oo = (((unsigned)tb * Go * 2 + hi) * (unsigned)HW + (unsigned)y * p.W + (unsigned)x) * 16u;
+                    const unsigned xo = ((unsigned)tb * (unsigned)(C >> 2) * xHW + (unsigned)(y >> p.x_up) * xW + (unsigned)(x >> p.x_up)) * 16u;
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int g = mtile64 * 4 + rq, run = rq * 2 + hi, c0 = g * 8 + 4 * hi;
+                        if (g >= Go) continue;
+                        const bool cok = c0 < C;
+                        const unsigned cc = cok ? c0 : 0;
+                        const float4 pg = par[run * NPAR + 0], pb = par[run * NPAR + 1], pa = par[run * NPAR + 2],
+                                     pd = par[run * NPAR + 3], pn = par[run * NPAR + 4];
+                        const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo + (cc >> 2) * (unsigned)xHW * 16u));
+                        float4 sg = z4, sb = z4;
+                        if (p.lut) {
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) {
+                                const unsigned o1 = loff[t] + cc * lrs;
+                                const float4 g4 = *reinterpret_cast<const float4*>(lbase + o1);
+                                const float4 b4 = *reinterpret_cast<const float4*>(lbase + (o1 + (unsigned)C * lrs));
+                                sg.x += g4.x; sg.y += g4.y; sg.z += g4.z; sg.w += g4.w;
+                                sb.x += b4.x; sb.y += b4.y; sb.z += b4.z; sb.w += b4.w;
+                            }
+                        }
+                        const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
+                        const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
+                        uint4 w = ace_quad<RESC>(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
+                                                 acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
+                                                 st, bg, bb, pa, pd, pn, x4, nz, slope, extra, amax);
+                        if (!cok) w = make_uint4(0, 0, 0, 0);
+                        *reinterpret_cast<uint4*>(obase + (oo + (unsigned)g * 2u * (unsigned)HW * 16u)) = sh16_pair_swap(w);
+                    }
                 }
-            }
+            };
+            if (p.pass == 1) body(std::true_type{});
+            else body(std::false_type{});
+        }
+    }
+    if constexpr (pre) {
+        if (p.pass != 1 && p.out_amax) {                       // one atomic per consumer wave per launch
+            amax = sh16_wave_max(amax);
+            if (lane == 0) atomicMax(p.out_amax, __float_as_uint(amax));
         }
     }
 }
@@ -807,7 +870,7 @@ hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
-    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 56 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
+    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
                                           : 2 * V3_STAGE * 16;
     static bool attr_set = false;
     static int ncu = 256;
@@ -847,7 +910,7 @@ __global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
         }
         const int cg = (int)((i / HW) % C4n);
         {   // undo the operand scaling (sh16.h): 2^-k[row] / s_in
-            const float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
+            const float isi = sh16_in_scale_inv(p);
             float4 s4 = make_float4(isi, isi, isi, isi);
             if (p.wscale) {
                 const float4 t = *reinterpret_cast<const float4*>(p.wscale + cg * 4);

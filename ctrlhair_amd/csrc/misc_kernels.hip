@@ -35,6 +35,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // [B][C/8][2][HW][8] of conv_sh16.h (plane index = b*C + c), feeding the f16x3 conv directly.
 __global__ __launch_bounds__(256) void instnorm_act_kernel(float* __restrict__ x, int HW, float eps, int act,
                                                            _Float16* __restrict__ sh16, int C, float scale) {
+    sh16_mode_on();
     __shared__ float red[4];
     float* p = x + (long long)blockIdx.x * HW;
     float s = 0.f;
@@ -78,6 +79,7 @@ __device__ __forceinline__ float block_sum1024(float v, float* red) {
 
 __global__ __launch_bounds__(1024) void instnorm_act_wide_kernel(float* __restrict__ x, int HW, float eps, int act,
                                                                  _Float16* __restrict__ sh16, int C, float scale) {
+    sh16_mode_on();
     __shared__ float red[16];
     float4* p4 = reinterpret_cast<float4*>(x + (long long)blockIdx.x * HW);
     const int n4 = HW >> 2;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(1024) void instnorm_act_wide_kernel(float* __restri
 // units (8 channels of one pixel, hi plane and lo plane) instead of 2-byte elements 16 bytes apart from 8 different blocks.
 __global__ __launch_bounds__(1024) void instnorm_act_sh16_kernel(const float* __restrict__ x, int HW, float eps, int act,
                                                                  uint4* __restrict__ sh16, int C, float scale) {
+    sh16_mode_on();
     typedef _Float16 half8v __attribute__((ext_vector_type(8)));
     __shared__ float red[16];
     __shared__ float mean_s[8], rstd_s[8];
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(1024) void instnorm_act_sh16_kernel(const float* __
 // Same, input in the C4 layout [B][C/4][HW][4] (output of an f16x3 conv): a block's 8 channels are two float4 per pixel.
 __global__ __launch_bounds__(1024) void instnorm_c4_sh16_kernel(const float4* __restrict__ x, int HW, float eps, int act,
                                                                 uint4* __restrict__ sh16, int C, float scale) {
+    sh16_mode_on();
     typedef _Float16 half8v __attribute__((ext_vector_type(8)));
     __shared__ float red[16];
     __shared__ float mean_s[8], rstd_s[8];

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
     // that hold different labels do not collide on the same banks) and one extra all-zero row that taps outside the image
     // point at -- every lane then issues the same 9 x 2 ds_read_b128 per 8 channels, no predication.
     constexpr int RS = OH_KC + 4, ZROW = 19 * 9;
+    sh16_mode_on();       // (the scale comes from a bound of the table sums: nothing can saturate; kept for uniformity)
     __shared__ __attribute__((aligned(16))) float T[(ZROW + 1) * RS];
     __shared__ __attribute__((aligned(16))) float bs[OH_KC];
     const int k0 = blockIdx.y * OH_KC;
@@ -159,7 +160,8 @@ hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const flo
 
 // SH16 -> f32 NCHW (test taps only)
 __global__ void sh16_decode_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int B, int C, long long HW,
-                                   float inv_scale) {
+                                   float inv_scale, const unsigned* __restrict__ amax) {
+    if (amax) inv_scale /= sh16_dyn_extra(*amax);
     const long long n = (long long)B * C * HW;
     const int G = (C + 7) / 8;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -169,9 +171,10 @@ __global__ void sh16_decode_kernel(const _Float16* __restrict__ in, float* __res
         out[i] = ((float)in[unit * 8 + (c & 7)] + (float)in[(unit + HW) * 8 + (c & 7)]) * inv_scale;
     }
 }
-hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, hipStream_t s) {
+hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, const unsigned* amax,
+                       hipStream_t s) {
     hipLaunchKernelGGL(sh16_decode_kernel, dim3(4096), dim3(256), 0, s, static_cast<const _Float16*>(in), out, B, C, HW,
-                       1.f / scale);
+                       1.f / scale, amax);
     return hipGetLastError();
 }
 
@@ -198,7 +201,17 @@ constexpr int FCMU_BT = 8;
 
 __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ codes, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ mu_img, int B,
-                                                    int Npad, float* __restrict__ mu_rows, int sh16, int bs, float scale) {
+                                                    int Npad, float* __restrict__ mu_rows, int sh16, int bs, float scale,
+                                                    unsigned* __restrict__ amax, int pass) {
+    // SH16 output (f16x3 LUT GEMM): first pass writes with `scale` and records max |mu * scale|; the second pass returns
+    // at once unless that maximum left the f16 window, else rewrites with the corrected scale (sh16.h)
+    sh16_mode_on();
+    if (sh16 && amax && pass == 1) {
+        const float e = sh16_dyn_extra(*amax);
+        if (e == 1.f) return;
+        scale *= e;
+    }
+    float vmax = 0.f;
     const int j = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o0 = (blockIdx.x * 4 + wave) * 4;           // 4 output features per wave
@@ -258,18 +271,20 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
                             _Float16* mh = reinterpret_cast<_Float16*>(mu_img);
                             _Float16 h, l;
                             sh16_split(r, scale, h, l);
+                            vmax = fmaxf(vmax, r * scale);
                             mh[(((long long)(o >> 3) * 2 + 0) * Npad + n) * 8 + (o & 7)] = h;
                             mh[(((long long)(o >> 3) * 2 + 1) * Npad + n) * 8 + (o & 7)] = l;
                         } else mu_img[(long long)o * Npad + n] = r;
                     }
         }
     }
+    if (sh16 && amax && pass == 0 && lane == 0) atomicMax(amax, __float_as_uint(vmax));
 }
 
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad,
-                 hipStream_t s, float* mu_rows, int sh16, int bs, float scale) {
+                 hipStream_t s, float* mu_rows, int sh16, int bs, float scale, unsigned* amax, int pass) {
     hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad, mu_rows, sh16, bs,
-                       scale);
+                       scale, amax, pass);
     return hipGetLastError();
 }
 

@@ -215,7 +215,12 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 return w * (beta ? sb : sg);
             };
             if (use_sh16) {
-                const auto kexp = sh16_row_exponents(tiles * 64, HID, 3, getsp);
+                auto kexp = sh16_row_exponents(tiles * 64, HID, 3, getsp);
+                for (int t0 = 0; t0 < tiles * 64; t0 += 64) {     // one power of two per 64-row wave tile (a scalar in the ACE epilogue)
+                    int km = kexp[t0];
+                    for (int r = 0; r < 64; ++r) km = std::min(km, kexp[t0 + r]);
+                    for (int r = 0; r < 64; ++r) kexp[t0 + r] = km;
+                }
                 a.spade_wpk = B.upload(pack_A_sh16(tiles * 64, HID, 3, getsp, kexp));
                 a.spade_wscale = B.upload(sh16_wscale(kexp));
             } else {
@@ -261,7 +266,9 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                         const int t = row / (2 * C), gb = (row / C) & 1, cc = row % C;
                         const float* src = gb ? cbp : cgp;
                         const float al = gb ? ab : ag;
-                        for (int k = 0; k < STYLE; ++k) rows[(size_t)row * STYLE + k] = al * src[((size_t)cc * STYLE + k) * 9 + t];
+                        // f16x3 path: the ACE epilogue expects the style LUT pre-multiplied by the output scale (conv_sh16.h)
+                        const float als = use_sh16 ? al * SH16_ACT_SCALE : al;
+                        for (int k = 0; k < STYLE; ++k) rows[(size_t)row * STYLE + k] = als * src[((size_t)cc * STYLE + k) * 9 + t];
                     }
                     a.lut_rows = B.upload(rows);
                 }
@@ -318,6 +325,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         has_zencoder = true;
     }
 
+    amax_slots = static_cast<unsigned*>(B.dalloc(64 * sizeof(unsigned)));   // 2 per ACE: [output, style projections]
     splitk_cap = (long long)16 << 20;     // 64 MiB of split-K slabs (low-resolution layers only)
     splitk_ws = B.falloc((size_t)splitk_cap);
 
@@ -411,10 +419,11 @@ struct Runner {
         check(hipEventRecord(r.e1, st), "hipEventRecord");
         m.prof.push_back(r);
     }
-    void tap_sh16(const std::string& name, const float* src, int C, size_t hw) {
+    void tap_sh16(const std::string& name, const float* src, int C, size_t hw, const AceW& producer) {
         auto it = m.taps.find(name);
         if (it == m.taps.end() || !it->second) return;
-        if (m.use_sh16) check(sh16_decode(src, it->second, B, C, (long long)hw, SH16_ACT_SCALE, st), "tap decode");
+        if (m.use_sh16)
+            check(sh16_decode(src, it->second, B, C, (long long)hw, SH16_ACT_SCALE, m.amax_slots + 2 * producer.index, st), "tap decode");
         else check(hipMemcpyAsync(it->second, src, (size_t)B * C * hw * 4, hipMemcpyDeviceToDevice, st), "tap copy");
     }
     // f32 tensors between kernels are NCHW on the exact-f32 path and C4 ([B][C/4][HW][4]) on the f16x3 path
@@ -457,7 +466,9 @@ struct Runner {
                 });
             } else if (m.use_sh16) {
                 // f16x3 LUT GEMM: 1x1 conv over the [npad/32 x 32] "image" of (sample, label) columns, C4 output
-                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs, SH16_ACT_SCALE), "fc_mu");
+                unsigned* mu_slot = m.amax_slots + 2 * a.index + 1;
+                for (int pass = 0; pass < 2; ++pass)     // second pass: returns at once unless the first one left the f16 window
+                    check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs, SH16_ACT_SCALE, mu_slot, pass), "fc_mu");
                 ConvParams p{};
                 p.in = m.mu_img;
                 p.wpk = a.lut_wpk;
@@ -472,6 +483,8 @@ struct Runner {
                 p.terms = m.terms;
                 p.wscale = a.lut_wscale;
                 p.in_scale_inv = 1.f / SH16_ACT_SCALE;
+                p.in_amax = mu_slot;
+                p.out_mul = SH16_ACT_SCALE;        // the ACE epilogue takes the LUT pre-multiplied by its output scale
                 p.partial = m.splitk_ws;           // K = 512 in 32 chunks on few tiles (C <= 512): split-K fills the chip
                 p.partial_cap = m.splitk_cap;
                 timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
@@ -531,8 +544,16 @@ struct Runner {
         p.in_scale_inv = 1.f / a.actv_scale;
         p.out_scale = SH16_ACT_SCALE;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
-        timed(1, 2.0 * 2 * a.C * HID * 9 * npix,
-              4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] { check(m.use_sh16 ? conv_sh16_ace(p, st) : conv_ace(p, st), "spade conv"); });
+        p.out_amax = m.amax_slots + 2 * a.index;
+        timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] {
+            if (!m.use_sh16) {
+                check(conv_ace(p, st), "spade conv");
+                return;
+            }
+            check(conv_sh16_ace(p, st), "spade conv");
+            p.pass = 1;        // returns at once unless the recorded maximum left the f16 window (sh16.h)
+            check(conv_sh16_ace(p, st), "spade conv (second pass)");
+        });
     }
 
     // fuse: optional (weights, input) of a 1x1 conv added into this 3x3 conv's accumulators (f16x3 path, W >= 32, no split-K)
@@ -540,14 +561,17 @@ struct Runner {
         return m.use_sh16 && !(m.dbg & 32) && w.KS == 3 && r >= 32 &&
                !(((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192);
     }
-    void conv(const ConvW& w, const float* in, float* out, int r, const float* res, int res_up, const ConvW* w2 = nullptr,
-              const float* in2 = nullptr) {
+    // `prod` / `prod2`: the ACEs that wrote `in` / `in2` (their slots hold the scale in effect)
+    void conv(const ConvW& w, const float* in, const AceW& prod, float* out, int r, const float* res, int res_up,
+              const ConvW* w2 = nullptr, const float* in2 = nullptr, const AceW* prod2 = nullptr) {
         ConvParams p{};
         if (w2) {
             p.in2 = in2;
             p.wpk2 = w2->wpk;
             p.Cin2 = w2->Cin;
+            p.in2_amax = m.amax_slots + 2 * prod2->index;
         }
+        p.in_amax = m.amax_slots + 2 * prod.index;
         p.in = in;
         p.wpk = w.wpk;
         p.out = out;
@@ -599,6 +623,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             nz = noise_ws;
         }
         for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");
+        if (use_sh16) R.check(hipMemsetAsync(amax_slots, 0, 64 * sizeof(unsigned), st), "amax slots");
 
         const int sw = S / 32;
         float* x = xa;
@@ -617,11 +642,11 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             if (b.learned) {
                 R.ace(b.ace_s, lab, cd, nz, nf, noff, xsrc, up, ACT_NONE, hs);
                 noff += rr;
-                R.tap_sh16(b.name + ".hs", hs, b.fin, rr);
+                R.tap_sh16(b.name + ".hs", hs, b.fin, rr, b.ace_s);
                 // the 1x1 shortcut conv is folded into conv_1 (extra K chunks on a second input) unless a test taps its output
                 fuse_s = R.can_fuse_1x1(b.conv_1, r) && !taps.count(b.name + ".xs");
                 if (!fuse_s) {
-                    R.conv(b.conv_s, hs, xs, r, nullptr, 0);
+                    R.conv(b.conv_s, hs, b.ace_s, xs, r, nullptr, 0);
                     R.tap_c4(b.name + ".xs", xs, b.fout, rr);
                 }
                 shortcut = fuse_s ? nullptr : xs;
@@ -632,13 +657,13 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             }
             R.ace(b.ace_0, lab, cd, nz, nf, noff, xsrc, up, ACT_LRELU, h0);
             noff += rr;
-            R.tap_sh16(b.name + ".h0", h0, b.fin, rr);
-            R.conv(b.conv_0, h0, dx, r, nullptr, 0);
+            R.tap_sh16(b.name + ".h0", h0, b.fin, rr, b.ace_0);
+            R.conv(b.conv_0, h0, b.ace_0, dx, r, nullptr, 0);
             R.tap_c4(b.name + ".dx", dx, b.fmid, rr);
             R.ace(b.ace_1, lab, cd, nz, nf, noff, dx, 0, ACT_LRELU, h1);
             noff += rr;
-            R.tap_sh16(b.name + ".h1", h1, b.fmid, rr);
-            R.conv(b.conv_1, h1, y, r, shortcut, sc_up, fuse_s ? &b.conv_s : nullptr, fuse_s ? hs : nullptr);
+            R.tap_sh16(b.name + ".h1", h1, b.fmid, rr, b.ace_1);
+            R.conv(b.conv_1, h1, b.ace_1, y, r, shortcut, sc_up, fuse_s ? &b.conv_s : nullptr, fuse_s ? hs : nullptr, fuse_s ? &b.ace_s : nullptr);
             R.tap_c4(b.name, y, b.fout, rr);
             std::swap(x, y);
         }

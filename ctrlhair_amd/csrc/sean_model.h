@@ -66,6 +66,7 @@ struct SeanModel {
     std::vector<void*> allocs;                         // everything to hipFree
     // workspace
     uint8_t* lab_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // res_div 32,16,8,4,2 (index by log2) ; [0] unused
+    unsigned* amax_slots = nullptr;            // f16x3 path: recorded maxima of the dynamically scaled SH16 tensors (sh16.h)
     float *noise_ws = nullptr, *mu_img = nullptr, *lut = nullptr, *actv = nullptr;
     float *h0 = nullptr, *hs = nullptr, *dx = nullptr, *h1 = nullptr, *xs = nullptr, *xa = nullptr, *xb = nullptr;
     std::map<std::string, float*> taps;

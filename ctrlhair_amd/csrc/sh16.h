@@ -1,35 +1,62 @@
 // sh16.h -- the split-operand number format shared by every producer / consumer of SH16 tensors.
 //
 // An f32 value v of a tensor with power-of-two scale s is stored as two f16 numbers
-//      hi = f16(clamp(v*s)),   lo = f16(v*s - hi)            (clamp to the finite f16 range: no inf ever reaches an MFMA)
-// hi + lo carries 22 significand bits of v*s as long as lo is a normal f16 number, i.e. |v*s| >= 2^-3; below that the
-// absolute error is at most 2^-25 (half an f16 subnormal step).  Scales are chosen so that this floor is irrelevant:
-//   * weights: every GEMM row is scaled by its own 2^k with max|row| * 2^k in [2^14, 2^15) (host, at ch_finalize); an
-//     element 2^18 times smaller than its row's maximum still has all 22 bits, the floor is 2^-40 of the row maximum;
-//   * activations: one power-of-two scale per tensor, a bound where the producer has one (label-table sums, instance norm),
-//     otherwise a fixed 2^3 -- values in [2^-4, 8188] keep f32-class relative accuracy, larger ones saturate and are counted
-//     (ch_get_stat); the consumer's epilogue multiplies its f32 accumulators by the exact inverse 2^-k / s.
-// All scalings are by powers of two, so the represented values are the same as without scaling wherever no floor is hit.
+//      hi = f16(v*s),   lo = f16(v*s - hi)
+// converted with MODE.FP16_OVFL set (sh16_mode_on): a finite value outside the f16 range becomes +-65504 instead of inf
+// (measured on gfx950, tools/fp16_ovfl_test.hip: 70000 -> hi 65504 + lo 4496; inf and NaN are preserved), so no inf can
+// reach an MFMA from a finite activation.  hi + lo carries 22 significand bits of v*s as long as lo is a normal f16
+// number, i.e. |v*s| >= 2^-3; below that the absolute error is at most 2^-25 (half an f16 subnormal step).  Scales are
+// chosen so that this floor is irrelevant:
+//   * weights: GEMM rows are scaled by a power of two 2^k with max|row| * 2^k in [2^14, 2^15) (host, at ch_finalize; per row
+//     for the plain convs, per 64-row wave tile for the SPADE gamma/beta rows): an element 2^18 times smaller than that
+//     maximum still has all 22 bits, the floor is 2^-40 of the maximum;
+//   * activations with a bound known before they are computed (label-table sums: a table bound; instance norm: sqrt(HW))
+//     use the scale that puts the bound in [2^14, 2^15): they cannot saturate;
+//   * data-dependent activations (ACE outputs, style projections) are written with the fixed scale SH16_ACT_SCALE while the
+//     producer tracks the exact max |v*s| of the tensor in a device slot.  If that maximum left the window [2^-1, 65504]
+//     (f32-class accuracy relative to the tensor's maximum needs max*s >= 2^-1), the producer's second pass -- the same
+//     kernel, launched again, returning at once in the normal case -- recomputes the tensor with the scale that puts the
+//     recorded maximum in [2^14, 2^15).  Consumers derive the scale in effect from the same slot (sh16_dyn_extra).
+// All scalings are by powers of two and are undone exactly in the consumer's f32 epilogue (accumulator * 2^-k / s).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace chk {
 
 constexpr float SH16_MAX = 65504.f;
-constexpr float SH16_ACT_SCALE = 8.f;        // fixed scale of data-dependent activation tensors (ACE outputs, style projections)
+constexpr float SH16_ACT_SCALE = 8.f;        // first-pass scale of data-dependent activation tensors
 
-// power-of-two scale that brings `bound` (an upper bound of |v|) into [2^14, 2^15]; host and device
+// power-of-two scale that brings `bound` (an upper bound of |v|) into [2^14, 2^15); host and device
 inline __host__ __device__ float sh16_scale_for_bound(float bound) {
-    if (!(bound > 0.f)) return 1.f;
+    if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
     int e;
     (void)frexpf(bound, &e);                 // bound = m * 2^e, m in [0.5, 1)
     return ldexpf(1.f, 15 - e);
 }
 
+// `amax_bits`: float bits of max |v * SH16_ACT_SCALE| recorded by the producer's first pass.  Returns the extra power of
+// two the tensor is (re)written with: 1 inside the window, else the factor that moves the maximum into [2^14, 2^15).
+inline __host__ __device__ float sh16_dyn_extra(unsigned amax_bits) {
+    float a;
+    __builtin_memcpy(&a, &amax_bits, 4);
+    if (a == 0.f || (a >= 0.5f && a <= SH16_MAX) || !(a < 3.0e38f)) return 1.f;      // all-zero / in window / inf, NaN
+    return sh16_scale_for_bound(a);
+}
+
+// MODE.FP16_OVFL = 1 for the rest of the wave's life: hwreg(HW_REG_MODE = 1, offset 23, size 1)
+__device__ __forceinline__ void sh16_mode_on() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
+
+// requires sh16_mode_on() earlier in the kernel
 __device__ __forceinline__ void sh16_split(float v, float s, _Float16& h, _Float16& l) {
-    const float t = __builtin_amdgcn_fmed3f(v * s, -SH16_MAX, SH16_MAX);
+    const float t = v * s;
     h = (_Float16)t;
     l = (_Float16)(t - (float)h);
+}
+
+__device__ __forceinline__ float sh16_wave_max(float m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return m;
 }
 
 }  // namespace chk

@@ -35,6 +35,7 @@ SYMBOLS = {
     'ch_blend_mask': (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
     'ch_poisson_blend': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _D, C.POINTER(_I), _VP]),
     'ch_sean_set_tap': (_I, [_VP, C.c_char_p, _VP]),
+    'ch_sean_scale_report': (_I, [_VP, C.POINTER(C.c_float), _I]),
     'ch_profile_enable': (_I, [_VP, _I]),
     'ch_profile_read': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
 }
@@ -117,6 +118,16 @@ class Handle:
 
     def sean_set_tap(self, name: str, ptr):
         self._check(self.lib.ch_sean_set_tap(self._h, name.encode(), ptr), 'ch_sean_set_tap')
+
+    def sean_scale_report(self):
+        """f16x3 / f16 paths: maxima of |value * 8| recorded by the producers of the dynamically scaled activation
+        tensors during the last generate chunk, as {'ace': float[18], 'style': float[18]} (0 = not written).  A value
+        outside [0.5, 65504] means that tensor was rewritten with a corrected scale (csrc/sh16.h).  Synchronises."""
+        import numpy as np
+        buf = (C.c_float * 36)()
+        self._check(self.lib.ch_sean_scale_report(self._h, buf, 36), 'ch_sean_scale_report')
+        a = np.array(buf[:], dtype=np.float32)
+        return {'ace': a[0::2].copy(), 'style': a[1::2].copy()}
 
     def profile_enable(self, on: bool):
         self._check(self.lib.ch_profile_enable(self._h, int(on)), 'ch_profile_enable')

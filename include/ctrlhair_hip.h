@@ -155,6 +155,13 @@ int  ch_poisson_blend(ch_handle* h, const uint8_t* source, const uint8_t* target
  * (device-to-device, same stream) to `dev_ptr` (caller-sized: [B,C,r,r] floats).  dev_ptr NULL removes the tap. */
 int  ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr);
 
+/* Diagnostic hook of the f16x3 / f16 paths (ctrlhair_amd/csrc/sh16.h): data-dependent activations are stored as f16 hi/lo
+ * pairs with a power-of-two scale; each producer records the maximum of |value * 8| over its tensor and rewrites the
+ * tensor with a corrected scale when that maximum left the window [0.5, 65504].  Copies to host_out[0..n) the maxima
+ * recorded by the last ch_sean_generate batch chunk: entry 2i = output of ACE layer i (execution order), 2i+1 = its style
+ * projections; 0 = not written.  Synchronises the device (not for the hot path). */
+int  ch_sean_scale_report(ch_handle* h, float* host_out, int n);
+
 /* Kernel-level timing hook for bench.py / roofline: when enabled, ch_sean_generate brackets every MFMA conv launch
  * with hipEvents on `stream`.  ch_profile_read synchronises those events and returns, for launches of `kind`
  * (0 = plain conv, 1 = SPADE conv with fused ACE epilogue, 2 = style-LUT GEMM, <0 = all), their count, summed

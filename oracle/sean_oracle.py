@@ -52,7 +52,10 @@ def one_hot(labels: torch.Tensor) -> torch.Tensor:
     """pix2pix_model.py:133-138: scatter_ of the label map into a [B,19,H,W] fp32 one-hot."""
     lab = labels.long().unsqueeze(1)
     B, _, H, W = lab.shape
-    return torch.zeros(B, LABEL_NC, H, W, dtype=torch.float32).scatter_(1, lab, 1.0)
+    # ids >= 19 ("no class", e.g. 255) make scatter_ raise in the reference; the library defines them as an all-zero
+    # one-hot (include/ctrlhair_hip.h), restated here through a 20th channel that is dropped
+    oh = torch.zeros(B, LABEL_NC + 1, H, W, dtype=torch.float32).scatter_(1, lab.clamp(max=LABEL_NC), 1.0)
+    return oh[:, :LABEL_NC].contiguous()
 
 
 def spade(sd, p, segmap):
@@ -95,6 +98,7 @@ def ace(sd, p, x, seg, codes, noise_plane, styled, stats_out=None):
         mu[:, j] = F.relu(F.linear(codes[:, j], sd[f'{p}.fc_mu{j}.weight'], sd[f'{p}.fc_mu{j}.bias']))
     middle_avg = torch.gather(mu, 1, lab.reshape(B, H * W, 1).expand(B, H * W, STYLE_LEN))
     middle_avg = middle_avg.reshape(B, H, W, STYLE_LEN).permute(0, 3, 1, 2).contiguous()
+    middle_avg = middle_avg * segmap.sum(dim=1, keepdim=True)         # pixels of no class are never written (:127-129)
     gamma_avg = F.conv2d(middle_avg, sd[p + '.conv_gamma.weight'], sd[p + '.conv_gamma.bias'], padding=1)  # :172
     beta_avg = F.conv2d(middle_avg, sd[p + '.conv_beta.weight'], sd[p + '.conv_beta.bias'], padding=1)    # :173
     ga = torch.sigmoid(sd[p + '.blending_gamma'])                     # :177-178

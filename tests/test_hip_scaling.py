@@ -1,0 +1,159 @@
+"""GPU tests that the f16 MFMA paths are f32-class BY CONSTRUCTION (ctrlhair_amd/csrc/sh16.h), not only on the weight
+distribution the other tests use: weights rescaled by 1e-4 ... 1e+3 (compensated in the following layer), activations
+driven to ~6e4 and to ~1e-6, and labels outside 0..18.  Bar: |HIP - oracle| <= 1e-3 per pixel on every path (the oracle runs
+the same modified weights), plus normwise f32-class agreement of the affected conv outputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+PATHS = ['f32', 'f16x3ws', 'f16x3nows']
+
+
+def _gen(sd, path, max_batch, max_size):
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    g = SeanGenerator(0, f16x3=0 if path == 'f32' else 1).load_state_dict(sd, max_batch=max_batch, max_size=max_size)
+    if path != 'f32':
+        g.handle.set_option('sean.dbg', 64 if path == 'f16x3ws' else 128)
+    return g
+
+
+def _run(gen, labels, codes, noise, taps=()):
+    dev = gen.device
+    bufs = {}
+    for name, shape in taps:
+        bufs[name] = torch.zeros(shape, dtype=torch.float32, device=dev)
+        gen.handle.sean_set_tap(name, bufs[name].data_ptr())
+    out = gen.generate(torch.from_numpy(labels).to(dev), torch.from_numpy(codes).to(dev), torch.from_numpy(noise).to(dev))
+    torch.cuda.synchronize()
+    for name, _ in taps:
+        gen.handle.sean_set_tap(name, None)
+    return out.cpu().numpy(), {k: v.cpu().numpy() for k, v in bufs.items()}
+
+
+def _scale_effective_conv(sd, prefix, f):
+    """Effective spectral-normed weight W_orig / (u . W v) times f, bias times f."""
+    sd[prefix + '.weight_u'] = (sd[prefix + '.weight_u'] / np.float32(f)).astype(np.float32)
+    if prefix + '.bias' in sd:
+        sd[prefix + '.bias'] = (sd[prefix + '.bias'] * np.float32(f)).astype(np.float32)
+
+
+def _inputs(B, S, ngf):
+    from ctrlhair_amd import procedural as P
+    return P.blocky_labels(B, S, grid=8), P.style_codes(B), P.noise_planes(B, S, ngf)
+
+
+@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('f', [2.0 ** -13, 1e3])
+def test_weight_magnitudes(hip_lib, path, f):
+    """up_2 of an ngf=16, S=128 generator: conv_0's effective weights x f (undone by ace_1's BN statistics), the SPADE
+    hidden layer x f (undone in mlp_gamma/beta), the style convs x f (undone in fc_mu, which makes the style projections
+    f times smaller or larger than usual)."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    ngf, S, B = 16, 128, 2
+    sd = dict(P.sean_state_dict(0, ngf))
+    blk = 'up_2'
+    _scale_effective_conv(sd, blk + '.conv_0', f)
+    a1 = blk + '.ace_1'
+    sd[a1 + '.param_free_norm.running_mean'] = sd[a1 + '.param_free_norm.running_mean'] * np.float32(f)
+    sd[a1 + '.param_free_norm.running_var'] = sd[a1 + '.param_free_norm.running_var'] * np.float32(f) ** 2
+    sd[a1 + '.noise_var'] = sd[a1 + '.noise_var'] * np.float32(f)
+    a0 = blk + '.ace_0'
+    for k in ('.Spade.mlp_shared.0.weight', '.Spade.mlp_shared.0.bias'):
+        sd[a0 + k] = sd[a0 + k] * np.float32(f)
+    for k in ('.Spade.mlp_gamma.weight', '.Spade.mlp_beta.weight'):
+        sd[a0 + k] = sd[a0 + k] / np.float32(f)
+    for k in ('.conv_gamma.weight', '.conv_beta.weight'):
+        sd[a0 + k] = sd[a0 + k] * np.float32(f)
+    for j in range(19):
+        for k in ('.weight', '.bias'):
+            sd[f'{a0}.fc_mu{j}{k}'] = sd[f'{a0}.fc_mu{j}{k}'] / np.float32(f)
+    labels, codes, noise = _inputs(B, S, ngf)
+    taps = {}
+    ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf, taps=taps).numpy()
+    gen = _gen(sd, path, B, S)
+    names = [blk + '.h0', blk + '.dx', blk + '.h1']
+    img, got = _run(gen, labels, codes, noise, [(n, tuple(taps[n].shape)) for n in names])
+    for n in names:
+        r = taps[n].numpy()
+        rel = float(np.abs(got[n] - r).max() / np.abs(r).max())
+        print(f'{path} f={f:g} {n}: max|ref| {np.abs(r).max():.3e}  normwise err {rel:.2e}')
+        assert rel <= 2e-5, (n, rel)
+    d = float(np.abs(img - ref).max())
+    print(f'{path} f={f:g}: image max |delta| {d:.3e}')
+    assert np.isfinite(img).all() and d <= TOL
+    if path != 'f32':          # f = 1e3 makes the style projections ~1e-3: their slot must show a rescaled tensor
+        rep = gen.handle.sean_scale_report()
+        assert (rep['ace'] > 0).sum() == 18 and (rep['style'] > 0).sum() == 15
+        if f > 1:
+            assert ((rep['style'] > 0) & (rep['style'] < 0.5)).any()
+    gen.handle.close()
+
+
+@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('target', [6e4, 3e-6])
+def test_activation_magnitudes(hip_lib, path, target):
+    """The ACE outputs of up_2 (ngf=64, S=256, B=3: large enough for the fused-shortcut kernel) are driven to max |h| ~
+    `target` -- h' = F h through gamma' = F gamma + F - 1, beta' = F beta -- and the following convs are divided by F, so
+    the image is unchanged.  ace_s and ace_0 get different F: the fused conv_1 + conv_s sees two inputs whose recorded
+    scales differ."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    ngf, S, B = 64, 256, 3
+    base = P.sean_state_dict(0, ngf)
+    labels, codes, noise = _inputs(B, S, ngf)
+    taps = {}
+    ref0 = O.generator_forward(O.to_torch(base), labels, codes, noise, ngf, taps=taps).numpy()
+    blk = 'up_2'
+    sd = dict(base)
+    plan = {'ace_s': ('hs', 'conv_s', 1.0), 'ace_0': ('h0', 'conv_0', 1.0), 'ace_1': ('h1', 'conv_1', 2.0 ** -10)}
+    factors = {}
+    for ace, (tapname, conv, rel) in plan.items():
+        hmax = float(taps[f'{blk}.{tapname}'].abs().max())
+        F = float(2.0 ** np.round(np.log2(target * rel / hmax)))
+        if ace == 'ace_1' and target < 1:
+            F = 1.0                       # (small targets: leave h1 alone, hs and h0 go tiny)
+        factors[ace] = F
+        a = f'{blk}.{ace}'
+        for g in ('gamma', 'beta'):
+            for pre in ('.Spade.mlp_', '.conv_'):
+                sd[f'{a}{pre}{g}.weight'] = sd[f'{a}{pre}{g}.weight'] * np.float32(F)
+                b = sd[f'{a}{pre}{g}.bias'] * np.float32(F)
+                sd[f'{a}{pre}{g}.bias'] = (b + np.float32(F - 1)) if g == 'gamma' else b
+        sd[f'{blk}.{conv}.weight_u'] = (sd[f'{blk}.{conv}.weight_u'] * np.float32(F)).astype(np.float32)
+    ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf).numpy()
+    assert np.abs(ref - ref0).max() <= 1e-4        # the compensation is exact up to fp32 rounding
+    gen = _gen(sd, path, 4, S)
+    img, _ = _run(gen, labels, codes, noise)
+    d = float(np.abs(img - ref).max())
+    print(f'{path} target={target:g} factors={factors}: image max |delta| {d:.3e}')
+    assert np.isfinite(img).all() and d <= TOL
+    if path != 'f32':
+        rep = gen.handle.sean_scale_report()['ace']
+        out_of_window = (rep > 65504) if target > 1 else ((rep > 0) & (rep < 0.5))
+        print('recorded maxima (|h| x 8):', np.array2string(rep, precision=3))
+        assert out_of_window.sum() >= 2        # hs and h0 of up_2 were rewritten with a corrected scale
+    gen.handle.close()
+
+
+@pytest.mark.parametrize('path', PATHS)
+def test_labels_outside_the_class_range(hip_lib, path):
+    """ids >= 19 (255 is the API's "no class", e.g. ch_shape_encode) are an all-zero one-hot: no table row, no style."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    ngf, S, B = 16, 64, 2
+    sd = P.sean_state_dict(0, ngf)
+    labels, codes, noise = P.blocky_labels(B, S, grid=8), P.style_codes(B), P.noise_planes(B, S, ngf)
+    labels = labels.copy()
+    labels[0, 8:40, 16:48] = 255
+    labels[1, :, :5] = 19
+    labels[1, 60:, 50:] = 200
+    ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf).numpy()
+    gen = _gen(sd, path, B, S)
+    img, _ = _run(gen, labels, codes, noise)
+    d = float(np.abs(img - ref).max())
+    print(f'{path}: labels with 19/200/255: max |delta| {d:.3e}')
+    assert np.isfinite(img).all() and d <= TOL
+    gen.handle.close()
