@@ -19,7 +19,7 @@ TEMP_FOLDER = 'temp_folder'
 def _cv2():
     try:
         import cv2
-        return cv2
+        return cv2 if hasattr(cv2, 'cvtColor') else None      # (an import-only stub module is not cv2)
     except Exception:
         return None
 

@@ -1,0 +1,157 @@
+"""The whole CtrlHair edit as ONE batched, device-resident pass (BASELINE.json configs[2], SURVEY.md 8d Config 3):
+
+    portrait -> BiSeNet parse @512 -> CelebAMask ids -> nearest 256 -> shape encoders            (ui/backend.py:67-90)
+             -> Zencoder @S -> hair code -> colour predictor + colour/texture encoder              (ui/backend.py:93-105)
+             -> sliders (curliness, texture / shape directions, HSV in the Gaussianised space)     (ui/backend.py:177-264,450-462)
+             -> colour/texture generator -> new hair code; shape decoder -> new mask               (ui/backend.py:147-170,304-315)
+             -> nearest x2 -> SEAN generator @S                                                    (hair_editor.py:159-179)
+
+It is what `Backend.set_input_img(img); Backend.change_*(...); Backend.output()` computes for one portrait, restated over
+a batch of portraits with every tensor left on the GPU (the reference round-trips through numpy / cv2 between the
+networks and handles one image at a time).  `ctrlhair_amd.ui.backend.Backend` remains the drop-in API;
+tests/test_pipeline.py pins this composition to a fixture made with the reference's own modules and Backend to this.
+"""
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import hostutil as U
+from .hostutil import HAIR_IDX
+
+# SURVEY.md 8d Config 3 slider deltas
+DEFAULT_SLIDERS = {'curliness': 1.0, 'texture': (0, 1.5), 'shape': (0, -1.0), 'hsv_gaussian': (2, 1.0)}
+
+_MEAN = (0.485, 0.456, 0.406)     # external_code/face_parsing/my_parsing_util.py:27
+_STD = (0.229, 0.224, 0.225)
+
+
+def rgb_to_hsv_u8(rgb: torch.Tensor) -> torch.Tensor:
+    """cv2.cvtColor(uint8 RGB, COLOR_RGB2HSV) on [N,3] uint8-valued tensors (same arithmetic as hostutil.rgb_to_hsv_u8:
+    H in [0,180), S, V in [0,255])."""
+    a = rgb.float()
+    r, g, b = a[:, 0], a[:, 1], a[:, 2]
+    v = a.max(dim=1).values
+    d = v - a.min(dim=1).values
+    s = torch.where(v > 0, d / v.clamp_min(1e-12) * 255.0, torch.zeros_like(v))
+    dd = d.clamp_min(1e-12)
+    h = torch.where(v == r, (g - b) / dd, torch.where(v == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd)) * 60.0
+    h = torch.where(d == 0, torch.zeros_like(h), h)
+    h = torch.where(h < 0, h + 360.0, h) / 2.0
+    out = torch.stack([torch.floor(h + 0.5) % 180, torch.floor(s + 0.5), v], dim=1)
+    return out.clamp(0, 255)
+
+
+def hsv_to_rgb_u8(hsv: torch.Tensor) -> torch.Tensor:
+    """cv2.cvtColor(uint8 HSV, COLOR_HSV2RGB) on [N,3] (hostutil.hsv_to_rgb_u8)."""
+    a = hsv.float()
+    h, s, v = a[:, 0] * 2.0, a[:, 1] / 255.0, a[:, 2]
+    c = v * s
+    hp = (h / 60.0) % 6.0
+    x = c * (1 - (hp % 2 - 1).abs())
+    z = torch.zeros_like(c)
+    sel = torch.floor(hp).long().clamp(0, 5)
+    pick = lambda opts: torch.stack(opts, dim=1).gather(1, sel[:, None])[:, 0]
+    r, g, b = pick([c, x, z, z, x, c]), pick([x, c, c, x, z, z]), pick([z, z, x, c, c, x])
+    m = v - c
+    return torch.floor(torch.stack([r + m, g + m, b + m], dim=1) + 0.5).clamp(0, 255)
+
+
+class EditPipeline:
+    def __init__(self, weights: Optional[Dict[str, dict]] = None, device: int = 0, img_size: int = 512, max_batch: int = 8,
+                 f16x3=1, models=None, texture_dirs=None, shape_dirs=None, hsv_table=None):
+        from .hair_editor import HipModels, procedural_weights
+        if models is None:
+            models = HipModels(weights if weights is not None else procedural_weights(), device=device, img_size=img_size,
+                               max_batch=max_batch, f16x3=f16x3)
+        self.models = models
+        self.device = models.device
+        self.img_size = img_size
+        td = texture_dirs if texture_dirs is not None else U.seeded_directions(2, 8, seed=45)      # hair_editor.py:82-91
+        sdirs = shape_dirs if shape_dirs is not None else U.seeded_directions(4, 16, seed=54)      # hair_editor.py:110-119
+        self.texture_dirs = torch.as_tensor(np.asarray(td)).float().to(self.device)
+        self.shape_dirs = torch.as_tensor(np.asarray(sdirs)).float().to(self.device)
+        self.dist_translation = U.DistTranslation(hsv_table)
+        import os
+        med = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'mean_style_code.npz'))['median']
+        self.median = torch.from_numpy(med.astype(np.float32)).to(self.device)
+        self.mean = torch.tensor(_MEAN, device=self.device).view(1, 3, 1, 1)
+        self.std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1)
+
+    def close(self):
+        self.models.generator.handle.close()
+
+    # ---- stages (each returns device tensors; citations: module docstring) -----------------------------------------------
+    def parse(self, img: torch.Tensor) -> torch.Tensor:
+        """img [B,3,H,W] in [-1,1] -> CelebAMask-HQ label map uint8 [B,H,W] (ToTensor + Normalize, net, argmax, remap)."""
+        x = ((img * 0.5 + 0.5) - self.mean) / self.std
+        return self.models.face_parsing.parse_tensor(x)[0]
+
+    def analyse(self, img: torch.Tensor, labels: torch.Tensor):
+        """-> dict(shape [B,16], face [B,1024], codes [B,19,512], rgb_mean [B,3], pca_std [B,1], texture [B,8],
+        curliness [B,1]) -- Backend.parse_img's latent representation, batched."""
+        m = self.models
+        S = img.shape[-1]
+        lab256 = labels if S == 256 else labels[:, ::S // 256, ::S // 256].contiguous()       # cv2 INTER_NEAREST: floor(dst * in/out)
+        shape, face = m.mask_generator.encode_labels(lab256)
+        codes = m.generator.encode(img, labels)
+        hair = codes[:, HAIR_IDX].contiguous()
+        stats = m.solver_feature.rgb_model({'code': hair})
+        lat = m.solver_feature.dis({'code': hair})
+        return {'shape': shape, 'face': face, 'codes': codes, 'rgb_mean': stats['rgb_mean'], 'pca_std': stats['pca_std'],
+                'texture': lat['noise'], 'curliness': lat['noise_curliness']}
+
+    def apply_sliders(self, lat: dict, sliders: dict) -> dict:
+        """Backend.change_curliness / change_texture / change_shape / change_color on every sample."""
+        out = dict(lat)
+        # colour lives as uint8 HSV in the reference (ui/backend.py:100: the predicted mean RGB is truncated to uint8)
+        hsv = rgb_to_hsv_u8(lat['rgb_mean'].clamp(0, 255).floor())
+        if sliders.get('hsv_gaussian') is not None:
+            idx, val = sliders['hsv_gaussian']
+            hsv = hsv.clone()
+            hsv[:, idx] = float(np.uint8(self.dist_translation.gaussian_to_val(idx, val)))   # stored into a uint8 tensor (:193)
+        out['hsv'] = hsv
+        out['rgb'] = hsv_to_rgb_u8(hsv)                                                         # tensor_hsv_to_rgb (:108-115)
+        if sliders.get('curliness') is not None:
+            out['curliness'] = torch.full_like(lat['curliness'], float(sliders['curliness']))
+        move = lambda cur, d, val: cur + (val - cur @ d)[:, None] * d[None]                     # continue_change_with_direction
+        if sliders.get('texture') is not None:
+            idx, val = sliders['texture']
+            out['texture'] = move(lat['texture'], self.texture_dirs[idx], val)
+        if sliders.get('shape') is not None:
+            idx, val = sliders['shape']
+            out['shape'] = move(lat['shape'], self.shape_dirs[idx], val)
+        return out
+
+    def render(self, lat: dict, noise: Optional[torch.Tensor] = None, seed: int = 0, out: Optional[torch.Tensor] = None,
+               mask: Optional[torch.Tensor] = None):
+        """Backend.output(): colour/texture generator -> hair code, shape decoder -> mask, SEAN generator.
+        Returns (image [B,3,S,S] in [-1,1], mask uint8 [B,256,256])."""
+        m = self.models
+        feature = m.solver_feature.gen({'noise': lat['texture'], 'noise_curliness': lat['curliness'], 'rgb_mean': lat['rgb'],
+                                        'pca_std': lat['pca_std']})['code']
+        codes = lat['codes'].clone()
+        codes[:, HAIR_IDX] = feature                                                            # ui/backend.py:170
+        zero = (codes == 0).all(dim=2, keepdim=True)                                            # absent regions keep the median
+        codes = torch.where(zero, self.median[None].expand_as(codes), codes).contiguous()       # code (hair_editor.py:165-168)
+        if mask is None:
+            mask = m.mask_generator.decode_labels(lat['shape'], lat['face'])                    # ui/backend.py:304-315
+        r = self.img_size // 256
+        lab = mask if r == 1 else mask.repeat_interleave(r, 1).repeat_interleave(r, 2).contiguous()
+        return m.generator.generate(lab, codes, noise, seed=seed, out=out), mask
+
+    def edit(self, img: torch.Tensor, sliders: Optional[dict] = None, noise: Optional[torch.Tensor] = None, seed: int = 1,
+             out: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+             stages: Optional[dict] = None) -> torch.Tensor:
+        """img: cuda float32 [B,3,S,S] in [-1,1] (what HairEditor.preprocess_img produces).  `labels` / `mask` override the
+        parsed label map / the decoded mask (a caller-supplied parsing; the tests use them to step over argmax ties).
+        `stages` (optional dict) receives every intermediate tensor."""
+        sliders = DEFAULT_SLIDERS if sliders is None else sliders
+        if labels is None:
+            labels = self.parse(img)
+        lat = self.analyse(img, labels)
+        lat = self.apply_sliders(lat, sliders)
+        image, mask = self.render(lat, noise=noise, seed=seed, out=out, mask=mask)
+        if stages is not None:
+            stages.update(lat, labels=labels, mask=mask, image=image)
+        return image

@@ -152,7 +152,90 @@ def aux_cases():
         print('bisenet', name, 'classes', np.unique(lg.argmax(1).numpy()), 'logit std', float(lg.std()))
 
 
+def pipeline_case(name='pipeline512', S=512, B=2, ngf=64, iseed=11, nseed=93):
+    """BASELINE.json configs[2] composed from the REFERENCE's own modules in the order of ui/backend.py:67-175 (Backend
+    itself needs cv2 / dlib / trained checkpoints): BiSeNet -> label remap -> shape encoders -> Zencoder -> colour
+    predictor / encoder -> sliders (SURVEY.md 8d Config 3) -> colour generator, shape decoder -> SPADEGenerator.
+    Stores every stage's output so that each HIP stage can be checked on the reference's inputs of that stage."""
+    import torch
+    from ctrlhair_amd import hostutil as U
+    from ctrlhair_amd.pipeline import DEFAULT_SLIDERS
+    from oracle import aux_oracle as A
+    from oracle import sean_oracle as O
+    w = {'sean': P.sean_state_dict(0, ngf), 'shape': P.shape_state_dict(0), 'color': P.color_state_dicts(0),
+         'bisenet': P.bisenet_state_dict(0)}
+    img = P.synthetic_images(B, S, seed=iseed)                                  # [-1,1], what preprocess_img yields
+    out = {'meta_S': np.array(S), 'meta_B': np.array(B), 'meta_ngf': np.array(ngf), 'meta_iseed': np.array(iseed),
+           'meta_nseed': np.array(nseed)}
+    with torch.no_grad():
+        # my_parsing_util.py:25-47: ToTensor + Normalize, BiSeNet, argmax of output [0]; :50-54 remap to CelebAMask ids
+        N = R.make_bisenet()
+        N.load_state_dict({k: torch.from_numpy(v) for k, v in w['bisenet'].items()})
+        mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        lg = N((torch.from_numpy(img) * 0.5 + 0.5 - mean) / std)[0]
+        top2 = torch.topk(lg, 2, dim=1).values
+        labels = np.array(A.BISENET_TO_CELEBA, np.uint8)[lg.argmax(1).numpy()]
+        out['labels'] = labels
+        out['labels_low_margin'] = np.packbits(((top2[:, 0] - top2[:, 1]) < 5e-3).numpy())
+        # ui/backend.py:79-90 (shape branch at 256: cv2 INTER_NEAREST down-sampling of the label map)
+        lab256 = np.stack([U.resize_nearest(l, (256, 256)) for l in labels])
+        G = R.make_shape_generator()
+        G.load_state_dict({k: torch.from_numpy(v) for k, v in w['shape'].items()})
+        hair, face = A.split_hair_face(A.label_to_onehot19(lab256))
+        hc = G.forward_hair_encoder(hair, testing=True)
+        fc = G.forward_face_encoder(face)
+        out['hair_code'], out['face_code'] = hc.numpy(), fc.numpy()
+        # :93-105 Zencoder codes, colour statistics, texture / curliness latents
+        codes = torch.from_numpy(R.run_zencoder(w['sean'], img, labels))
+        out['codes'] = codes.numpy()
+        Sv = R.make_color_solver()
+        for nm, mod in (('gen', Sv.gen), ('dis', Sv.dis), ('rgb', Sv.rgb_model)):
+            mod.load_state_dict({k: torch.from_numpy(v) for k, v in w['color'][nm].items()})
+        hairf = codes[:, 13]
+        col = Sv.rgb_model({'code': hairf})
+        enc = Sv.dis({'code': hairf})
+        out['rgb_mean'], out['pca_std'] = col['rgb_mean'].numpy(), col['pca_std'].numpy()
+        out['texture'], out['curliness'] = enc['noise'].numpy(), enc['noise_curliness'].numpy()
+        hsv = U.rgb_to_hsv_u8(col['rgb_mean'].numpy().astype('uint8')[None])[0]                 # :99-101
+        # sliders (SURVEY.md 8d Config 3): change_color (:192-199), change_curliness, change_texture / change_shape (:450-462)
+        sl = DEFAULT_SLIDERS
+        idx, val = sl['hsv_gaussian']
+        hsv[:, idx] = U.DistTranslation().gaussian_to_val(idx, val)
+        rgb = torch.from_numpy(U.hsv_to_rgb_u8(hsv[None])[0])                                   # tensor_hsv_to_rgb :108-115
+        out['hsv'], out['rgb'] = hsv, rgb.numpy()
+        tdirs = torch.from_numpy(U.seeded_directions(2, 8, seed=45))
+        sdirs = torch.from_numpy(U.seeded_directions(4, 16, seed=54))
+        move = lambda cur, d, v: cur + (v - cur @ d)[:, None] * d[None]
+        tex = move(enc['noise'], tdirs[sl['texture'][0]], sl['texture'][1])
+        shp = move(hc, sdirs[sl['shape'][0]], sl['shape'][1])
+        curl = torch.full_like(enc['noise_curliness'], sl['curliness'])
+        feat = Sv.gen({'noise': tex, 'noise_curliness': curl, 'rgb_mean': rgb, 'pca_std': col['pca_std']})['code']   # :162-169
+        out['feature'] = feat.numpy()
+        probs = G.forward_decode_by_code(shp, fc)                                                # :304-315
+        t2 = torch.topk(probs, 2, dim=1).values
+        mask = torch.argmax(probs, dim=1).to(torch.uint8).numpy()
+        out['mask'] = mask
+        out['mask_low_margin'] = np.packbits(((t2[:, 0] - t2[:, 1]) < 5e-3).numpy())
+        codes2 = codes.clone()
+        codes2[:, 13] = feat                                                                     # :170
+        med = torch.from_numpy(median_codes())
+        zero = (codes2 == 0).all(dim=2, keepdim=True)                                            # hair_editor.py:165-168
+        codes2 = torch.where(zero, med[None].expand_as(codes2), codes2)
+        lab_up = np.stack([U.resize_nearest(m, (S, S)) for m in mask])
+        nz = P.noise_planes(B, S, ngf, seed=nseed)
+        image = R.run_generator(w['sean'], lab_up, codes2.numpy(), nz, ngf, ui_mode=False)
+    out.update(summarize(image))
+    path = os.path.join(HERE, f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print(name, 'image std', image.std(), 'hair px', int((mask == 13).sum()), 'classes', np.unique(labels), 'bytes',
+          os.path.getsize(path))
+
+
 def main():
+    if 'pipeline' in sys.argv[1:]:
+        pipeline_case()
+        return
     if 'aux' in sys.argv[1:] or len(sys.argv) == 1:
         aux_cases()
     if 'zenc' in sys.argv[1:] or len(sys.argv) == 1:

@@ -34,6 +34,59 @@ def _worker(rank, world, port, B, q):
     dist.destroy_process_group()
 
 
+def _worker_pipelined(rank, world, port, steps, q):
+    """bench.py's multi-GPU step (parallel.PipelinedGather) with two gloo ranks: per step every rank renders ITS shard
+    (global sample index offset rank * n, as bench.py does), the gather of each step must hold both shards in rank order."""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from ctrlhair_amd import parallel
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ngf, S, n = 16, 64, 2
+    sd = O.to_torch(P.sean_state_dict(0, ngf))
+    pg = parallel.PipelinedGather((n, 3, S, S), torch.float32, 'cpu')
+    ok = True
+    for step in range(steps):
+        first = rank * n + 100 * step          # different inputs every step: a stale buffer would be noticed
+        out = pg.begin()
+        out.copy_(O.generator_forward(sd, P.blocky_labels(n, S, grid=8, first=first), P.style_codes(n, first=first),
+                                      P.noise_planes(n, S, ngf, first=first), ngf))
+        pg.submit()
+        ok = ok and pg.check_slot()
+    full = pg.finish()
+    if rank == 0:
+        q.put((ok, full.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_two_ranks():
+    sys.path.insert(0, ROOT)
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    ngf, S, n, steps = 16, 64, 2, 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, 29613, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, got = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok and got.shape == (2 * n, 3, S, S)
+    sd = O.to_torch(P.sean_state_dict(0, ngf))
+    for r in range(2):          # the last step's gathered buffer = [rank 0's shard | rank 1's shard]
+        first = r * n + 100 * (steps - 1)
+        ref = O.generator_forward(sd, P.blocky_labels(n, S, grid=8, first=first), P.style_codes(n, first=first),
+                                  P.noise_planes(n, S, ngf, first=first), ngf).numpy()
+        assert np.abs(got[r * n:(r + 1) * n] - ref).max() <= 1e-5
+
+
 def _run(B, port):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
