@@ -272,12 +272,26 @@ int ch_sean_scale_report(ch_handle* h, float* host_out, int n) {
     return CH_OK;
 }
 
+int ch_sean_debug_read(ch_handle* h, void* host_out, size_t bytes) {
+    if (!h || !host_out) return CH_ERR_ARG;
+    if (!h->sean_ready || !h->sean.splitk_ws) return fail(h, CH_ERR_STATE, "ch_sean_debug_read: SEAN weights not finalized");
+    DeviceGuard guard(h->device);
+    if ((long long)bytes > h->sean.splitk_cap * 4) return fail(h, CH_ERR_ARG, "ch_sean_debug_read: too many bytes");
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, h->sean.splitk_ws, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(h, CH_ERR_HIP, "ch_sean_debug_read: device read failed");
+    return CH_OK;
+}
+
 int ch_set_option(ch_handle* h, const char* key, int value) {
     if (!h || !key) return CH_ERR_ARG;
     if (std::strcmp(key, "sean.f16x3") == 0) {
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.f16x3) must precede ch_finalize");
         h->sean.use_sh16 = value != 0;          // 0 exact f32 | 1 f16x3 split operands (f32-class) | 2 single-term f16 operands
         h->sean.terms = value == 2 ? 1 : 3;
+        return CH_OK;
+    }
+    if (std::strcmp(key, "sean.dbg_sel") == 0) {
+        h->sean.dbg_sel = value;
         return CH_OK;
     }
     if (std::strcmp(key, "sean.dbg") == 0) {

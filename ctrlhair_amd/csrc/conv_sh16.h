@@ -726,9 +726,14 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     int q = 0;
     float amax = 0.f;                                         // running max |out * out_scale| of this wave (ACE, pass 0)
     const float extra = (pre && p.pass == 1) ? sh16_dyn_extra(*p.out_amax) : 1.f;
+    // dbg bit 256 (profiling only): wave 0 of every block stamps s_memtime at tile start / end of the k-loop / end of the
+    // epilogue into p.partial (3 x int64 per tile, 64 tiles per block)
+    const bool stamp = (p.dbg & 256) && wn == 0 && lane == 0 && p.partial;
+    long long* stamps = reinterpret_cast<long long*>(p.partial) + (long long)blockIdx.x * 64 * 3;
     for (int k = 0; k < my_tiles; ++k) {
         int mtile64, x0, y0, b0;
         tile_coords(k, mtile64, x0, y0, b0);
+        if (stamp && k < 64) stamps[k * 3] = __builtin_amdgcn_s_memtime();
         f32x16 acc[2][4];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -782,6 +787,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         }
         // after the last chunk's barrier the consumers no longer touch LDS: the loaders go on staging the next tile
         // while the epilogue runs
+        if (stamp && k < 64) stamps[k * 3 + 1] = __builtin_amdgcn_s_memtime();
         if (p.dbg & 4) continue;
         if constexpr (!pre) {
             sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
@@ -853,6 +859,10 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             };
             if (p.pass == 1) body(std::true_type{});
             else body(std::false_type{});
+        }
+        if (stamp && k < 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (profiling only) include the store drain
+            stamps[k * 3 + 2] = __builtin_amdgcn_s_memtime();
         }
     }
     if constexpr (pre) {

@@ -545,6 +545,8 @@ struct Runner {
         p.out_scale = SH16_ACT_SCALE;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         p.out_amax = m.amax_slots + 2 * a.index;
+        if ((m.dbg & 256) && a.index == m.dbg_sel) p.partial = m.splitk_ws;      // cycle stamps of this launch (profiling)
+        else p.dbg &= ~256;
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] {
             if (!m.use_sh16) {
                 check(conv_ace(p, st), "spade conv");

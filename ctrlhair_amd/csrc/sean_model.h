@@ -53,6 +53,7 @@ struct SeanModel {
     float* splitk_ws = nullptr;
     long long splitk_cap = 0;
     int dbg = 0;               // perf experiments (conv_mfma.h ConvParams::dbg)
+    int dbg_sel = 16;          // dbg bit 256: index of the ACE launch whose tiles are cycle-stamped
     int terms = 3;             // f16 MFMA path: 3 = split operands (f32-class), 1 = f16 operands (BASELINE configs[4] class)
     bool use_sh16 = false;     // generator convs on the f16x3 split-operand MFMA path (conv_sh16.h)
     std::vector<BlockW> blocks;

@@ -36,6 +36,7 @@ SYMBOLS = {
     'ch_poisson_blend': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _D, C.POINTER(_I), _VP]),
     'ch_sean_set_tap': (_I, [_VP, C.c_char_p, _VP]),
     'ch_sean_scale_report': (_I, [_VP, C.POINTER(C.c_float), _I]),
+    'ch_sean_debug_read': (_I, [_VP, _VP, C.c_size_t]),
     'ch_profile_enable': (_I, [_VP, _I]),
     'ch_profile_read': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
 }

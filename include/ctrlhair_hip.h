@@ -162,6 +162,10 @@ int  ch_sean_set_tap(ch_handle* h, const char* name, float* dev_ptr);
  * projections; 0 = not written.  Synchronises the device (not for the hot path). */
 int  ch_sean_scale_report(ch_handle* h, float* host_out, int n);
 
+/* Profiling hook (tools/ only): copies the first `bytes` of the generator's split-K scratch to host memory; with option
+ * "sean.dbg" bit 256 the wave-specialised conv kernel leaves per-tile cycle stamps there.  Synchronises the device. */
+int  ch_sean_debug_read(ch_handle* h, void* host_out, size_t bytes);
+
 /* Kernel-level timing hook for bench.py / roofline: when enabled, ch_sean_generate brackets every MFMA conv launch
  * with hipEvents on `stream`.  ch_profile_read synchronises those events and returns, for launches of `kind`
  * (0 = plain conv, 1 = SPADE conv with fused ACE epilogue, 2 = style-LUT GEMM, <0 = all), their count, summed

@@ -96,8 +96,7 @@ def test_weight_magnitudes(hip_lib, path, f):
 @pytest.mark.parametrize('target', [6e4, 3e-6])
 def test_activation_magnitudes(hip_lib, path, target):
     """The ACE outputs of up_2 (ngf=64, S=256, B=3: large enough for the fused-shortcut kernel) are driven to max |h| ~
-    `target` -- h' = F h through gamma' = F gamma + F - 1, beta' = F beta -- and the following convs are divided by F, so
-    the image is unchanged.  ace_s and ace_0 get different F: the fused conv_1 + conv_s sees two inputs whose recorded
+    `target` (h' = F h) and the following convs are divided by F, so the image is unchanged.  ace_s and ace_0 get different F: the fused conv_1 + conv_s sees two inputs whose recorded
     scales differ."""
     from ctrlhair_amd import procedural as P
     from oracle import sean_oracle as O
@@ -117,11 +116,18 @@ def test_activation_magnitudes(hip_lib, path, target):
             F = 1.0                       # (small targets: leave h1 alone, hs and h0 go tiny)
         factors[ace] = F
         a = f'{blk}.{ace}'
-        for g in ('gamma', 'beta'):
+        if F >= 1:        # h' = F h through gamma' = F gamma + F - 1, beta' = F beta
+            for g in ('gamma', 'beta'):
+                for pre in ('.Spade.mlp_', '.conv_'):
+                    sd[f'{a}{pre}{g}.weight'] = sd[f'{a}{pre}{g}.weight'] * np.float32(F)
+                    b = sd[f'{a}{pre}{g}.bias'] * np.float32(F)
+                    sd[f'{a}{pre}{g}.bias'] = (b + np.float32(F - 1)) if g == 'gamma' else b
+        else:             # F << 1: (1 + gamma') would cancel catastrophically in fp32 -- shrink the normalised input instead
+            #               (running_var / F^2: the eps of the BN only loses weight) and beta' = F beta
+            sd[a + '.param_free_norm.running_var'] = sd[a + '.param_free_norm.running_var'] / np.float32(F) ** 2
             for pre in ('.Spade.mlp_', '.conv_'):
-                sd[f'{a}{pre}{g}.weight'] = sd[f'{a}{pre}{g}.weight'] * np.float32(F)
-                b = sd[f'{a}{pre}{g}.bias'] * np.float32(F)
-                sd[f'{a}{pre}{g}.bias'] = (b + np.float32(F - 1)) if g == 'gamma' else b
+                sd[f'{a}{pre}beta.weight'] = sd[f'{a}{pre}beta.weight'] * np.float32(F)
+                sd[f'{a}{pre}beta.bias'] = sd[f'{a}{pre}beta.bias'] * np.float32(F)
         sd[f'{blk}.{conv}.weight_u'] = (sd[f'{blk}.{conv}.weight_u'] * np.float32(F)).astype(np.float32)
     ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf).numpy()
     assert np.abs(ref - ref0).max() <= 1e-4        # the compensation is exact up to fp32 rounding
