@@ -1,5 +1,6 @@
 // single-term f16 SPADE conv with fused ACE epilogue: the TERMS = 1 instantiations of conv_sh16.h
 #include "conv_sh16.h"
+#include "conv_sh16_ws2.h"
 namespace chk {
 hipError_t conv_h16_ace(const ConvParams& p, hipStream_t s) { return dispatch_sh16_ace<1>(p, s); }
 }  // namespace chk

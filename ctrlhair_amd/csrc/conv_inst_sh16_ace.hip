@@ -1,5 +1,6 @@
 // f16x3 split-operand SPADE conv with fused ACE epilogue (see conv_sh16.h)
 #include "conv_sh16.h"
+#include "conv_sh16_ws2.h"
 namespace chk {
 hipError_t conv_sh16_ace(const ConvParams& p, hipStream_t s) {
     return p.terms == 1 ? conv_h16_ace(p, s) : dispatch_sh16_ace<3>(p, s);

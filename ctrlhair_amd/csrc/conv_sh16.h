@@ -988,6 +988,9 @@ hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int TERMS>
+hipError_t launch_sh16_ws2(ConvParams p, int rows, hipStream_t stream);     // conv_sh16_ws2.h
+
 // implemented in conv_inst_sh16*.hip
 // ---- layer -> kernel selection, shared by the 3-term (f32-class) and 1-term (plain f16 operands) instantiation files
 template <int TERMS>
@@ -997,6 +1000,9 @@ hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
     // dbg bit 64 forces the wave-specialised persistent kernel, bit 128 forbids it; default: layers with at least two
     // rounds of tiles per CU (its loaders then hide every tile's prologue behind the previous tile's epilogue)
     const long long ntiles = (long long)(rows / 64) * ((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+    // dbg bit 2048: the experimental kernel of conv_sh16_ws2.h (epilogue pipelined into the next tile's k-loop; correct,
+    // but its half-size tiles double the A-fragment traffic and the loaders cannot deliver it: DESIGN.md section 7)
+    if ((p.dbg & 2048) && p.Cin == 128 && p.W >= 32) return launch_sh16_ws2<TERMS>(p, rows, s);
     const bool ws_ok = p.W >= 32 && p.Cin >= 48;
     if (ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512)))
         return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS>(p, rows, s);

@@ -8,14 +8,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-PATHS = ['f32', 'f16x3ws', 'f16x3nows']
+PATHS = ['f32', 'f16x3ws', 'f16x3ws2', 'f16x3nows']
+DBG = {'f16x3ws': 64, 'f16x3ws2': 64 | 2048, 'f16x3nows': 128}
 
 
 def _gen(sd, path, max_batch, max_size):
     from ctrlhair_amd.sean.generator import SeanGenerator
     g = SeanGenerator(0, f16x3=0 if path == 'f32' else 1).load_state_dict(sd, max_batch=max_batch, max_size=max_size)
     if path != 'f32':
-        g.handle.set_option('sean.dbg', 64 if path == 'f16x3ws' else 128)
+        g.handle.set_option('sean.dbg', DBG[path])
     return g
 
 

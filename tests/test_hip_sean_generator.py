@@ -11,8 +11,10 @@ TOL = 1e-3
 
 
 # exact-f32 MFMA kernel | 3-term split-operand f16 MFMA kernels (conv_sh16.h), default dispatch | the same with every
-# eligible layer forced onto the wave-specialised persistent kernel | ... onto the 2-blocks-per-CU kernel
-PATHS = ['f32', 'f16x3', 'f16x3ws', 'f16x3nows']
+# eligible layer forced onto the wave-specialised persistent kernel | ... SPADE convs on the experimental kernel of
+# conv_sh16_ws2.h (epilogue pipelined into the next tile's k-loop) | ... onto the 2-blocks-per-CU kernel
+PATHS = ['f32', 'f16x3', 'f16x3ws', 'f16x3ws2', 'f16x3nows']
+DBG = {'f16x3ws': 64, 'f16x3ws2': 64 | 2048, 'f16x3nows': 128}
 PATH_TOL = {'f16': 5e-2}      # single-term f16 operands: the reduced-precision configuration (BASELINE.json configs[4])
 
 
@@ -42,8 +44,8 @@ def gen_for(ngf, wseed=0, path='f32'):
         if (ngf, wseed) not in _sds:
             _sds[(ngf, wseed)] = P.sean_state_dict(wseed, ngf)
         _gens[key] = _gen(_sds[(ngf, wseed)], 4 if ngf == 64 else 8, 512 if ngf == 64 else 128, f16x3={'f32': 0, 'f16': 2}.get(path, 1))
-        if path in ('f16x3ws', 'f16x3nows'):
-            _gens[key].handle.set_option('sean.dbg', 64 if path == 'f16x3ws' else 128)
+        if path in DBG:
+            _gens[key].handle.set_option('sean.dbg', DBG[path])
     return _gens[key]
 
 

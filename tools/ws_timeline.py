@@ -27,7 +27,7 @@ def main():
     nz = torch.from_numpy(P.noise_planes(B, S, ngf)).to(dev)
     gen.generate(lab, cd, nz)
     gen.handle.set_option('sean.dbg_sel', sel)
-    gen.handle.set_option('sean.dbg', 256)
+    gen.handle.set_option('sean.dbg', 256 | (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
     for _ in range(2):
         gen.generate(lab, cd, nz)
     torch.cuda.synchronize()
