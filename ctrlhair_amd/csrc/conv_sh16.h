@@ -81,14 +81,30 @@ __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3
     return w;
 }
 
-// scale of the accumulators of an SH16 conv: 1 / s_in, with s_in = first-pass scale x dynamic factor of the input's slot
-__device__ __forceinline__ float sh16_in_scale_inv(const ConvParams& p) {
+// Scales in effect for an SH16 conv: returns 1 / s_in of the accumulators (first-pass scale x dynamic factor of the input's
+// slot) and, for a fused second operand (conv_1 + conv_s on one accumulator), the powers of two `mul1` / `mul2` the two
+// inputs' units are multiplied by while staged.  The weights of the two operands are packed so that, with both tensors at
+// their first-pass scales, the products already share the accumulator scale (sean_model.cpp: the shortcut activations'
+// first-pass scale carries the 2^D that aligns the two weight matrices).  If a second pass changed a scale, the operands
+// are brought back together: in2 by e1 / e2, and both down by a common factor if that would push in2 out of the f16 range.
+__device__ __forceinline__ float sh16_in_scale_inv(const ConvParams& p, float* mul1 = nullptr, float* mul2 = nullptr) {
     float isi = p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f;
+    float m1 = 1.f, m2 = 1.f;
     if (p.in_amax) {
-        float e = sh16_dyn_extra(*p.in_amax);
-        if (p.in2_amax) e = fminf(e, sh16_dyn_extra(*p.in2_amax));   // fused second operand: both are brought to the smaller scale
-        isi /= e;
+        const float e1 = sh16_dyn_extra(*p.in_amax);
+        if (p.in2_amax) {
+            const unsigned a2b = *p.in2_amax;
+            const float e2 = sh16_dyn_extra(a2b);
+            float a2;
+            __builtin_memcpy(&a2, &a2b, 4);
+            const float t = a2 * e1;                         // max |in2 unit| after the e1 / e2 alignment
+            if (t >= 32768.f && t < 3.0e38f) m1 = sh16_scale_for_bound(t);
+            m2 = m1 * e1 / e2;
+        }
+        isi /= e1 * m1;
     }
+    if (mul1) *mul1 = m1;
+    if (mul2) *mul2 = m2;
     return isi * (p.out_mul != 0.f ? p.out_mul : 1.f);
 }
 
@@ -367,21 +383,22 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
         }
     }
-    // FUSE: the two inputs share the accumulators, so they must carry the same scale.  Their first-pass scales are equal
-    // by construction; if a second pass changed one of them (sh16.h), the other operand's units are multiplied down to
-    // the smaller scale while they are staged (exact power of two; wave-uniform, false in the normal case).
+    // FUSE: the two inputs share the accumulators (sh16_in_scale_inv).  mul1 = mul2 = 1 unless a second pass changed one of
+    // the tensors' scales; then the units are rescaled while they are staged (through f32: the factor may be far outside
+    // the f16 range; wave-uniform branch, not taken in the normal case).
     float mul1 = 1.f, mul2 = 1.f;
     if constexpr (FUSE) {
-        if (p.in_amax && p.in2_amax) {
-            const float e1 = sh16_dyn_extra(*p.in_amax), e2 = sh16_dyn_extra(*p.in2_amax), e = fminf(e1, e2);
-            mul1 = e / e1;
-            mul2 = e / e2;
-        }
+        sh16_mode_on();
+        (void)sh16_in_scale_inv(p, &mul1, &mul2);
     }
     auto rescale = [&](uint4 (&stg)[NLOAD], float f) {
-        const half8 fv = {(_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f, (_Float16)f};
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) stg[i] = __builtin_bit_cast(uint4, __builtin_bit_cast(half8, stg[i]) * fv);
+        for (int i = 0; i < NLOAD; ++i) {
+            half8 h = __builtin_bit_cast(half8, stg[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)((float)h[e] * f);
+            stg[i] = __builtin_bit_cast(uint4, h);
+        }
     };
     auto stage = [&](int chunk, int buf) {
         // No scheduling fence in here on purpose: the compiler issues these loads early and sinks the LDS writes

@@ -125,6 +125,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 if (bb) cw.bias = B.upload(std::vector<float>(bb->f32(), bb->f32() + r.cout));
             }
         };
+        int fuse_shift = 0;
         {
             const SN c0 = sn_read(bw.name + ".conv_0", bw.fmid, bw.fin, 3), c1 = sn_read(bw.name + ".conv_1", bw.fout, bw.fmid, 3);
             SN cs;
@@ -135,10 +136,19 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 k0 = sh16_row_exponents(c0.cout, c0.cin, 3, sn_get(c0));
                 k1 = sh16_row_exponents(c1.cout, c1.cin, 3, sn_get(c1));
                 if (bw.learned) {
-                    // conv_s is folded into conv_1 as extra K chunks on the same accumulators (both inputs are ACE outputs
-                    // with the same activation scale): the two weight rows must share their power of two
+                    // conv_s is folded into conv_1 as extra K chunks on the same accumulators: row by row the two operands
+                    // must share 2^k * s_in.  conv_1's rows keep their own exponents; conv_s's rows take k1[row] - D with
+                    // D = max over rows of (k1 - ks) (no row overflows, rows of similar relative size lose nothing), and the
+                    // 2^D is carried by the first-pass scale of the shortcut activations (ace_s writes hs * 8 * 2^D).
                     ks_ = sh16_row_exponents(cs.cout, cs.cin, 1, sn_get(cs));
-                    for (int r = 0; r < c1.cout; ++r) k1[r] = ks_[r] = std::min(k1[r], ks_[r]);
+                    int D = k1[0] - ks_[0];
+                    for (int r = 0; r < c1.cout; ++r) D = std::max(D, k1[r] - ks_[r]);
+                    D = std::max(-24, std::min(24, D));
+                    for (int r = 0; r < c1.cout; ++r) {       // exactly ks = k1 - D, neither above its own optimum
+                        ks_[r] = std::min(ks_[r], k1[r] - D);
+                        k1[r] = ks_[r] + D;
+                    }
+                    fuse_shift = D;
                 }
             }
             sn_pack(c0, bw.name + ".conv_0", true, &k0, bw.conv_0);
@@ -147,7 +157,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         }
         if (!B.err.empty()) return B.err;
 
-        auto ace = [&](const std::string& p, int C, AceW& a) {
+        auto ace = [&](const std::string& p, int C, AceW& a, float out_scale = SH16_ACT_SCALE) {
+            a.out_scale = out_scale;
             a.name = p;
             a.C = C;
             a.res_div = s.res_div;
@@ -267,7 +278,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                         const float* src = gb ? cbp : cgp;
                         const float al = gb ? ab : ag;
                         // f16x3 path: the ACE epilogue expects the style LUT pre-multiplied by the output scale (conv_sh16.h)
-                        const float als = use_sh16 ? al * SH16_ACT_SCALE : al;
+                        const float als = use_sh16 ? al * a.out_scale : al;
                         for (int k = 0; k < STYLE; ++k) rows[(size_t)row * STYLE + k] = als * src[((size_t)cc * STYLE + k) * 9 + t];
                     }
                     a.lut_rows = B.upload(rows);
@@ -279,7 +290,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             a.bias_g = B.upload(vbg);
             a.bias_b = B.upload(vbb);
         };
-        if (bw.learned) ace(bw.name + ".ace_s", bw.fin, bw.ace_s);
+        if (bw.learned) ace(bw.name + ".ace_s", bw.fin, bw.ace_s, std::ldexp(SH16_ACT_SCALE, fuse_shift));
         ace(bw.name + ".ace_0", bw.fin, bw.ace_0);
         ace(bw.name + ".ace_1", bw.fmid, bw.ace_1);
         if (!B.err.empty()) return B.err;
@@ -423,7 +434,7 @@ struct Runner {
         auto it = m.taps.find(name);
         if (it == m.taps.end() || !it->second) return;
         if (m.use_sh16)
-            check(sh16_decode(src, it->second, B, C, (long long)hw, SH16_ACT_SCALE, m.amax_slots + 2 * producer.index, st), "tap decode");
+            check(sh16_decode(src, it->second, B, C, (long long)hw, producer.out_scale, m.amax_slots + 2 * producer.index, st), "tap decode");
         else check(hipMemcpyAsync(it->second, src, (size_t)B * C * hw * 4, hipMemcpyDeviceToDevice, st), "tap copy");
     }
     // f32 tensors between kernels are NCHW on the exact-f32 path and C4 ([B][C/4][HW][4]) on the f16x3 path
@@ -484,7 +495,7 @@ struct Runner {
                 p.wscale = a.lut_wscale;
                 p.in_scale_inv = 1.f / SH16_ACT_SCALE;
                 p.in_amax = mu_slot;
-                p.out_mul = SH16_ACT_SCALE;        // the ACE epilogue takes the LUT pre-multiplied by its output scale
+                p.out_mul = a.out_scale;           // the ACE epilogue takes the LUT pre-multiplied by its output scale
                 p.partial = m.splitk_ws;           // K = 512 in 32 chunks on few tiles (C <= 512): split-K fills the chip
                 p.partial_cap = m.splitk_cap;
                 timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
@@ -542,7 +553,7 @@ struct Runner {
         p.terms = m.terms;
         p.wscale = a.spade_wscale;
         p.in_scale_inv = 1.f / a.actv_scale;
-        p.out_scale = SH16_ACT_SCALE;
+        p.out_scale = a.out_scale;
         const double xin = npix * a.C / (x_up ? 4.0 : 1.0);
         p.out_amax = m.amax_slots + 2 * a.index;
         if ((m.dbg & 256) && a.index == m.dbg_sel) p.partial = m.splitk_ws;      // cycle stamps of this launch (profiling)
@@ -590,7 +601,7 @@ struct Runner {
         p.dbg = m.dbg;
         p.terms = m.terms;
         p.wscale = w.wscale;                       // shared with w2's rows when a 1x1 operand is fused (build())
-        p.in_scale_inv = 1.f / SH16_ACT_SCALE;     // inputs are ACE outputs
+        p.in_scale_inv = 1.f / prod.out_scale;     // inputs are ACE outputs (a fused second operand: see sh16_in_scale_inv)
         p.partial = m.splitk_ws;
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;

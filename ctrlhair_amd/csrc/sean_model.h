@@ -31,6 +31,8 @@ struct AceW {
     float* lut_wpk = nullptr;                   // rows (tap, gamma|beta, c) x K=512
     float* lut_rows = nullptr;                  // same rows, plain [18C][512] (GEMV path for batches <= 3)
     float *spade_wscale = nullptr, *lut_wscale = nullptr;   // f16x3 path: per-row 2^-k of the packed rows (sh16.h)
+    float out_scale = 8.f;                      // f16x3 path: first-pass SH16 scale of this ACE's output (SH16_ACT_SCALE; the
+                                                //   shortcut's ace_s carries the 2^D aligning conv_s with conv_1, sean_model.cpp)
     float actv_scale = 1.f;                     // f16x3 path: SH16 scale of the SPADE hidden activations (from a table bound)
 };
 
