@@ -24,9 +24,23 @@ def _cv2():
         return None
 
 
+def _linear_taps(n_out: int, n_in: int):
+    """Source taps and 11-bit weights of one axis of cv2.resize(INTER_LINEAR): half-pixel centres, taps clamped to the image,
+    weights rounded to 1/2048 (the two weights always sum to 2048)."""
+    f = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+    i0 = np.floor(f).astype(np.int64)
+    f = (f - i0).astype(np.float32)
+    f = np.where((i0 < 0) | (i0 >= n_in - 1), np.float32(0), f)
+    i0 = np.clip(i0, 0, n_in - 1)
+    w1 = np.rint(f * 2048.0).astype(np.int64)
+    w0 = np.rint((1.0 - f) * 2048.0).astype(np.int64)
+    return i0, np.minimum(i0 + 1, n_in - 1), w0, w1
+
+
 def resize_bilinear(img: np.ndarray, size) -> np.ndarray:
-    """cv2.resize(img, (w, h)) (INTER_LINEAR: half-pixel centres, edge clamp, no anti-aliasing).  uint8 in/out
-    (round-half-up like cv2's fixed point to within 1 LSB)."""
+    """cv2.resize(img, (w, h)) for uint8 images, in OpenCV's own fixed-point arithmetic (11-bit tap weights, int32 rows,
+    vertical pass with the >> 4 / >> 16 / + 2 / >> 2 rounding): bit-exact against tests/golden/host_vectors.npz.  Other
+    dtypes: plain float interpolation with the same taps."""
     cv2 = _cv2()
     if cv2 is not None:
         return cv2.resize(img, tuple(size))
@@ -34,22 +48,20 @@ def resize_bilinear(img: np.ndarray, size) -> np.ndarray:
     H, W = img.shape[:2]
     if (H, W) == (h, w):
         return img.copy()
+    x0, x1, a0, a1 = _linear_taps(w, W)
+    y0, y1, b0, b1 = _linear_taps(h, H)
+    tail = (1,) * (img.ndim - 2)
+    if img.dtype == np.uint8:
+        a = img.astype(np.int64)
+        rows = a[:, x0] * a0.reshape((1, -1) + tail) + a[:, x1] * a1.reshape((1, -1) + tail)
+        top, bot = rows[y0] >> 4, rows[y1] >> 4
+        out = (((b0.reshape((-1, 1) + tail) * top) >> 16) + ((b1.reshape((-1, 1) + tail) * bot) >> 16) + 2) >> 2
+        return np.clip(out, 0, 255).astype(np.uint8)
     a = img.astype(np.float32)
-
-    def axis(n_out, n_in):
-        t = (np.arange(n_out, dtype=np.float32) + 0.5) * (n_in / n_out) - 0.5
-        i0 = np.floor(t).astype(np.int64)
-        f = t - i0
-        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
-
-    y0, y1, fy = axis(h, H)
-    x0, x1, fx = axis(w, W)
-    fy = fy.reshape(-1, 1, *([1] * (a.ndim - 2)))
-    fx = fx.reshape(1, -1, *([1] * (a.ndim - 2)))
-    top = a[y0][:, x0] * (1 - fx) + a[y0][:, x1] * fx
-    bot = a[y1][:, x0] * (1 - fx) + a[y1][:, x1] * fx
-    out = top * (1 - fy) + bot * fy
-    return np.clip(np.floor(out + 0.5), 0, 255).astype(img.dtype) if img.dtype == np.uint8 else out.astype(img.dtype)
+    fx = (a1 / 2048.0).astype(np.float32).reshape((1, -1) + tail)
+    fy = (b1 / 2048.0).astype(np.float32).reshape((-1, 1) + tail)
+    rows = a[:, x0] * (1 - fx) + a[:, x1] * fx
+    return (rows[y0] * (1 - fy) + rows[y1] * fy).astype(img.dtype)
 
 
 def resize_nearest(img: np.ndarray, size) -> np.ndarray:
@@ -61,42 +73,45 @@ def resize_nearest(img: np.ndarray, size) -> np.ndarray:
     return img[ys][:, xs]
 
 
+_HSV_SHIFT = 12
+_SDIV = np.array([0] + [int(np.rint((255 << _HSV_SHIFT) / v)) for v in range(1, 256)], np.int64)
+_HDIV = np.array([0] + [int(np.rint((180 << _HSV_SHIFT) / (6.0 * d))) for d in range(1, 256)], np.int64)
+
+
 def rgb_to_hsv_u8(rgb: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(uint8 RGB, COLOR_RGB2HSV): H in [0,180), S,V in [0,255]."""
+    """cv2.cvtColor(uint8 RGB, COLOR_RGB2HSV): H in [0,180), S,V in [0,255] -- OpenCV's 8-bit integer path (12-bit fixed
+    point with division tables), bit-exact against tests/golden/host_vectors.npz."""
     cv2 = _cv2()
     if cv2 is not None:
         return cv2.cvtColor(rgb.astype('uint8'), cv2.COLOR_RGB2HSV)
-    a = rgb.astype(np.float32)
+    a = rgb.astype(np.int64)
     r, g, b = a[..., 0], a[..., 1], a[..., 2]
     v = a.max(-1)
-    mn = a.min(-1)
-    d = v - mn
-    s = np.where(v > 0, d / np.maximum(v, 1e-12) * 255.0, 0.0)
-    dd = np.maximum(d, 1e-12)
-    h = np.where(v == r, (g - b) / dd, np.where(v == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd)) * 60.0
-    h = np.where(d == 0, 0.0, h)
-    h = np.where(h < 0, h + 360.0, h) / 2.0
-    out = np.stack([np.floor(h + 0.5) % 180, np.floor(s + 0.5), v], -1)
-    return np.clip(out, 0, 255).astype(np.uint8)
+    d = v - a.min(-1)
+    half = 1 << (_HSV_SHIFT - 1)
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * d, r - g + 4 * d))
+    h = (h * _HDIV[d] + half) >> _HSV_SHIFT
+    h = np.where(h < 0, h + 180, h)
+    sat = (d * _SDIV[v] + half) >> _HSV_SHIFT
+    return np.stack([h, sat, v], -1).astype(np.uint8)
 
 
 def hsv_to_rgb_u8(hsv: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(uint8 HSV, COLOR_HSV2RGB)."""
+    """cv2.cvtColor(uint8 HSV, COLOR_HSV2RGB): float32 sector formula on (h * 6/180, s/255, v/255), times 255, rounded half to
+    even and saturated (bit-exact against tests/golden/host_vectors.npz)."""
     cv2 = _cv2()
     if cv2 is not None:
         return cv2.cvtColor(hsv.astype('uint8'), cv2.COLOR_HSV2RGB)
     a = hsv.astype(np.float32)
-    h, s, v = a[..., 0] * 2.0, a[..., 1] / 255.0, a[..., 2]
-    c = v * s
-    hp = (h / 60.0) % 6.0
-    x = c * (1 - np.abs(hp % 2 - 1))
-    z = np.zeros_like(c)
-    sel = np.floor(hp).astype(np.int64)
-    r = np.choose(sel, [c, x, z, z, x, c])
-    g = np.choose(sel, [x, c, c, x, z, z])
-    b = np.choose(sel, [z, z, x, c, c, x])
-    m = v - c
-    return np.clip(np.floor(np.stack([r + m, g + m, b + m], -1) + 0.5), 0, 255).astype(np.uint8)
+    h, s, v = a[..., 0] * np.float32(6.0 / 180.0), a[..., 1] * np.float32(1.0 / 255.0), a[..., 2] * np.float32(1.0 / 255.0)
+    sec = np.floor(h).astype(np.int64)
+    f = h - sec
+    sec = sec % 6
+    p0, p1, p2, p3 = v, v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))
+    r = np.choose(sec, [p0, p2, p1, p1, p3, p0])
+    g = np.choose(sec, [p3, p0, p0, p2, p1, p1])
+    b = np.choose(sec, [p1, p1, p3, p0, p0, p2])
+    return np.clip(np.rint(np.stack([r, g, b], -1) * np.float32(255.0)), 0, 255).astype(np.uint8)
 
 
 _MASK_COLORS = np.array([[0, 128, 64], [204, 0, 0], [76, 153, 0], [204, 204, 0], [51, 51, 255], [204, 0, 204], [0, 255, 255],

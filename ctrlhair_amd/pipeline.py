@@ -27,34 +27,33 @@ _STD = (0.229, 0.224, 0.225)
 
 
 def rgb_to_hsv_u8(rgb: torch.Tensor) -> torch.Tensor:
-    """cv2.cvtColor(uint8 RGB, COLOR_RGB2HSV) on [N,3] uint8-valued tensors (same arithmetic as hostutil.rgb_to_hsv_u8:
-    H in [0,180), S, V in [0,255])."""
-    a = rgb.float()
+    """cv2.cvtColor(uint8 RGB, COLOR_RGB2HSV) on [N,3] uint8-valued tensors, on the tensor's device: the same 12-bit
+    fixed-point arithmetic as hostutil.rgb_to_hsv_u8 (H in [0,180), S, V in [0,255])."""
+    a = rgb.long()
     r, g, b = a[:, 0], a[:, 1], a[:, 2]
     v = a.max(dim=1).values
     d = v - a.min(dim=1).values
-    s = torch.where(v > 0, d / v.clamp_min(1e-12) * 255.0, torch.zeros_like(v))
-    dd = d.clamp_min(1e-12)
-    h = torch.where(v == r, (g - b) / dd, torch.where(v == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd)) * 60.0
-    h = torch.where(d == 0, torch.zeros_like(h), h)
-    h = torch.where(h < 0, h + 360.0, h) / 2.0
-    out = torch.stack([torch.floor(h + 0.5) % 180, torch.floor(s + 0.5), v], dim=1)
-    return out.clamp(0, 255)
+    sdiv = torch.as_tensor(U._SDIV, device=rgb.device)
+    hdiv = torch.as_tensor(U._HDIV, device=rgb.device)
+    half = 1 << (U._HSV_SHIFT - 1)
+    h = torch.where(v == r, g - b, torch.where(v == g, b - r + 2 * d, r - g + 4 * d))
+    h = (h * hdiv[d] + half) >> U._HSV_SHIFT
+    h = torch.where(h < 0, h + 180, h)
+    s = (d * sdiv[v] + half) >> U._HSV_SHIFT
+    return torch.stack([h, s, v], dim=1).float()
 
 
 def hsv_to_rgb_u8(hsv: torch.Tensor) -> torch.Tensor:
-    """cv2.cvtColor(uint8 HSV, COLOR_HSV2RGB) on [N,3] (hostutil.hsv_to_rgb_u8)."""
+    """cv2.cvtColor(uint8 HSV, COLOR_HSV2RGB) on [N,3] (hostutil.hsv_to_rgb_u8: float32 sector formula, round half to even)."""
     a = hsv.float()
-    h, s, v = a[:, 0] * 2.0, a[:, 1] / 255.0, a[:, 2]
-    c = v * s
-    hp = (h / 60.0) % 6.0
-    x = c * (1 - (hp % 2 - 1).abs())
-    z = torch.zeros_like(c)
-    sel = torch.floor(hp).long().clamp(0, 5)
-    pick = lambda opts: torch.stack(opts, dim=1).gather(1, sel[:, None])[:, 0]
-    r, g, b = pick([c, x, z, z, x, c]), pick([x, c, c, x, z, z]), pick([z, z, x, c, c, x])
-    m = v - c
-    return torch.floor(torch.stack([r + m, g + m, b + m], dim=1) + 0.5).clamp(0, 255)
+    h, s, v = a[:, 0] * (6.0 / 180.0), a[:, 1] * (1.0 / 255.0), a[:, 2] * (1.0 / 255.0)
+    sec = torch.floor(h).long()
+    f = h - sec
+    sec = sec % 6
+    p0, p1, p2, p3 = v, v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))
+    pick = lambda opts: torch.stack(opts, dim=1).gather(1, sec[:, None])[:, 0]
+    r, g, b = pick([p0, p2, p1, p1, p3, p0]), pick([p3, p0, p0, p2, p1, p1]), pick([p1, p1, p3, p0, p0, p2])
+    return torch.round(torch.stack([r, g, b], dim=1) * 255.0).clamp(0, 255)
 
 
 class EditPipeline:

@@ -72,3 +72,49 @@ def test_batched_masks_and_codes_equal_per_image_api(hip_lib, tmp_path):
         c = merged[f'ds___{i:02d}']
         assert c.shape == (19, 512) and c.dtype == np.float32
         assert np.abs(c - ref).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_files_on_disk_against_the_oracle(hip_lib, tmp_path):
+    """What lands on disk (label PNGs, code pickles) against the CPU ORACLE of the two networks on the same image files:
+    dataset_scripts/script_get_mask.py:55-71 and script_get_sean_code.py:40-62 in the reference's formats."""
+    from PIL import Image
+    import torch
+    from ctrlhair_amd import procedural as P
+    from ctrlhair_amd.hair_editor import HairEditor, procedural_weights
+    from ctrlhair_amd.models import BISENET_TO_CELEBA, _MEAN, _STD
+    from oracle import aux_oracle as A
+    from oracle import sean_oracle as O
+    w = procedural_weights(0, 64)
+    w['sean'] = P.sean_state_dict(0, 16)
+    he = HairEditor(True, True, weights=w, device=0, img_size=256, max_batch=2)
+    img_dir, label_dir, code_dir = tmp_path / 'ds' / 'images_256', tmp_path / 'ds' / 'label', tmp_path / 'codes'
+    img_dir.mkdir(parents=True)
+    imgs = ((P.synthetic_images(3, 256, seed=77).transpose(0, 2, 3, 1) * 0.5 + 0.5) * 255).astype(np.uint8)
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(img_dir / f'{i:02d}.png')
+    D.extract_masks(he, str(img_dir), str(label_dir), batch=2)
+    D.encode_sean_codes(he, str(img_dir), str(label_dir), str(code_dir), 'ds', batch=2)
+    bsd = {k: torch.from_numpy(np.asarray(v)) for k, v in w['bisenet'].items()}
+    ssd = O.to_torch(w['sean'])
+    mean, std = torch.tensor(_MEAN).view(1, 3, 1, 1), torch.tensor(_STD).view(1, 3, 1, 1)
+    for i in range(3):
+        im = np.asarray(Image.open(img_dir / f'{i:02d}.png').convert('RGB'))
+        # masks: PIL bilinear resize to 512, ToTensor + Normalize, BiSeNet, argmax, remap (my_parsing_util.py:31-54)
+        big = np.asarray(Image.fromarray(im).resize((512, 512), Image.BILINEAR))
+        x = (torch.from_numpy(big.copy()).permute(2, 0, 1)[None].float() / 255.0 - mean) / std
+        with torch.no_grad():
+            lg = A.bisenet_forward(bsd, x)
+        top2 = torch.topk(lg, 2, dim=1).values
+        ref = BISENET_TO_CELEBA[lg.argmax(1).numpy()[0]]
+        got = D.read_gray(str(label_dir / f'{i:02d}.png'))
+        low = ((top2[:, 0] - top2[:, 1]) < 5e-3).numpy()[0]
+        assert got.shape == ref.shape and not ((got != ref) & ~low).any()
+        # codes: the file's label map, nearest-resized to the image size, through the oracle Zencoder
+        lab = he.preprocess_mask(got)[0]
+        with torch.no_grad():
+            rc = O.zencoder_forward(ssd, he.preprocess_img(im).astype(np.float32), lab).numpy()[0]
+        with open(code_dir / f'ds___{i:02d}.pkl', 'rb') as f:
+            c = pickle.load(f)
+        assert c.shape == (19, 512) and c.dtype == np.float32 and np.abs(c - rc).max() <= 1e-3
+    he.models.generator.handle.close()
