@@ -160,6 +160,16 @@ int ch_sean_generate(ch_handle* h, const uint8_t* labels, const float* codes, co
     return CH_OK;
 }
 
+int ch_sean_draw_noise(ch_handle* h, uint64_t seed, float* noise, int B, int S, ch_stream_t stream) {
+    if (!h) return CH_ERR_ARG;
+    if (!h->sean_ready) return fail(h, CH_ERR_STATE, "ch_sean_draw_noise: SEAN weights not finalized");
+    if (!noise || B < 1) return fail(h, CH_ERR_ARG, "ch_sean_draw_noise: bad argument");
+    DeviceGuard guard(h->device);
+    std::string e = h->sean.draw_noise(seed, noise, B, S, static_cast<hipStream_t>(stream));
+    if (!e.empty()) return fail(h, CH_ERR_HIP, "ch_sean_draw_noise: " + e);
+    return CH_OK;
+}
+
 int ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float* codes, int B, int S,
                    ch_stream_t stream) {
     if (!h) return CH_ERR_ARG;

@@ -616,6 +616,20 @@ struct Runner {
 
 }  // namespace
 
+// seed of the planes of the batch chunk that starts at sample `bo` (ch_sean_generate with noise == NULL, ch_sean_draw_noise)
+static uint64_t chunk_seed(uint64_t seed, int bo) { return seed + 0x632BE59BD9B4E019ull * (uint64_t)(bo + 1); }
+
+std::string SeanModel::draw_noise(uint64_t seed, float* out, int Btot, int S, hipStream_t st) {
+    if (blocks.empty()) return "model not finalized";
+    if (S % 32 != 0 || S < 32 || S > max_size) return "S must be a multiple of 32 and <= max_size";
+    const size_t nf = noise_floats(S);
+    for (int bo = 0; bo < Btot; bo += max_batch) {
+        const int B = std::min(max_batch, Btot - bo);
+        if (gen_noise(out + (size_t)bo * nf, (long long)B * nf, chunk_seed(seed, bo), st) != hipSuccess) return "gen_noise failed";
+    }
+    return "";
+}
+
 std::string SeanModel::generate(const uint8_t* labels, const float* codes, const float* noise, uint64_t seed,
                                 float* out, int Btot, int S, hipStream_t st) {
     if (blocks.empty()) return "model not finalized";
@@ -631,8 +645,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         if (noise) {
             nz = noise + (size_t)bo * nf;
         } else {
-            R.check(gen_noise(noise_ws, (long long)B * nf, seed + 0x632BE59BD9B4E019ull * (uint64_t)(bo + 1), st),
-                    "gen_noise");
+            R.check(gen_noise(noise_ws, (long long)B * nf, chunk_seed(seed, bo), st), "gen_noise");
             nz = noise_ws;
         }
         for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");

@@ -83,6 +83,8 @@ struct SeanModel {
     std::string build(const TensorStore& ts, int max_batch, int max_size);
     std::string generate(const uint8_t* labels, const float* codes, const float* noise, uint64_t seed, float* out,
                          int B, int S, hipStream_t stream);
+    // the planes generate() draws on device when it is given noise == nullptr, written out explicitly
+    std::string draw_noise(uint64_t seed, float* out, int B, int S, hipStream_t stream);
     // Zencoder (style encoder + region average pooling), architecture.py:177-207
     std::string encode(const float* img, const uint8_t* labels, float* codes_out, int B, int S, hipStream_t stream);
     void destroy();

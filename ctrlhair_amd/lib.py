@@ -24,6 +24,7 @@ SYMBOLS = {
     'ch_finalize': (_I, [_VP, _I, _I, _I]),
     'ch_sean_noise_floats': (C.c_size_t, [_VP, _I]),
     'ch_sean_generate': (_I, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _I, _I, _VP]),
+    'ch_sean_draw_noise': (_I, [_VP, C.c_uint64, _VP, _I, _I, _VP]),
     'ch_sean_encode': (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
     'ch_color_generate': (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     'ch_color_encode': (_I, [_VP, _VP, _VP, _I, _VP]),

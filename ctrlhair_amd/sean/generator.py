@@ -57,6 +57,28 @@ class SeanGenerator:
         self.handle.sean_generate(labels.data_ptr(), codes.data_ptr(), nptr, seed, out.data_ptr(), B, S, stream)
         return out
 
+    def draw_noise(self, B: int, S: int, seed: int = 0) -> torch.Tensor:
+        """The planes `generate(..., noise=None, seed=seed)` uses, as a tensor [B, noise_floats(S)]."""
+        out = torch.empty(B, self.noise_floats(S), dtype=torch.float32, device=self.device)
+        self.handle.call('ch_sean_draw_noise', seed, out.data_ptr(), B, S, torch.cuda.current_stream(self.device).cuda_stream)
+        return out
+
+    def capture(self, labels: torch.Tensor, codes: torch.Tensor, noise: Optional[torch.Tensor] = None, seed: int = 0):
+        """hipGraph capture of one generate() call at fixed shapes (interactive use: a 256x256 render is ~400 launches of
+        1-40 us, so eager mode is host-launch bound).  Returns (graph, out): refill `labels` / `codes` / `noise` IN PLACE,
+        then graph.replay() and read `out`.  The library allocates nothing and never synchronises inside generate, so the
+        stock torch.cuda.CUDAGraph capture applies (device-drawn noise keeps the seed of the capture)."""
+        out = torch.empty(labels.shape[0], 3, labels.shape[-1], labels.shape[-1], dtype=torch.float32, device=labels.device)
+        side = torch.cuda.Stream(labels.device)
+        side.wait_stream(torch.cuda.current_stream(labels.device))
+        with torch.cuda.stream(side):
+            self.generate(labels, codes, noise, seed=seed, out=out)        # warm-up outside the capture (lazy kernel attributes)
+        torch.cuda.current_stream(labels.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.generate(labels, codes, noise, seed=seed, out=out)
+        return g, out
+
     def encode(self, img: torch.Tensor, labels: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Zencoder: img cuda float32 [B,3,S,S] in [-1,1], labels cuda uint8 [B,S,S] -> codes [B,19,512]
         (Pix2PixModel.forward(mode='style_code'), pix2pix_model.py:69-72)."""

@@ -86,6 +86,11 @@ size_t ch_sean_noise_floats(const ch_handle* h, int S);
 int  ch_sean_generate(ch_handle* h, const uint8_t* labels, const float* codes, const float* noise, uint64_t seed,
                       float* out, int B, int S, ch_stream_t stream);
 
+/* The noise planes ch_sean_generate(noise = NULL, seed) draws on device, written out: noise [B, noise_floats(S)] (device).
+ * ch_sean_generate(..., noise = these planes, ...) reproduces the NULL call bit for bit; the planes are i.i.d. N(0,1) from a
+ * counter-based generator (the reference draws torch.randn from an unseeded global generator, normalization.py:111). */
+int  ch_sean_draw_noise(ch_handle* h, uint64_t seed, float* noise, int B, int S, ch_stream_t stream);
+
 /* Replaces Pix2PixModel.forward(data, mode='style_code') -> Zencoder.forward
  * (pix2pix_model.py:69-72; architecture.py:177-207; callers hair_editor.py:149-157 get_code, :208-231):
  * conv stack (reflection-padded 3x3, two stride-2 convs, ConvTranspose2d, InstanceNorm + LeakyReLU, tanh) at

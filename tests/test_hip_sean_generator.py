@@ -147,3 +147,65 @@ def test_error_paths(hip_lib):
     dev = gen.device
     with pytest.raises(RuntimeError, match='multiple of 32'):
         gen.generate(torch.zeros(1, 48, 48, dtype=torch.uint8, device=dev), torch.zeros(1, 19, 512, device=dev))
+
+
+def test_device_noise_is_standard_normal_and_is_what_generate_uses(hip_lib):
+    """noise=None path: the planes (ch_sean_draw_noise) are N(0,1), serially uncorrelated, independent between planes,
+    samples and seeds; and generate(noise=None, seed) is bit-identical to generate(noise=those planes)."""
+    from ctrlhair_amd import procedural as P
+    ngf, S, B = 16, 128, 11                      # max_batch 8: two chunks, the second one gets its own stream of numbers
+    gen = gen_for(ngf, path='f16x3')
+    z = gen.draw_noise(B, S, seed=123)
+    torch.cuda.synchronize()
+    a = z.cpu().numpy().astype(np.float64)
+    n = a.size
+    assert n > 2e6
+    m, v = a.mean(), a.var()
+    skew = ((a - m) ** 3).mean() / v ** 1.5
+    kurt = ((a - m) ** 4).mean() / v ** 2
+    print(f'n={n} mean {m:.2e} var {v:.5f} skew {skew:.2e} kurtosis {kurt:.4f} max {np.abs(a).max():.2f}')
+    assert abs(m) < 5 / np.sqrt(n) and abs(v - 1) < 5 * np.sqrt(2 / n) and abs(skew) < 5 * np.sqrt(6 / n) \
+        and abs(kurt - 3) < 5 * np.sqrt(24 / n)
+    assert 4.0 < np.abs(a).max() < 7.0           # tails present, nothing absurd
+    flat = a.reshape(-1)
+    for lag in (1, 2, 7, 128):                   # serial correlation (lag 128 = the next row of a 128-wide plane)
+        assert abs(np.mean(flat[:-lag] * flat[lag:])) < 5 / np.sqrt(n)
+    # plane-to-plane / sample-to-sample / seed-to-seed independence
+    assert abs(np.mean(a[0] * a[1])) < 5 / np.sqrt(a.shape[1]) and abs(np.mean(a[3] * a[9])) < 5 / np.sqrt(a.shape[1])
+    r2 = S * S                                    # the three full-resolution planes of up_3 sit at the end of a sample's block
+    p1, p2 = a[:, -r2:], a[:, -2 * r2:-r2]
+    assert abs(np.mean(p1 * p2)) < 5 / np.sqrt(p1.size)
+    z2 = gen.draw_noise(B, S, seed=124).cpu().numpy()
+    assert abs(np.mean(a * z2)) < 5 / np.sqrt(n) and not np.array_equal(a[:1], z2[:1])
+    # uniform marginal through the normal CDF (Kolmogorov-Smirnov distance on a subsample)
+    from scipy import stats
+    ks = stats.kstest(flat[::37], 'norm').statistic
+    assert ks < 1.63 / np.sqrt(flat[::37].size) * 1.5
+    dev = gen.device
+    labels, codes = torch.from_numpy(P.blocky_labels(B, S, grid=8)).to(dev), torch.from_numpy(P.style_codes(B)).to(dev)
+    x = gen.generate(labels, codes, None, seed=123)
+    y = gen.generate(labels, codes, z)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+
+
+def test_graph_replay_equals_eager(hip_lib):
+    """hipGraph capture of a batch-1 render (SeanGenerator.capture): replays with refilled inputs equal eager calls."""
+    from ctrlhair_amd import procedural as P
+    ngf, S = 16, 128
+    gen = gen_for(ngf, path='f16x3')
+    dev = gen.device
+    lab = torch.from_numpy(P.blocky_labels(1, S, grid=8)).to(dev)
+    cd = torch.from_numpy(P.style_codes(1)).to(dev)
+    nz = torch.from_numpy(P.noise_planes(1, S, ngf)).to(dev)
+    g, out = gen.capture(lab, cd, nz)
+    for seed in (5, 6):
+        lab.copy_(torch.from_numpy(P.blocky_labels(1, S, grid=8, seed=seed)))
+        cd.copy_(torch.from_numpy(P.style_codes(1, seed=seed)))
+        nz.copy_(torch.from_numpy(P.noise_planes(1, S, ngf, seed=seed)))
+        g.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        ref = gen.generate(lab, cd, nz)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
