@@ -82,7 +82,7 @@ def test_files_on_disk_against_the_oracle(hip_lib, tmp_path):
     import torch
     from ctrlhair_amd import procedural as P
     from ctrlhair_amd.hair_editor import HairEditor, procedural_weights
-    from ctrlhair_amd.models import BISENET_TO_CELEBA, _MEAN, _STD
+    from ctrlhair_amd.models import _MEAN, _STD
     from oracle import aux_oracle as A
     from oracle import sean_oracle as O
     w = procedural_weights(0, 64)
@@ -103,10 +103,9 @@ def test_files_on_disk_against_the_oracle(hip_lib, tmp_path):
         # masks: PIL bilinear resize to 512, ToTensor + Normalize, BiSeNet, argmax, remap (my_parsing_util.py:31-54)
         big = np.asarray(Image.fromarray(im).resize((512, 512), Image.BILINEAR))
         x = (torch.from_numpy(big.copy()).permute(2, 0, 1)[None].float() / 255.0 - mean) / std
-        with torch.no_grad():
-            lg = A.bisenet_forward(bsd, x)
+        lg, ref = A.bisenet_forward(bsd, x)                # (logits, CelebAMask-HQ ids)
         top2 = torch.topk(lg, 2, dim=1).values
-        ref = BISENET_TO_CELEBA[lg.argmax(1).numpy()[0]]
+        ref = ref.numpy()[0]
         got = D.read_gray(str(label_dir / f'{i:02d}.png'))
         low = ((top2[:, 0] - top2[:, 1]) < 5e-3).numpy()[0]
         assert got.shape == ref.shape and not ((got != ref) & ~low).any()
