@@ -296,8 +296,9 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
     if (!h || !key) return CH_ERR_ARG;
     if (std::strcmp(key, "sean.f16x3") == 0) {
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.f16x3) must precede ch_finalize");
-        h->sean.use_sh16 = value != 0;          // 0 exact f32 | 1 f16x3 split operands (f32-class) | 2 single-term f16 operands
-        h->sean.terms = value == 2 ? 1 : 3;
+        // 0 exact f32 | 1 f16x3 split operands (f32-class) | 2 single-term f16 operands | 3 single-term bf16 operands
+        h->sean.use_sh16 = value != 0;
+        h->sean.terms = value == 2 ? 1 : (value == 3 ? 2 : 3);
         return CH_OK;
     }
     if (std::strcmp(key, "sean.dbg_sel") == 0) {

@@ -1,0 +1,6 @@
+// single-term bf16 SPADE conv with fused ACE epilogue: the TERMS = 2 instantiations of conv_sh16.h (BASELINE.json configs[4])
+#include "conv_sh16.h"
+#include "conv_sh16_ws2.h"
+namespace chk {
+hipError_t conv_bf16_ace(const ConvParams& p, hipStream_t s) { return dispatch_sh16_ace<2>(p, s); }
+}  // namespace chk

@@ -2,5 +2,5 @@
 #include "conv_sh16.h"
 #include "conv_sh16_ws2.h"
 namespace chk {
-hipError_t conv_h16_ace(const ConvParams& p, hipStream_t s) { return dispatch_sh16_ace<1>(p, s); }
+hipError_t conv_h16_ace(const ConvParams& p, hipStream_t s) { return p.terms == 2 ? conv_bf16_ace(p, s) : dispatch_sh16_ace<1>(p, s); }
 }  // namespace chk

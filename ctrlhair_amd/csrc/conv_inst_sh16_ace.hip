@@ -3,6 +3,6 @@
 #include "conv_sh16_ws2.h"
 namespace chk {
 hipError_t conv_sh16_ace(const ConvParams& p, hipStream_t s) {
-    return p.terms == 1 ? conv_h16_ace(p, s) : dispatch_sh16_ace<3>(p, s);
+    return (p.terms == 1 || p.terms == 2) ? conv_h16_ace(p, s) : dispatch_sh16_ace<3>(p, s);
 }
 }  // namespace chk

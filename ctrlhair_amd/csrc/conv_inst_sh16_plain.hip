@@ -2,7 +2,7 @@
 #include "conv_sh16.h"
 namespace chk {
 hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s) {
-    if (p.terms == 1) return conv_h16_plain(p, KS, s);
+    if (p.terms == 1 || p.terms == 2) return conv_h16_plain(p, KS, s);
     return KS == 3 ? dispatch_sh16_plain<3, 3>(p, s) : (KS == 1 ? dispatch_sh16_plain<1, 3>(p, s) : hipErrorInvalidValue);
 }
 }  // namespace chk

@@ -42,6 +42,18 @@ struct ShCfg {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// TERMS: 3 = three-term f16 split (f32-class) | 1 = f16 operands (hi planes only) | 2 = bf16 operands (the hi planes hold
+// bf16 bit patterns instead of f16; same layouts, same kernels, v_mfma_f32_32x32x16_bf16) -- BASELINE.json configs[4]
+template <int TERMS>
+__device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c) {
+    if constexpr (TERMS == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
 
 // ACE modulation of 4 consecutive channels of one pixel, written on float2 pairs so that the arithmetic maps onto the
 // packed-f32 VALU ops (v_pk_add/mul/fma_f32) and v_cvt_pk_f16_f32:
@@ -52,7 +64,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // pass of a tensor whose maximum left the f16 window): one more multiply by the corrective power of two.  !RESC: the
 // running max |o| is kept in `amax`.  f32 -> f16 conversions saturate (MODE.FP16_OVFL, set at kernel entry).
 // Returns the f16 hi halves in .x/.y and the residual lo halves in .z/.w (two channels per dword).
-template <bool RESC>
+template <bool RESC, bool BF = false>
 __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3, float b0, float b1, float b2, float b3,
                                           float st, const float4& bg, const float4& bb, const float4& pa, const float4& pd,
                                           const float4& pn, const float4& x4, float nz, float slope, float extra, float& amax) {
@@ -72,11 +84,17 @@ __device__ __forceinline__ uint4 ace_quad(float g0, float g1, float g2, float g3
         o.y = fmaxf(o.y, os.y);
         if (RESC) o = o * extra;
         else amax = fmaxf(fmaxf(amax, fabsf(o.x)), fabsf(o.y));       // v_max3_f32 with |.| source modifiers
-        const f16x2 hh = __builtin_convertvector(o, f16x2);
-        const f32x2 lo = o - __builtin_convertvector(hh, f32x2);
-        const f16x2 ll = __builtin_convertvector(lo, f16x2);
-        if (h == 0) { w.x = __builtin_bit_cast(unsigned, hh); w.z = __builtin_bit_cast(unsigned, ll); }
-        else        { w.y = __builtin_bit_cast(unsigned, hh); w.w = __builtin_bit_cast(unsigned, ll); }
+        if constexpr (BF) {                                  // bf16 operands: hi plane = bf16 bits, lo plane unused
+            const bf16x2 hb = __builtin_convertvector(o, bf16x2);
+            if (h == 0) { w.x = __builtin_bit_cast(unsigned, hb); w.z = 0u; }
+            else        { w.y = __builtin_bit_cast(unsigned, hb); w.w = 0u; }
+        } else {
+            const f16x2 hh = __builtin_convertvector(o, f16x2);
+            const f32x2 lo = o - __builtin_convertvector(hh, f32x2);
+            const f16x2 ll = __builtin_convertvector(lo, f16x2);
+            if (h == 0) { w.x = __builtin_bit_cast(unsigned, hh); w.z = __builtin_bit_cast(unsigned, ll); }
+            else        { w.y = __builtin_bit_cast(unsigned, hh); w.w = __builtin_bit_cast(unsigned, ll); }
+        }
     }
     return w;
 }
@@ -118,7 +136,7 @@ __device__ __forceinline__ uint4 sh16_pair_swap(const uint4& w) {
     return make_uint4(r0[0], r1[0], r0[1], r1[1]);
 }
 
-template <int TW, int TH, int TB, int EPI>
+template <int TW, int TH, int TB, int EPI, bool BF = false>
 __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)[2][4], int mtile64, int wn, int lane,
                                               int x0, int y0, int b0, int ks = 0) {
     const int HW = p.H * p.W;
@@ -289,7 +307,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                     const float4 x4 = *reinterpret_cast<const float4*>(xbase + (xo_[n] + (unsigned)(cc >> 2) * xHW * 16u));
                     const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
                     const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
-                    uint4 w = ace_quad<RESC>(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
+                    uint4 w = ace_quad<RESC, BF>(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
                                              acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
                                              st, bg, bb, pa, pd, pn, x4, nzv[n], slope, extra, amax);
                     if (!cok) w = make_uint4(0, 0, 0, 0);            // padding channels of the last group hold zeros
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
                     soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
                 }
             }
-            if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
+            if (TERMS != 3 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
         }
     }
     // FUSE: the two inputs share the accumulators (sh16_in_scale_inv).  mul1 = mul2 = 1 unless a second pass changed one of
@@ -471,17 +489,14 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
-                const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
+                const uint4 ah = a_cur[m * 2 + 0], al = a_cur[m * 2 + 1];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const half8 xh = __builtin_bit_cast(half8, bh[n]);
-                    const half8 xl = __builtin_bit_cast(half8, bl[n]);
                     if (TERMS == 3) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m][n], 0, 0, 0);
+                        acc[m][n] = mfma16<TERMS>(al, bh[n], acc[m][n]);
+                        acc[m][n] = mfma16<TERMS>(ah, bl[n], acc[m][n]);
                     }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m][n], 0, 0, 0);
+                    acc[m][n] = mfma16<TERMS>(ah, bh[n], acc[m][n]);
                 }
             }
 #pragma unroll
@@ -510,17 +525,14 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const half8 ah = __builtin_bit_cast(half8, a2[m * 2 + 0]);
-                const half8 al = __builtin_bit_cast(half8, a2[m * 2 + 1]);
+                const uint4 ah = a2[m * 2 + 0], al = a2[m * 2 + 1];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const half8 xh = __builtin_bit_cast(half8, bh[n]);
-                    const half8 xl = __builtin_bit_cast(half8, bl[n]);
                     if (TERMS == 3) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m][n], 0, 0, 0);
+                        acc[m][n] = mfma16<TERMS>(al, bh[n], acc[m][n]);
+                        acc[m][n] = mfma16<TERMS>(ah, bl[n], acc[m][n]);
                     }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m][n], 0, 0, 0);
+                    acc[m][n] = mfma16<TERMS>(ah, bh[n], acc[m][n]);
                 }
             }
             __syncthreads();
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     }
 
     if (p.dbg & 4) return;
-    sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0, ks);
+    sh16_epilogue<TW, TH, TB, EPI, TERMS == 2>(p, acc, mtile64, wn, lane, x0, y0, b0, ks);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     }
                     if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                         soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
-                    if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
+                    if (TERMS != 3 && (gh & 1)) soff[i] = -1;           // single-term f16 path never reads the lo planes
                 }
             }
             cur_tile = k;
@@ -788,12 +800,8 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * i + jj, term = j >> 3, m = (j & 7) >> 2, n = j & 3;
-                        if (TERMS == 1 && term != 2) continue;
-                        const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
-                        const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
-                        const half8 xh = __builtin_bit_cast(half8, bh[n]);
-                        const half8 xl = __builtin_bit_cast(half8, bl[n]);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al : ah, term == 1 ? xl : xh, acc[m][n], 0, 0, 0);
+                        if (TERMS != 3 && term != 2) continue;
+                        acc[m][n] = mfma16<TERMS>(a_cur[m * 2 + (term == 0 ? 1 : 0)], term == 1 ? bl[n] : bh[n], acc[m][n]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         if (stamp && k < 64) stamps[k * 3 + 1] = __builtin_amdgcn_s_memtime();
         if (p.dbg & 4) continue;
         if constexpr (!pre) {
-            sh16_epilogue<TW, TH, TB, EPI>(p, acc, mtile64, wn, lane, x0, y0, b0);
+            sh16_epilogue<TW, TH, TB, EPI, TERMS == 2>(p, acc, mtile64, wn, lane, x0, y0, b0);
         } else {
             // ---- ACE epilogue fed from LDS (x, parameters, noise, labels): no global load except the style-LUT gathers
             const int C = p.C, Go = (C + 7) >> 3;
@@ -866,7 +874,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                         }
                         const float4 bg = make_float4(pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w);
                         const float4 bb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
-                        uint4 w = ace_quad<RESC>(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
+                        uint4 w = ace_quad<RESC, TERMS == 2>(acc[0][n][rq * 4 + 0], acc[0][n][rq * 4 + 1], acc[0][n][rq * 4 + 2], acc[0][n][rq * 4 + 3],
                                                  acc[1][n][rq * 4 + 0], acc[1][n][rq * 4 + 1], acc[1][n][rq * 4 + 2], acc[1][n][rq * 4 + 3],
                                                  st, bg, bb, pa, pd, pn, x4, nz, slope, extra, amax);
                         if (!cok) w = make_uint4(0, 0, 0, 0);
@@ -1045,10 +1053,12 @@ hipError_t dispatch_sh16_plain(const ConvParams& p, hipStream_t s) {
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, TERMS>(p, p.Mrows, s);
 }
 
-// p.terms == 1 selects the single-term instantiations (operands rounded to f16, f32 accumulate: BASELINE configs[4])
+// p.terms == 1 / 2 selects the single-term instantiations (operands rounded to f16 / bf16, f32 accumulate: BASELINE configs[4])
 hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s);   // SH16 in -> f32 C4 out
 hipError_t conv_sh16_ace(const ConvParams& p, hipStream_t s);             // SH16 in -> SH16 out (fused ACE)
 hipError_t conv_h16_plain(const ConvParams& p, int KS, hipStream_t s);    // the TERMS = 1 instantiations
 hipError_t conv_h16_ace(const ConvParams& p, hipStream_t s);
+hipError_t conv_bf16_plain(const ConvParams& p, int KS, hipStream_t s);   // the TERMS = 2 instantiations
+hipError_t conv_bf16_ace(const ConvParams& p, hipStream_t s);
 
 }  // namespace chk

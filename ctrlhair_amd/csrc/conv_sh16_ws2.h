@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws2_kernel(const ConvParams 
                     const int y = y0 + py - 1, x = x0 + px - 1;
                     if (b0 < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                         soff[i] = ((b0 * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
-                    if (TERMS == 1 && (gh & 1)) soff[i] = -1;           // single-term path never reads the lo planes
+                    if (TERMS != 3 && (gh & 1)) soff[i] = -1;           // single-term path never reads the lo planes
                 }
             }
             cur_tile = k;
@@ -313,11 +313,17 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws2_kernel(const ConvParams 
         (void)step_cc(s, cok);
         const float am = fmaxf(fmaxf(amax, fabsf(o.x)), fabsf(o.y));
         if (pvalid[n] && cok) amax = am;                      // (no tile yet / padding channels: not recorded)
-        const f16x2 hh = __builtin_convertvector(o, f16x2);
-        const f32x2 lo = o - __builtin_convertvector(hh, f32x2);
-        const f16x2 ll = __builtin_convertvector(lo, f16x2);
-        if (h == 0) { wq.x = __builtin_bit_cast(unsigned, hh); wq.z = __builtin_bit_cast(unsigned, ll); }
-        else        { wq.y = __builtin_bit_cast(unsigned, hh); wq.w = __builtin_bit_cast(unsigned, ll); }
+        if constexpr (TERMS == 2) {
+            const bf16x2 hb = __builtin_convertvector(o, bf16x2);
+            if (h == 0) { wq.x = __builtin_bit_cast(unsigned, hb); wq.z = 0u; }
+            else        { wq.y = __builtin_bit_cast(unsigned, hb); wq.w = 0u; }
+        } else {
+            const f16x2 hh = __builtin_convertvector(o, f16x2);
+            const f32x2 lo = o - __builtin_convertvector(hh, f32x2);
+            const f16x2 ll = __builtin_convertvector(lo, f16x2);
+            if (h == 0) { wq.x = __builtin_bit_cast(unsigned, hh); wq.z = __builtin_bit_cast(unsigned, ll); }
+            else        { wq.y = __builtin_bit_cast(unsigned, hh); wq.w = __builtin_bit_cast(unsigned, ll); }
+        }
     };
     auto finalize_store = [&](auto sc) {
         constexpr int s = decltype(sc)::value, n = s >> 2, rq = s & 3;
@@ -381,12 +387,8 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws2_kernel(const ConvParams 
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * i + jj, term = j >> 2, m = (j & 3) >> 1, n = j & 1;
-                        if (TERMS == 1 && term != 2) continue;
-                        const half8 ah = __builtin_bit_cast(half8, a_cur[m * 2 + 0]);
-                        const half8 al = __builtin_bit_cast(half8, a_cur[m * 2 + 1]);
-                        const half8 xh = __builtin_bit_cast(half8, bh[n]);
-                        const half8 xl = __builtin_bit_cast(half8, bl[n]);
-                        cur[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al : ah, term == 1 ? xl : xh, cur[m][n], 0, 0, 0);
+                        if (TERMS != 3 && term != 2) continue;
+                        cur[m][n] = mfma16<TERMS>(a_cur[m * 2 + (term == 0 ? 1 : 0)], term == 1 ? bl[n] : bh[n], cur[m][n]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

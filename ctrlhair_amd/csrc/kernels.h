@@ -9,13 +9,13 @@ hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* b
                           int K, int relu, hipStream_t s, int c4 = 0);
 // `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
-                               int K, int relu, float scale, hipStream_t s);
+                               int K, int relu, float scale, hipStream_t s, int bf16 = 0);
 // amax: device slot of a dynamically scaled tensor (sh16.h), null = static scale
 hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, const unsigned* amax,
-                       hipStream_t s);
+                       hipStream_t s, int bf16 = 0);
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad, hipStream_t s,
                  float* mu_rows = nullptr, int sh16 = 0, int bs = 19, float scale = 1.f, unsigned* amax = nullptr,
-                 int pass = 0);
+                 int pass = 0, int bf16 = 0);
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                          hipStream_t s, int c4 = 0);
 hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hipStream_t s);

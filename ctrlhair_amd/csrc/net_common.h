@@ -127,7 +127,7 @@ std::vector<int> sh16_row_exponents(int rows, int Cin, int KS, F get) {
     return k;
 }
 template <class F>
-std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get, const std::vector<int>& kexp) {
+std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get, const std::vector<int>& kexp, bool bf16 = false) {
     const int mt64 = (rows + 63) / 64, nch = (Cin + 15) / 16, nt = KS * KS;
     std::vector<_Float16> dst((size_t)mt64 * nch * nt * 2 * 2 * 64 * 8, (_Float16)0.f);
     size_t o = 0;
@@ -142,6 +142,15 @@ std::vector<float> pack_A_sh16(int rows, int Cin, int KS, F get, const std::vect
                                 const int ci = ch * 16 + (lane >> 5) * 8 + e;
                                 if (row < rows && ci < Cin) {
                                     const float w = std::ldexp(get(row, ci, t), kexp[row]);
+                                    if (bf16) {            // bf16 single-term mode: hi = bf16 bits (round to nearest even), lo unused
+                                        uint32_t u;
+                                        std::memcpy(&u, &w, 4);
+                                        const uint16_t b = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+                                        _Float16 hb;
+                                        std::memcpy(&hb, &b, 2);
+                                        dst[o] = hl == 0 ? hb : (_Float16)0.f;
+                                        continue;
+                                    }
                                     const _Float16 h = (_Float16)w;
                                     dst[o] = hl == 0 ? h : (_Float16)(w - (float)h);
                                 }

@@ -88,7 +88,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t* __restrict__ lab,
                                                                   const float* __restrict__ table,
                                                                   const float* __restrict__ bias, uint4* __restrict__ out,
-                                                                  int B, int H, int W, int K, int relu, float scale) {
+                                                                  int B, int H, int W, int K, int relu, float scale, int bf16) {
     // Table slice in LDS with a padded row pitch (36 floats: consecutive (label, tap) rows start 4 banks apart, so lanes
     // that hold different labels do not collide on the same banks) and one extra all-zero row that taps outside the image
     // point at -- every lane then issues the same 9 x 2 ds_read_b128 per 8 channels, no predication.
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
             if (relu) v = v > 0.f ? v : 0.f;
             if (k0 + gq * 8 + e >= K) v = 0.f;
             _Float16 h, l;
-            sh16_split(v, scale, h, l);
+            sh16_split_any(v, scale, bf16, h, l);
             vh[e] = h;
             vl[e] = l;
         }
@@ -150,17 +150,17 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
 }
 
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
-                               int K, int relu, float scale, hipStream_t s) {
+                               int K, int relu, float scale, hipStream_t s, int bf16) {
     const long long npix = (long long)B * H * W;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
     hipLaunchKernelGGL(onehot_conv3x3_sh16_kernel, grid, dim3(256), 0, s, lab, table, bias, static_cast<uint4*>(out), B, H,
-                       W, K, relu, scale);
+                       W, K, relu, scale, bf16);
     return hipGetLastError();
 }
 
 // SH16 -> f32 NCHW (test taps only)
 __global__ void sh16_decode_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int B, int C, long long HW,
-                                   float inv_scale, const unsigned* __restrict__ amax) {
+                                   float inv_scale, const unsigned* __restrict__ amax, int bf16) {
     if (amax) inv_scale /= sh16_dyn_extra(*amax);
     const long long n = (long long)B * C * HW;
     const int G = (C + 7) / 8;
@@ -168,13 +168,14 @@ __global__ void sh16_decode_kernel(const _Float16* __restrict__ in, float* __res
         const long long p = i % HW;
         const int c = (int)((i / HW) % C), b = (int)(i / (HW * C));
         const long long unit = (((long long)b * G + c / 8) * 2) * HW + p;
-        out[i] = ((float)in[unit * 8 + (c & 7)] + (float)in[(unit + HW) * 8 + (c & 7)]) * inv_scale;
+        if (bf16) out[i] = (float)__builtin_bit_cast(__bf16, in[unit * 8 + (c & 7)]) * inv_scale;
+        else out[i] = ((float)in[unit * 8 + (c & 7)] + (float)in[(unit + HW) * 8 + (c & 7)]) * inv_scale;
     }
 }
 hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, const unsigned* amax,
-                       hipStream_t s) {
+                       hipStream_t s, int bf16) {
     hipLaunchKernelGGL(sh16_decode_kernel, dim3(4096), dim3(256), 0, s, static_cast<const _Float16*>(in), out, B, C, HW,
-                       1.f / scale, amax);
+                       1.f / scale, amax, bf16);
     return hipGetLastError();
 }
 
@@ -202,7 +203,7 @@ constexpr int FCMU_BT = 8;
 __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ codes, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ mu_img, int B,
                                                     int Npad, float* __restrict__ mu_rows, int sh16, int bs, float scale,
-                                                    unsigned* __restrict__ amax, int pass) {
+                                                    unsigned* __restrict__ amax, int pass, int bf16) {
     // SH16 output (f16x3 LUT GEMM): first pass writes with `scale` and records max |mu * scale|; the second pass returns
     // at once unless that maximum left the f16 window, else rewrites with the corrected scale (sh16.h)
     sh16_mode_on();
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
                         else if (sh16) {   // split-operand image [512/8][hi|lo][Npad][8] for the f16x3 LUT GEMM
                             _Float16* mh = reinterpret_cast<_Float16*>(mu_img);
                             _Float16 h, l;
-                            sh16_split(r, scale, h, l);
+                            sh16_split_any(r, scale, bf16, h, l);
                             vmax = fmaxf(vmax, r * scale);
                             mh[(((long long)(o >> 3) * 2 + 0) * Npad + n) * 8 + (o & 7)] = h;
                             mh[(((long long)(o >> 3) * 2 + 1) * Npad + n) * 8 + (o & 7)] = l;
@@ -282,9 +283,9 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
 }
 
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad,
-                 hipStream_t s, float* mu_rows, int sh16, int bs, float scale, unsigned* amax, int pass) {
+                 hipStream_t s, float* mu_rows, int sh16, int bs, float scale, unsigned* amax, int pass, int bf16) {
     hipLaunchKernelGGL(fc_mu_kernel, dim3(512 / 16, 19), dim3(256), 0, s, codes, Wt, bias, mu_img, B, Npad, mu_rows, sh16, bs,
-                       scale, amax, pass);
+                       scale, amax, pass, bf16);
     return hipGetLastError();
 }
 

@@ -112,7 +112,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             if (!r.w) return;
             auto getw = sn_get(r);
             if (use_sh16) {
-                cw.wpk = B.upload(pack_A_sh16(r.cout, r.cin, r.ks, getw, *kexp));
+                cw.wpk = B.upload(pack_A_sh16(r.cout, r.cin, r.ks, getw, *kexp, terms == 2));
                 cw.wscale = B.upload(sh16_wscale(*kexp));
             } else {
                 cw.wpk = B.upload(pack_A(r.cout, r.cin, r.ks, r.ks == 3 ? CK_KS3 : CK_KS1, getw));
@@ -232,7 +232,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     for (int r = 0; r < 64; ++r) km = std::min(km, kexp[t0 + r]);
                     for (int r = 0; r < 64; ++r) kexp[t0 + r] = km;
                 }
-                a.spade_wpk = B.upload(pack_A_sh16(tiles * 64, HID, 3, getsp, kexp));
+                a.spade_wpk = B.upload(pack_A_sh16(tiles * 64, HID, 3, getsp, kexp, terms == 2));
                 a.spade_wscale = B.upload(sh16_wscale(kexp));
             } else {
                 a.spade_wpk = B.upload(pack_A(tiles * 64, HID, 3, CK_KS3, getsp));
@@ -266,7 +266,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 };
                 if (use_sh16) {
                     const auto kexp = sh16_row_exponents(18 * C, STYLE, 1, getl);
-                    a.lut_wpk = B.upload(pack_A_sh16(18 * C, STYLE, 1, getl, kexp));
+                    a.lut_wpk = B.upload(pack_A_sh16(18 * C, STYLE, 1, getl, kexp, terms == 2));
                     a.lut_wscale = B.upload(sh16_wscale(kexp));
                 } else {
                     a.lut_wpk = B.upload(pack_A(18 * C, STYLE, 1, CK_KS1, getl));
@@ -434,7 +434,7 @@ struct Runner {
         auto it = m.taps.find(name);
         if (it == m.taps.end() || !it->second) return;
         if (m.use_sh16)
-            check(sh16_decode(src, it->second, B, C, (long long)hw, producer.out_scale, m.amax_slots + 2 * producer.index, st), "tap decode");
+            check(sh16_decode(src, it->second, B, C, (long long)hw, producer.out_scale, m.amax_slots + 2 * producer.index, st, m.terms == 2), "tap decode");
         else check(hipMemcpyAsync(it->second, src, (size_t)B * C * hw * 4, hipMemcpyDeviceToDevice, st), "tap copy");
     }
     // f32 tensors between kernels are NCHW on the exact-f32 path and C4 ([B][C/4][HW][4]) on the f16x3 path
@@ -479,7 +479,7 @@ struct Runner {
                 // f16x3 LUT GEMM: 1x1 conv over the [npad/32 x 32] "image" of (sample, label) columns, C4 output
                 unsigned* mu_slot = m.amax_slots + 2 * a.index + 1;
                 for (int pass = 0; pass < 2; ++pass)     // second pass: returns at once unless the first one left the f16 window
-                    check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs, SH16_ACT_SCALE, mu_slot, pass), "fc_mu");
+                    check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs, SH16_ACT_SCALE, mu_slot, pass, m.terms == 2), "fc_mu");
                 ConvParams p{};
                 p.in = m.mu_img;
                 p.wpk = a.lut_wpk;
@@ -520,7 +520,7 @@ struct Runner {
             }
         }
         if (m.use_sh16)
-            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, a.actv_scale, st), "mlp_shared");
+            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, a.actv_scale, st, m.terms == 2), "mlp_shared");
         else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
         ConvParams p{};

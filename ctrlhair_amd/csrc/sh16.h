@@ -53,6 +53,17 @@ __device__ __forceinline__ void sh16_split(float v, float s, _Float16& h, _Float
     l = (_Float16)(t - (float)h);
 }
 
+// bf16 single-term mode (BASELINE.json configs[4]): the hi plane holds the bf16 bit pattern of v*s, the lo plane is unused
+__device__ __forceinline__ void sh16_split_any(float v, float s, int bf16, _Float16& h, _Float16& l) {
+    if (bf16) {
+        const __bf16 b = (__bf16)(v * s);
+        h = __builtin_bit_cast(_Float16, b);
+        l = (_Float16)0.f;
+    } else {
+        sh16_split(v, s, h, l);
+    }
+}
+
 __device__ __forceinline__ float sh16_wave_max(float m) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));

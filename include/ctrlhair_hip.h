@@ -58,7 +58,9 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   1  f16 matrix cores with the 3-term split-operand scheme of ctrlhair_amd/csrc/conv_sh16.h: f32-class accuracy, f32
  *      accumulation, activations between ACE and conv stored as f16 hi/lo pairs;
  *   2  f16 matrix cores, single term: operands rounded to f16, f32 accumulation and f32 normalisation / modulation
- *      (the reduced-precision configuration of BASELINE.json configs[4]; tolerance 5e-2). */
+ *      (the reduced-precision configuration of BASELINE.json configs[4]; tolerance 5e-2);
+ *   3  bf16 matrix cores (v_mfma_f32_32x32x16_bf16), single term: operands rounded to bf16, f32 accumulation and f32
+ *      normalisation / modulation -- configs[4] as written ("bf16 MFMA conv path"; tolerance 5e-2). */
 int  ch_set_option(ch_handle* h, const char* key, int value);
 
 /* Fold + pack + upload the loaded tensors: spectral-norm sigma (torch spectral_norm eval semantics,
