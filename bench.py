@@ -42,13 +42,13 @@ PATH_OPTION = {'f32': 0, 'f16x3': 1, 'f16': 2, 'bf16': 3}
 
 
 def csrc_sha():
-    """Hash of the kernel sources: profiles/latest_traffic.json records the one its PMC passes were taken at."""
+    """Hash of the sources of the dominant kernels (the MFMA conv headers): profiles/latest_traffic.json records the one its
+    PMC passes were taken at; a mismatch means the committed traffic figure is stale and is not reported."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'ctrlhair_amd', 'csrc')
-    for f in sorted(os.listdir(d)):
-        if f.endswith(('.h', '.hip', '.cpp')):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), 'rb').read())
+    for f in ('conv_mfma.h', 'conv_sh16.h', 'conv_sh16_ws2.h', 'sh16.h'):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
 
 

@@ -22,7 +22,29 @@ def per_kernel(db, counter):
     return {(short(r[0]), r[1]): r[2:] for r in c.execute(q, (counter,))}
 
 
+def calibration(d):
+    """MFMA-only loop (tools/mfma_peak.hip) profiled with the same counters: returns (busy / GUI_ACTIVE of its longest
+    dispatches, its measured fraction of the 2.5 PFLOP/s dense peak) or None."""
+    db, log = os.path.join(d, 'peak', 't_results.db'), os.path.join(d, 'peak.log')
+    if not (os.path.exists(db) and os.path.exists(log)):
+        return None
+    c = sqlite3.connect(db)
+    q = ("select a.value, b.value from counters_collection a join counters_collection b on a.dispatch_id = b.dispatch_id "
+         "where a.counter_name='SQ_VALU_MFMA_BUSY_CYCLES' and b.counter_name='GRBM_GUI_ACTIVE' and a.kernel_name like '%mfma_loop%' "
+         "order by b.value desc limit 3")
+    try:
+        rows = list(c.execute(q))
+    except Exception:
+        return None
+    tf = [float(m.group(1)) for m in re.finditer(r'([0-9.]+) TFLOP/s', open(log).read())]
+    if not rows or not tf:
+        return None
+    r0 = sum(a / b for a, b in rows) / len(rows)
+    return r0, max(tf[-3:]) / 2500.0, max(tf[-3:])
+
+
 def main(d):
+    cal = calibration(d)
     f = per_kernel(os.path.join(d, 'fetch', 't_results.db'), 'FETCH_SIZE')
     w = per_kernel(os.path.join(d, 'write', 't_results.db'), 'WRITE_SIZE')
     sq = {}
@@ -31,7 +53,12 @@ def main(d):
         sq[name] = per_kernel(os.path.join(d, 'sq', 't_results.db'), name)
     print('# rocprofv3 PMC summary (separate --pmc passes: FETCH_SIZE | WRITE_SIZE | SQ/GRBM)\n')
     print('Per dispatch averages.  `fetch x2` = FETCH_SIZE doubled (gfx950 128-B request correction, upper bound).\n')
-    print('| kernel | grid (threads) | calls | fetch MB | fetch x2 MB | write MB | MFMA busy/(GUI_ACTIVE*1024) % (raw; counter appears to cover 1 of 8 XCDs -> x8) | LDS conflict % | avg ms (pmc pass) |')
+    if cal:
+        print(f'MFMA pipe busy is CALIBRATED: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of each kernel divided by the same ratio of an '
+              f'MFMA-only loop (tools/mfma_peak.hip, ratio {cal[0]:.1f}, measured {cal[2]:.0f} TFLOP/s = {100 * cal[1]:.1f} % of the 2.5 PFLOP/s '
+              f'dense peak in the same profiled run), times that loop\'s fraction of peak -- i.e. the share of the 2.5 PFLOP/s issue '
+              f'rate at which the kernel kept the matrix cores busy.\n')
+    print('| kernel | grid (threads) | calls | fetch MB | fetch x2 MB | write MB | MFMA pipe busy, % of 2.5 PFLOP/s issue rate (calibrated) | LDS conflict % | avg ms (pmc pass) |')
     print('|---|---|---|---|---|---|---|---|---|')
     keys = sorted(f, key=lambda k: -f[k][2])
     for k in keys[:40]:
@@ -42,7 +69,7 @@ def main(d):
         util = ''
         if busy and gui and gui[1] > 0:
             # MfmaUtil = sum(MFMA busy cycles over SIMDs) / (GUI_ACTIVE * #SIMD); 256 CU * 4 SIMD
-            util = f'{100.0 * busy[1] / (gui[1] * 1024):.1f}'
+            util = f'{100.0 * (busy[1] / gui[1]) / cal[0] * cal[1]:.1f}' if cal else f'raw {busy[1] / gui[1]:.1f}'
         lc = sq['SQ_LDS_BANK_CONFLICT'].get(k)
         la = sq['SQ_LDS_IDX_ACTIVE'].get(k)
         lds = f'{100.0 * lc[1] / la[1]:.1f}' if lc and la and la[1] > 0 else ''
