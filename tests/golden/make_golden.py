@@ -236,6 +236,9 @@ def main():
     if 'pipeline' in sys.argv[1:]:
         pipeline_case()
         return
+    if 'b2' in sys.argv[1:]:
+        case('ngf64_S512_B2', 64, 512, 2, False, lseed=41, cseed=42, nseed=43)
+        return
     if 'aux' in sys.argv[1:] or len(sys.argv) == 1:
         aux_cases()
     if 'zenc' in sys.argv[1:] or len(sys.argv) == 1:
@@ -250,6 +253,7 @@ def main():
     case('ngf64_S256_ui', 64, 256, 1, True)
     case('ngf64_S256_face_B2', 64, 256, 2, False, labels='face', codes='median', lseed=21, nseed=22)
     case('ngf64_S512_ui', 64, 512, 1, True, lseed=31, cseed=32, nseed=33)
+    case('ngf64_S512_B2', 64, 512, 2, False, lseed=41, cseed=42, nseed=43)
 
 
 if __name__ == '__main__':

@@ -9,7 +9,7 @@ from ctrlhair_amd import procedural as P
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 SEAN_CASES = ['ngf16_S64_B3', 'ngf16_S64_ui', 'ngf16_S128_face', 'ngf64_S256_ui', 'ngf64_S256_face_B2',
-              'ngf64_S512_ui']
+              'ngf64_S512_ui', 'ngf64_S512_B2']
 
 
 class Case:
@@ -36,11 +36,23 @@ class Case:
         plus the per-channel-sum check scaled to a per-pixel figure."""
         z = self.z
         assert img.shape == (self.B, 3, self.S, self.S), img.shape
-        if 'image' in z.files:
+        return self.diff_samples(img, range(self.B))
+
+    def diff_samples(self, img: np.ndarray, rows) -> float:
+        """The same comparison for `img` [len(rows),3,S,S] holding the fixture's samples `rows` (a fixture's samples
+        embedded in a larger batch)."""
+        z = self.z
+        rows = list(rows)
+        zz = {k: (z[k][rows] if (k in ('image', 'sub4', 'sums') or (k.startswith('crop') and not k.endswith('_yx'))) else z[k])
+              for k in z.files}
+        return self._diff(zz, img)
+
+    def _diff(self, z, img):
+        if 'image' in z:
             return float(np.abs(img - z['image']).max())
         d = float(np.abs(img[:, :, ::4, ::4] - z['sub4']).max())
         i = 0
-        while f'crop{i}' in z.files:
+        while f'crop{i}' in z:
             y, x = z[f'crop{i}_yx']
             c = z[f'crop{i}']
             d = max(d, float(np.abs(img[:, :, y:y + c.shape[2], x:x + c.shape[3]] - c).max()))

@@ -226,3 +226,27 @@ def test_reduced_precision_paths_against_exact(hip_lib):
         assert d.max() <= 5e-2
     print('vs exact f32 (max, mean |delta|):', err)
     assert err['f16'][1] < err['bf16'][1]          # 11 vs 8 significand bits
+
+
+@pytest.mark.parametrize('path', ['f32', 'f16x3'])
+def test_golden_batch16_full_size(hip_lib, path):
+    """BASELINE.json configs[1] as benchmarked: ngf=64, 512x512, max_batch=16, B=16 in ONE call.  Samples 0-2 are the inputs
+    of the reference-made fixtures ngf64_S512_ui (1) and ngf64_S512_B2 (2) and must reproduce them; samples 3-15 are
+    seeded synthetic inputs and must equal the same sample rendered alone (no cross-sample op)."""
+    from ctrlhair_amd import procedural as P
+    ui, b2 = Case('ngf64_S512_ui'), Case('ngf64_S512_B2')
+    ngf, S, B = 64, 512, 16
+    assert ui.wseed == b2.wseed == 0
+    gen = _gen(_sds.setdefault((ngf, 0), P.sean_state_dict(0, ngf)), 16, S, f16x3={'f32': 0}.get(path, 1))
+    labels = np.concatenate([ui.labels, b2.labels, P.blocky_labels(13, S, seed=900)])
+    codes = np.concatenate([ui.codes, b2.codes, P.style_codes(13, seed=901)])
+    noise = np.concatenate([ui.noise, b2.noise, P.noise_planes(13, S, ngf, seed=902)])
+    img = _run(gen, labels, codes, noise)
+    assert np.isfinite(img).all()
+    d_ui, d_b2 = ui.diff_samples(img[0:1], [0]), b2.diff_samples(img[1:3], [0, 1])
+    print(f'{path}: B=16 batch vs reference fixtures: {d_ui:.3e} (ui), {d_b2:.3e} (B2)')
+    assert d_ui <= TOL and d_b2 <= TOL
+    for i in (3, 9, 15):
+        one = _run(gen, labels[i:i + 1], codes[i:i + 1], noise[i:i + 1])
+        assert np.abs(one[0] - img[i]).max() <= 1e-5
+    gen.handle.close()
