@@ -2,7 +2,9 @@
 // Reference behaviour restated (file:line in /root/reference) is cited at each forward.
 #include "aux_models.h"
 
+#include "conv_sh16.h"
 #include "kernels.h"
+#include "sh16.h"
 
 namespace chk {
 
@@ -167,9 +169,29 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
         for (int l = 0; l < 7; ++l) {
             const int co = std::min(32 << (6 - l), 2048);
             const std::string p = d + ".layers." + std::to_string(2 * l + 1);
-            dec[w][l] = make_conv(B, B.vec(p + ".conv.weight", (size_t)co * ci * 9), B.vec(p + ".conv.bias", co), co, ci, 3, 1, 1);
-            dec_ln[w][l].gamma = B.upload(B.vec(p + ".norm.gamma", co));
-            dec_ln[w][l].beta = B.upload(B.vec(p + ".norm.beta", co));
+            const auto wv = B.vec(p + ".conv.weight", (size_t)co * ci * 9);
+            const auto gam = B.vec(p + ".norm.gamma", co), bet = B.vec(p + ".norm.beta", co);
+            if (use_sh16 && l >= 1) {          // f16x3 path: only the bias of the f32 layer object is used
+                const float* wp = wv.data();
+                auto getw = [&](int row, int c, int t) { return wp[((size_t)row * ci + c) * 9 + t]; };
+                const auto kexp = sh16_row_exponents(co, ci, 3, getw);
+                dec_sh[w][l] = B.upload(pack_A_sh16(co, ci, 3, getw, kexp));
+                dec_ws[w][l] = B.upload(sh16_wscale(kexp));
+                dec[w][l].bias = B.upload(B.vec(p + ".conv.bias", co));
+                dec[w][l].Cout = co;
+                dec[w][l].Cin = ci;
+                dec[w][l].KS = 3;
+            } else {
+                dec[w][l] = make_conv(B, wv, B.vec(p + ".conv.bias", co), co, ci, 3, 1, 1);
+            }
+            dec_ln[w][l].gamma = B.upload(gam);
+            dec_ln[w][l].beta = B.upload(bet);
+            {   // |(x - mean) / (std + eps)| <= sqrt(N) over the N = C*H*W elements of a sample
+                float gm = 0.f, bm = 0.f;
+                for (int c = 0; c < co; ++c) { gm = std::max(gm, std::fabs(gam[c])); bm = std::max(bm, std::fabs(bet[c])); }
+                const int sz = 4 << l;            // output side of layer l
+                dec_ln_scale[w][l] = sh16_scale_for_bound(std::sqrt((float)co * sz * sz) * gm + bm);
+            }
             ci = co;
         }
         const int oc = w == 0 ? 1 : 18;
@@ -262,6 +284,39 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
     up.in_mode = IN_UP2_NEAREST;
     up.partial = splitk_ws;
     up.partial_cap = splitk_cap;
+    if (use_sh16) {
+        // layer 0 (2x2 -> 4x4, input straight from the Linear) on the exact-f32 kernel; its LayerNorm writes SH16.  Layers 1-6:
+        // f16x3 conv over the nearest-x2 view (SH16 in, C4 out) -> LayerNorm + lrelu (C4 in, SH16 out; the last one NCHW f32).
+        ck(run_conv(dec[w][0], x, bufc, B, size, size, up, st), "shape dec conv0");
+        size *= 2;
+        ck(layernorm_act_conv(bufc, 0, bufb, 1, dec_ln_scale[w][0], dec_ln[w][0].gamma, dec_ln[w][0].beta, lnpart, B,
+                              dec[w][0].Cout, size * size, 1e-5f, ACT_LRELU, st), "shape dec ln0");
+        for (int l = 1; l < 7; ++l) {
+            ConvParams p{};
+            p.in = bufb;
+            p.wpk = dec_sh[w][l];
+            p.wscale = dec_ws[w][l];
+            p.in_scale_inv = 1.f / dec_ln_scale[w][l - 1];
+            p.out = bufc;
+            p.B = B;
+            p.Cin = dec[w][l].Cin;
+            p.H = 2 * size;
+            p.W = 2 * size;
+            p.Mrows = dec[w][l].Cout;
+            p.bias = dec[w][l].bias;
+            p.act = ACT_NONE;
+            p.in_mode = IN_UP2_NEAREST;
+            p.partial = splitk_ws;
+            p.partial_cap = splitk_cap;
+            ck(conv_sh16_plain(p, 3, st), "shape dec conv (f16x3)");
+            size *= 2;
+            const bool last = l == 6;
+            ck(layernorm_act_conv(bufc, 1, bufb, last ? 0 : 1, dec_ln_scale[w][l], dec_ln[w][l].gamma, dec_ln[w][l].beta, lnpart, B,
+                                  dec[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st), "shape dec ln");
+        }
+        ck(run_conv(dec_out[w], bufb, logit, B, size, size, ConvOpts(), st), "shape dec out");
+        return ck.err;
+    }
     for (int l = 0; l < 7; ++l) {
         float* y = bufs[l & 1];
         ck(run_conv(dec[w][l], x, y, B, size, size, up, st), "shape dec conv");

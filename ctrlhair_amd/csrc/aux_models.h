@@ -39,6 +39,11 @@ struct ShapeModel {
     float *dec_in_w[2] = {}, *dec_in_b[2] = {};
     ConvLayer dec[2][7], dec_out[2];
     LnW dec_ln[2][7];
+    // decoder layers 1..6 on the f16x3 split-operand kernels (conv_sh16.h): packed weights, per-row inverse scales, and the
+    // power-of-two SH16 scale of each LayerNorm output (from the bound sqrt(C*HW) * max|gamma| + max|beta|: cannot saturate)
+    bool use_sh16 = true;
+    float *dec_sh[2][7] = {}, *dec_ws[2][7] = {};
+    float dec_ln_scale[2][7] = {};
     float* pos = nullptr;      // [40][S*S]
     float *in_hair = nullptr, *in_face = nullptr, *bufa = nullptr, *bufb = nullptr, *bufc = nullptr, *lnpart = nullptr,
           *codecat = nullptr, *splitk_ws = nullptr;

@@ -301,6 +301,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.terms = value == 2 ? 1 : (value == 3 ? 2 : 3);
         return CH_OK;
     }
+    if (std::strcmp(key, "shape.f16x3") == 0) {
+        if (h->shape.ready) return fail(h, CH_ERR_STATE, "ch_set_option(shape.f16x3) must precede ch_finalize");
+        h->shape.use_sh16 = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.dbg_sel") == 0) {
         h->sean.dbg_sel = value;
         return CH_OK;

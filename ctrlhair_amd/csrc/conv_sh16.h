@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
 
     const uint4* gin = reinterpret_cast<const uint4*>(p.in);
     // physical plane size of the input: ConvTranspose2d(k3,s2,p1,op1) runs as a conv over the zero-inserted x2 view
-    const int HWi = p.in_mode == IN_UP2_ZEROINS ? (p.H >> 1) * (p.W >> 1) : HW;
+    // (IN_UP2_NEAREST: the shape decoder's nearest x2 up-sampling, shape_branch/model.py:128, as address arithmetic)
+    const int HWi = p.in_mode != IN_DIRECT ? (p.H >> 1) * (p.W >> 1) : HW;
     // per-thread source offsets of its NLOAD patch units (chunk-invariant part), -1 = outside the image -> zeros.
     // Hoisted out of the chunk loop: the decode (3 div/mod per unit) was ~half of the kernel's VALU issue.
     int soff[NLOAD];
@@ -392,7 +393,9 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
                 x = x < 0 ? -x : (x >= p.W ? 2 * (p.W - 1) - x : x);
             }
             if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-                if (p.in_mode == IN_UP2_ZEROINS) {   // logical input = physical input with zeros between the samples
+                if (p.in_mode == IN_UP2_NEAREST) {
+                    soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HWi + (y >> 1) * (p.W >> 1) + (x >> 1);
+                } else if (p.in_mode == IN_UP2_ZEROINS) {   // logical input = physical input with zeros between the samples
                     if (!((y | x) & 1)) soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HWi + (y >> 1) * (p.W >> 1) + (x >> 1);
                 } else {
                     soff[i] = ((b * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;

@@ -27,6 +27,9 @@ hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStr
 hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s);
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
                          int act, hipStream_t s);
+// LayerNorm + activation with layout conversion: in NCHW / C4 -> out SH16 (scaled) / NCHW f32 (shape decoder, f16x3 convs)
+hipError_t layernorm_act_conv(const float* x, int in_c4, void* out, int out_sh16, float out_scale, const float* gamma,
+                              const float* beta, float* part, int B, int C, int HW, float eps, int act, hipStream_t s);
 hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B, int F, int h, int w, int S,
                        hipStream_t s, int c4 = 0);
 hipError_t maxpool3x3s2(const float* in, float* out, long long planes, int H, int W, hipStream_t s);

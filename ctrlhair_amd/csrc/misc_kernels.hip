@@ -302,6 +302,86 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(float* __restrict__ x, co
         p[i] = act_fn((p[i] - mean) * inv * gamma[c] + beta[c], act);
     }
 }
+// Same normalisation with layout conversion (shape decoder on the f16x3 conv path): input NCHW or C4 ([B][C/4][HW][4], the
+// f16x3 convs' output), output SH16 ([B][C/8][hi|lo][HW][8] f16, scaled by out_scale: feeds the next f16x3 conv) or NCHW f32.
+// One thread = 8 channels of one pixel.  The statistics (ln_partial_kernel) do not depend on the layout: a sample is one
+// contiguous block of C*HW floats either way.
+template <bool IN_C4, bool OUT_SH16>
+__global__ __launch_bounds__(256) void ln_apply_conv_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            void* __restrict__ out, int C, int HW, int nblk, float eps, int act,
+                                                            float out_scale) {
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    sh16_mode_on();
+    const int b = blockIdx.y;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        const float* o = part + ((long long)b * nblk + k) * 3;
+        const float nb = o[0], mb = o[1], qb = o[2];
+        if (nb > 0.f) {
+            const float nn = n + nb, d = mb - mean;
+            mean += d * nb / nn;
+            m2 += qb + d * d * n * nb / nn;
+            n = nn;
+        }
+    }
+    const float inv = 1.f / (sqrtf(m2 / (n - 1.f)) + eps);
+    const int G = C >> 3;
+    const long long items = (long long)G * HW;
+    const float* xb = x + (long long)b * C * HW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i / HW), p = (int)(i % HW);
+        float v[8];
+        if (IN_C4) {
+            const float4 a = reinterpret_cast<const float4*>(xb)[(long long)(2 * g) * HW + p];
+            const float4 c = reinterpret_cast<const float4*>(xb)[(long long)(2 * g + 1) * HW + p];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xb[(long long)(g * 8 + e) * HW + p];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_fn((v[e] - mean) * inv * gamma[g * 8 + e] + beta[g * 8 + e], act);
+        if (OUT_SH16) {
+            half8v vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h, l;
+                sh16_split(v[e], out_scale, h, l);
+                vh[e] = h;
+                vl[e] = l;
+            }
+            uint4* o = static_cast<uint4*>(out) + ((long long)b * G + g) * 2 * HW;
+            o[p] = __builtin_bit_cast(uint4, vh);
+            o[HW + p] = __builtin_bit_cast(uint4, vl);
+        } else {
+            float* o = static_cast<float*>(out) + (long long)b * C * HW;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[(long long)(g * 8 + e) * HW + p] = v[e];
+        }
+    }
+}
+
+hipError_t layernorm_act_conv(const float* x, int in_c4, void* out, int out_sh16, float out_scale, const float* gamma,
+                              const float* beta, float* part, int B, int C, int HW, float eps, int act, hipStream_t s) {
+    if (C & 7) return hipErrorInvalidValue;
+    const long long N = (long long)C * HW;
+    int nblk = (int)((N + 16383) / 16384);
+    if (nblk > 128) nblk = 128;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(ln_partial_kernel, dim3(nblk, B), dim3(256), 0, s, x, part, N, nblk);
+    int gx = (int)((N / 8 + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+#define LN_LAUNCH(A, O) hipLaunchKernelGGL((ln_apply_conv_kernel<A, O>), dim3(gx, B), dim3(256), 0, s, x, part, gamma, beta, out, C, HW, nblk, eps, act, out_scale)
+    if (in_c4 && out_sh16) LN_LAUNCH(true, true);
+    else if (in_c4) LN_LAUNCH(true, false);
+    else if (out_sh16) LN_LAUNCH(false, true);
+    else LN_LAUNCH(false, false);
+#undef LN_LAUNCH
+    return hipGetLastError();
+}
+
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
                          int act, hipStream_t s) {
     const long long N = (long long)C * HW;

@@ -60,7 +60,9 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   2  f16 matrix cores, single term: operands rounded to f16, f32 accumulation and f32 normalisation / modulation
  *      (the reduced-precision configuration of BASELINE.json configs[4]; tolerance 5e-2);
  *   3  bf16 matrix cores (v_mfma_f32_32x32x16_bf16), single term: operands rounded to bf16, f32 accumulation and f32
- *      normalisation / modulation -- configs[4] as written ("bf16 MFMA conv path"; tolerance 5e-2). */
+ *      normalisation / modulation -- configs[4] as written ("bf16 MFMA conv path"; tolerance 5e-2).
+ * "shape.f16x3" (default 1): the shape decoder's 3x3 convs from 4x4 resolution up run on the same f16x3 split-operand
+ *   kernels (LayerNorm outputs are bounded, so their scales are static); 0 = every conv on the exact-f32 kernels. */
 int  ch_set_option(ch_handle* h, const char* key, int value);
 
 /* Fold + pack + upload the loaded tensors: spectral-norm sigma (torch spectral_norm eval semantics,

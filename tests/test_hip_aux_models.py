@@ -137,3 +137,27 @@ def test_parsing_img_surface(hip_lib):
     assert parsing.shape == (512, 512) and pil.size == (512, 512) and parsing.max() <= 18
     celeba = e['bise'].swap_parsing_label_to_celeba_mask(parsing)
     assert celeba.shape == (512, 512) and celeba.dtype == np.uint8
+
+
+def test_shape_decoder_exact_f32_path_matches_golden_too(hip_lib):
+    """Option shape.f16x3 = 0 keeps every shape-decoder conv on the exact-f32 kernels (the default, tested above, runs the
+    decoder from 4x4 up on the f16x3 split-operand kernels): same golden bar, and the two paths agree far inside it."""
+    from ctrlhair_amd import lib, models
+    from ctrlhair_amd import procedural as P
+    e = env()
+    z = np.load(os.path.join(GOLDEN, 'shape_054.npz'))
+    h = lib.Handle(0)
+    h.set_option('shape.f16x3', 0)
+    sg = models.ShapeGenerator(h, e['dev']).load_state_dict(P.shape_state_dict(0), max_batch=2)
+    ghc, gfc = torch.from_numpy(z['hair_code']).to(e['dev']), torch.from_numpy(z['face_code']).to(e['dev'])
+    fl = sg.forward_face_decoder(gfc)
+    hl = sg.forward_hair_decoder(ghc, gfc)
+    fl2 = e['shape'].forward_face_decoder(gfc)
+    hl2 = e['shape'].forward_hair_decoder(ghc, gfc)
+    torch.cuda.synchronize()
+    assert np.abs(fl.cpu().numpy()[:, :, ::4, ::4] - z['face_logit_sub4']).max() <= TOL
+    assert np.abs(hl.cpu().numpy()[:, :, ::4, ::4] - z['hair_logit_sub4']).max() <= TOL
+    d = max(float((fl - fl2).abs().max()), float((hl - hl2).abs().max()))
+    print('shape decoder f16x3 vs exact f32: max |delta| of the logits', d, ' |logit| max', float(fl.abs().max()))
+    assert d <= 2e-4
+    h.close()
