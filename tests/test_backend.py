@@ -124,7 +124,8 @@ def test_batched_gen_imgs_equals_per_sample(hip_lib):
     batched = he.gen_imgs(codes, labels, noise=noise)
     for b in range(B):
         one = he.gen_img(codes[b:b + 1], labels[b][None, None], noise=noise[b:b + 1])
-        assert float((one - batched[b]).abs().max()) <= 1e-6
+        # (the style-LUT GEMM picks its split-K schedule from the batch size: sums associate differently, a few fp32 ulp)
+        assert float((one - batched[b]).abs().max()) <= 5e-6
 
 
 @pytest.mark.gpu
