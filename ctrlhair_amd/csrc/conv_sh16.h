@@ -776,40 +776,57 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
             const uint4* sb = smem_u + (q & 1) * STAGE;
             const uint4* sa = sb + UNITS + lane;
-            // One wave per SIMD: nothing hides a stalled MFMA stream, so the k-step is hand-ordered and pinned with
-            // sched_barrier: group i = {1 operand fetch of k-step t+1 (4 A + 8 B ds_read_b128), 2 MFMAs of k-step t};
-            // consecutive MFMAs hit different accumulators (term-major order).
+            // One wave per SIMD: nothing hides a stalled MFMA stream, so the k-step is hand-ordered and pinned with sched_barrier.
+            // A tap is two halves of 12 MFMAs: pixel sub-tiles {0,1}, then {2,3} (term-major inside a half: the same accumulator
+            // comes back every 4th MFMA; tools/mfma_dep.hip: 2.6 % below 8 independent accumulators).  The B fragments are
+            // reloaded IN PLACE: those of sub-tiles {2,3} for this tap during the first half, those of {0,1} for the next tap
+            // during the second half, i.e. right after their last use -- no second B buffer; only the A fragments (live
+            // through the whole tap) are double-buffered.
             uint4 a_cur[4], bh[4], bl[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) a_cur[i] = sa[i * 64];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < 2; ++n) {
                 bh[n] = sb[ub[n]];
                 bl[n] = sb[ub[n] + PLANE];
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                uint4 a_nxt[4], bhn[4], bln[4];
+                uint4 a_nxt[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a_nxt[i] = a_cur[i]; bhn[i] = bh[i]; bln[i] = bl[i]; }
-                const int koff = ((t + 1) / KS) * PW + ((t + 1) % KS);
+                for (int i = 0; i < 4; ++i) a_nxt[i] = a_cur[i];
+                const int kcur = (t / KS) * PW + (t % KS), knxt = ((t + 1) / KS) * PW + ((t + 1) % KS);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    if (t + 1 < NT) {
-                        if (i < 4) a_nxt[i] = sa[((t + 1) * 4 + i) * 64];
-                        else if ((i & 1) == 0) bhn[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff];
-                        else bln[(i - 4) >> 1] = sb[ub[(i - 4) >> 1] + koff + PLANE];
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        // group i of this half: one operand fetch, then 2 MFMAs
+                        if (half == 0) {
+                            if (i == 0) bh[2] = sb[ub[2] + kcur];
+                            if (i == 1) bl[2] = sb[ub[2] + kcur + PLANE];
+                            if (i == 2) bh[3] = sb[ub[3] + kcur];
+                            if (i == 3) bl[3] = sb[ub[3] + kcur + PLANE];
+                            if (t + 1 < NT && i == 4) a_nxt[0] = sa[((t + 1) * 4 + 0) * 64];
+                            if (t + 1 < NT && i == 5) a_nxt[1] = sa[((t + 1) * 4 + 1) * 64];
+                        } else if (t + 1 < NT) {
+                            if (i == 0) bh[0] = sb[ub[0] + knxt];
+                            if (i == 1) bl[0] = sb[ub[0] + knxt + PLANE];
+                            if (i == 2) bh[1] = sb[ub[1] + knxt];
+                            if (i == 3) bl[1] = sb[ub[1] + knxt + PLANE];
+                            if (i == 4) a_nxt[2] = sa[((t + 1) * 4 + 2) * 64];
+                            if (i == 5) a_nxt[3] = sa[((t + 1) * 4 + 3) * 64];
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * i + jj, term = j >> 2, m = (j & 3) >> 1, n = half * 2 + (j & 1);
+                            if (TERMS != 3 && term != 2) continue;
+                            acc[m][n] = mfma16<TERMS>(a_cur[m * 2 + (term == 0 ? 1 : 0)], term == 1 ? bl[n] : bh[n], acc[m][n]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int j = 2 * i + jj, term = j >> 3, m = (j & 7) >> 2, n = j & 3;
-                        if (TERMS != 3 && term != 2) continue;
-                        acc[m][n] = mfma16<TERMS>(a_cur[m * 2 + (term == 0 ? 1 : 0)], term == 1 ? bl[n] : bh[n], acc[m][n]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a_cur[i] = a_nxt[i]; bh[i] = bhn[i]; bl[i] = bln[i]; }
+                for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
             }
             __syncthreads();
         }
