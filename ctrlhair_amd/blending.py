@@ -17,6 +17,7 @@ class PoissonBlender:
         self.handle, self.device = handle, device
         self.max_iters, self.rel_tol = max_iters, rel_tol
         self.last_iters = 0
+        self.last_converged = True
 
     def _u8(self, a, shape):
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
@@ -45,5 +46,10 @@ class PoissonBlender:
         self.handle.call('ch_poisson_blend', s.data_ptr(), t.data_ptr(), m.data_ptr(), out.data_ptr(), H, W,
                          1 if with_gamma else 0, self.max_iters, float(self.rel_tol), C.byref(iters),
                          torch.cuda.current_stream(self.device).cuda_stream)
-        self.last_iters = iters.value
+        self.last_iters, self.last_converged = abs(iters.value), iters.value >= 0
+        if not self.last_converged:
+            # the reference solves the system directly (poisson_blending.py:80-85): a partially converged image is not its result
+            import warnings
+            warnings.warn(f'Poisson blending stopped after {self.last_iters} CG iterations without reaching rel_tol='
+                          f'{self.rel_tol:g}; raise PoissonBlender.max_iters', RuntimeWarning)
         return out.cpu().numpy()

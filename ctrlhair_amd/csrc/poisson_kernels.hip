@@ -235,11 +235,13 @@ hipError_t poisson_blend(const uint8_t* src, const uint8_t* tgt, const uint8_t* 
         }
     }
     hipLaunchKernelGGL(pb_finish_kernel, g, b, 0, s, X, out, HW, gamma);
-    if (iters_out) {
-        hipError_t e = hipMemcpyAsync(iters_out, &cg->iters, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (iters_out) {       // iteration count; NEGATIVE when the solve stopped at max_iters without reaching rel_tol
+        int st[2] = {0, 0};                                   // PoissonCG {done, iters}
+        hipError_t e = hipMemcpyAsync(st, &cg->done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return e;
+        *iters_out = st[0] ? st[1] : -st[1];
     }
     return hipGetLastError();
 }

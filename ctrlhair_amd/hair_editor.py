@@ -70,6 +70,12 @@ class HairEditor:
             elif weights == 'reference' or (isinstance(weights, str) and os.path.isdir(weights)):
                 # the reference's checkpoint tree ('reference' = the current directory, like the reference itself)
                 weights = reference_checkpoints('.' if weights == 'reference' else weights)
+                from .checkpoints import validate
+                fcw = weights['sean'].get('fc.weight') if isinstance(weights.get('sean'), dict) else None
+                ngf = int(fcw.shape[0]) // 16 if fcw is not None else 64      # generator width as the C library infers it
+                problems = validate(weights, ngf=ngf)   # strict=True semantics before anything is uploaded
+                if problems:
+                    raise RuntimeError('checkpoint tree does not match the implemented architectures:\n  ' + '\n  '.join(problems[:20]))
                 if texture_dirs is None and weights.get('texture_dirs'):
                     texture_dirs = weights['texture_dirs']          # hair_editor.py:82-91
                 if shape_dirs is None and weights.get('shape_dirs'):

@@ -145,3 +145,25 @@ def test_full_size_properties(blender):
     far[S // 2 + 40:S - 8, 8:S - 8] = True                    # well below the hair ellipse
     lap_o, lap_s = O.laplacian_apply(g(out)[:, :, 0].copy()), O.laplacian_apply(g(src)[:, :, 0].copy())
     assert np.abs(lap_o - lap_s)[far].mean() < 0.05          # uint8 quantisation of the output bounds this, not the solver
+
+
+@pytest.mark.gpu
+def test_unconverged_solve_is_reported(hip_lib):
+    """The reference solves the system directly; a CG run cut off at max_iters must say so (negative iteration count from
+    ch_poisson_blend -> PoissonBlender.last_converged False + a RuntimeWarning)."""
+    import warnings
+    blender = _blender(max_iters=8, rel_tol=1e-12)
+    S = 64
+    ys, xs = np.mgrid[0:S, 0:S]
+    mask = ((ys - 32) ** 2 + (xs - 32) ** 2 <= 20 ** 2).astype(np.uint8)
+    src = np.full((S, S, 3), 120, np.uint8)
+    src[::2] = 40
+    tgt = np.full((S, S, 3), 200, np.uint8)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        out = blender(src, tgt, mask)
+    assert out.shape == (S, S, 3) and not blender.last_converged and blender.last_iters == 8
+    assert any(issubclass(x.category, RuntimeWarning) for x in w)
+    ok = _blender(max_iters=4000, rel_tol=1e-7)
+    ok(src, tgt, mask)
+    assert ok.last_converged and 0 < ok.last_iters < 4000
