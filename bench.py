@@ -121,6 +121,28 @@ class PipelineJob:
     def step(self, out):
         self.pipe.edit(self.img, out=out)
 
+    # algorithmic GFLOP per image of each stage (generator: FLOPs executed after the exact reformulations)
+    STAGE_GFLOP = {'parse': 27.5, 'shape_encode': 4.9, 'zencoder': 169.6, 'shape_decode': 32.2, 'generator': 1083.8}
+
+    def stages(self, path):
+        """Per-stage time and roofline of one edit (separate instrumented runs, torch events)."""
+        ms = self.pipe.stage_times(self.img)
+        out = {}
+        for k, t in ms.items():
+            row = {'ms': round(t, 3)}
+            if k in self.STAGE_GFLOP:
+                tf = self.STAGE_GFLOP[k] * self.images / t            # GFLOP per ms = TFLOP/s
+                # matrix-core path of the stage's dominant convs: exact-f32 MFMA, or 3 executed f16 products per f32 product
+                f16 = path != 'f32' and k in ('generator', 'zencoder', 'shape_decode')
+                terms = 3.0 if (f16 and (path == 'f16x3' or k != 'generator')) else 1.0     # (Zencoder / shape decoder: always f16x3)
+                peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+                row.update({'algorithmic_tflops': round(tf, 1), 'bound': 'mfma', 'peak_tflops': peak,
+                            'frac': round(terms * tf / peak, 4)})
+            else:
+                row['bound'] = 'launch latency (three small MLPs + slider arithmetic)'
+            out[k] = row
+        return out
+
     def close(self):
         self.pipe.close()
 
@@ -288,6 +310,8 @@ def main():
         value = world * job.images * args.steps / dt if args.steps else 0.0
         results[path] = {'value': round(value, 3), 'ms_per_step': round(dt / max(args.steps, 1) * 1e3, 3),
                          'roofline': roofline_block(path, prof, value / world, B)}
+        if hasattr(job, 'stages') and rank == 0:
+            results[path]['stages'] = job.stages(path)
         job.close()
         del job
         torch.cuda.empty_cache()
@@ -307,12 +331,16 @@ def main():
             'config': {'workload': wl, 'global_batch': world * B, 'conv_path': args.path, 'parallelism': par},
             'roofline': head['roofline'],
         }
+        if 'stages' in head:
+            res['stages'] = head['stages']
         if 'f32' in results and args.path != 'f32':
             s = results['f32']
             res['strict_fp32'] = {'value': s['value'], 'unit': 'images/s', 'ms_per_step': s['ms_per_step'],
                                   'dtype': DTYPE['f32'], 'steps': args.steps, 'warmup': args.warmup,
                                   'note': 'same job, same timed protocol, exact-f32 matrix-core path (the reference\'s arithmetic)',
                                   'roofline': s['roofline']}
+            if 'stages' in s:
+                res['strict_fp32']['stages'] = s['stages']
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(ngf, S, sd)
     if dist is not None:

@@ -53,7 +53,8 @@ class HipModels:
         self.sean_model = Pix2PixModel(self.generator)
         self.solver_feature = ColorTextureModels(h, dev).load_state_dicts(weights['color_gen'], weights['color_dis'],
                                                                           weights['color_rgb'], max_batch=max(max_batch, 16))
-        self.mask_generator = ShapeGenerator(h, dev).load_state_dict(weights['shape'], max_batch=max(max_batch, 1))
+        self.mask_generator = ShapeGenerator(h, dev).load_state_dict(weights['shape'], max_batch=max(max_batch, 1),
+                                                                     f16x3=bool(f16x3))      # exact f32 everywhere when f16x3=False
         self.face_parsing = FaceParsing(h, dev).load_state_dict(weights['bisenet'], max_batch=max(max_batch, 1), max_size=512)
         from .blending import PoissonBlender
         self.blender = PoissonBlender(h, dev)       # blending step after the generator (Backend(blending=True))

@@ -56,7 +56,10 @@ class ShapeGenerator:
     def __init__(self, handle: _lib.Handle, device: torch.device):
         self.handle, self.device = handle, device
 
-    def load_state_dict(self, sd: Dict[str, object], max_batch: int = 4):
+    def load_state_dict(self, sd: Dict[str, object], max_batch: int = 4, f16x3: bool = True):
+        """f16x3: the decoder's 3x3 convs from 4x4 resolution up on the split-operand f16 MFMA kernels (f32-class; default) or,
+        False, every conv on the exact-f32 kernels (option shape.f16x3 of the library)."""
+        self.handle.set_option('shape.f16x3', 1 if f16x3 else 0)
         for k, v in sd.items():
             if 'std_out_layer' in k:
                 continue        # VAE std head: unused with testing=True (shape_branch/model.py:164-169)

@@ -154,3 +154,48 @@ class EditPipeline:
         if stages is not None:
             stages.update(lat, labels=labels, mask=mask, image=image)
         return image
+
+    def stage_times(self, img: torch.Tensor, reps: int = 3) -> Dict[str, float]:
+        """ms per stage of one edit() over `img` (torch events on the current stream, averaged over `reps` runs; measurement
+        only -- edit() itself is never instrumented).  Keys: parse (BiSeNet), shape_encode, zencoder, colour (3 MLPs + sliders),
+        shape_decode, generator."""
+        m, S = self.models, img.shape[-1]
+        acc: Dict[str, float] = {}
+
+        def timed(name, fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            acc.setdefault(name, []).append((e0, e1))
+            return r
+
+        for _ in range(reps):
+            labels = timed('parse', lambda: self.parse(img))
+            lab256 = labels if S == 256 else labels[:, ::S // 256, ::S // 256].contiguous()
+            shape, face = timed('shape_encode', lambda: m.mask_generator.encode_labels(lab256))
+            codes = timed('zencoder', lambda: m.generator.encode(img, labels))
+
+            def colour():
+                hair = codes[:, HAIR_IDX].contiguous()
+                st = m.solver_feature.rgb_model({'code': hair})
+                la = m.solver_feature.dis({'code': hair})
+                lat = self.apply_sliders({'shape': shape, 'face': face, 'codes': codes, 'rgb_mean': st['rgb_mean'], 'pca_std': st['pca_std'],
+                                          'texture': la['noise'], 'curliness': la['noise_curliness']}, DEFAULT_SLIDERS)
+                lat['feature'] = m.solver_feature.gen({'noise': lat['texture'], 'noise_curliness': lat['curliness'],
+                                                       'rgb_mean': lat['rgb'], 'pca_std': lat['pca_std']})['code']
+                return lat
+            lat = timed('colour', colour)
+            mask = timed('shape_decode', lambda: m.mask_generator.decode_labels(lat['shape'], lat['face']))
+
+            def gen():
+                c = lat['codes'].clone()
+                c[:, HAIR_IDX] = lat['feature']
+                zero = (c == 0).all(dim=2, keepdim=True)
+                c = torch.where(zero, self.median[None].expand_as(c), c).contiguous()
+                r = self.img_size // 256
+                lab = mask if r == 1 else mask.repeat_interleave(r, 1).repeat_interleave(r, 2).contiguous()
+                return m.generator.generate(lab, c, None, seed=1)
+            timed('generator', gen)
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in acc.items()}
