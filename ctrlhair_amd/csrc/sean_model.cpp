@@ -339,6 +339,28 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     amax_slots = static_cast<unsigned*>(B.dalloc(64 * sizeof(unsigned)));   // 2 per ACE: [output, style projections]
     splitk_cap = (long long)16 << 20;     // 64 MiB of split-K slabs (low-resolution layers only)
     splitk_ws = B.falloc((size_t)splitk_cap);
+    n_aces = ace_index;
+    // Run-ahead mode of small jobs (Runner::prepare_all_ahead): a side stream, one join event and one set of buffers per ACE.
+    // Only when the handle is sized for interactive work -- for large batches the convs own every CU and nothing co-schedules.
+    ahead_pixels = (long long)4 * 512 * 512;
+    if ((long long)mb * ms * ms <= ahead_pixels) {
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess)
+            return "side stream creation failed";
+        ev_join.assign(n_aces, nullptr);
+        actv_ahead.assign(n_aces, nullptr);
+        lut_ahead.assign(n_aces, nullptr);
+        for (auto& e : ev_join)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return "event creation failed";
+        const size_t npad_b = ((size_t)mb * (LABEL_NC + 1) + 31) / 32 * 32;
+        for (const auto& b : blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
+                if (!a) continue;
+                const size_t r = (size_t)ms / a->res_div;
+                actv_ahead[a->index] = B.falloc((size_t)mb * r * r * HID);
+                if (a->styled) lut_ahead[a->index] = B.falloc(npad_b * 18 * a->C);
+            }
+        splitk_side = B.falloc((size_t)splitk_cap);
+    }
 
     // ---- workspace arena --------------------------------------------------------------------------------
     const size_t MB = mb, S = ms;
@@ -381,6 +403,16 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
 void SeanModel::destroy() {
     for (void* p : allocs) (void)hipFree(p);
     allocs.clear();
+    for (auto e : ev_join)
+        if (e) (void)hipEventDestroy(e);
+    ev_join.clear();
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    ev_fork = nullptr;
+    if (side) (void)hipStreamDestroy(side);
+    side = nullptr;
+    actv_ahead.clear();
+    lut_ahead.clear();
+    splitk_side = nullptr;
     for (auto& r : prof) {
         ev_pool.push_back(r.e0);
         ev_pool.push_back(r.e1);
@@ -456,34 +488,47 @@ struct Runner {
         return m.lab_r[k];
     }
 
-    // one ACE: SPADE hidden activations (label LUT) -> fused gamma/beta conv + modulation -> h
-    void ace(const AceW& a, const uint8_t* labfull, const float* codes, const float* noise, size_t nf, size_t noff,
-             const float* x, int x_up, int act, float* hout) {
+    // What an ACE needs that depends on the label map and the style codes only -- never on the activations flowing
+    // through the generator: the SPADE hidden activations (label table) and the style LUT (fc_mu + LUT GEMM / GEMV).
+    struct AcePrep {
+        const float* actv = nullptr;
+        const float* lut = nullptr;
+        int lut_rs = 1, lut_ns = 0, lut_bs = LABEL_NC;
+    };
+    AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
+                        float* splitk, bool prof) {
         const int r = S / a.res_div;
         const uint8_t* lab = labels_at(labfull, a.res_div);
-        const double npix = (double)B * r * r;
-        int lut_rs = 1, lut_ns = 18 * a.C, lut_bs = LABEL_NC;
+        AcePrep q;
+        q.actv = actv_buf;
+        q.lut_ns = 18 * a.C;
+        auto tm = [&](double flops, double bytes, auto launch) {
+            if (prof) timed(2, flops, bytes, launch);
+            else launch();
+        };
         if (a.styled) {
+            q.lut = lut_buf;
             // f16x3 path: one extra all-zero column per sample (mu = 0 -> LUT = 0) that taps outside the image point at
             const int bs = m.use_sh16 ? LABEL_NC + 1 : LABEL_NC;
             const int N = B * bs, npad = ((N + 31) / 32) * 32;
-            lut_bs = bs;
+            q.lut_bs = bs;
+            const double fl = 2.0 * 18 * a.C * STYLE * N, by = 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N);
             if (a.lut_rows && N <= 64) {
                 // interactive batch sizes: P[n][row] = sum_k W[row][k] mu[n][k] as a batched GEMV (weight-bandwidth bound)
-                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, m.mu_img, 0, bs), "fc_mu");
-                timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N), [&] {
-                    check(linear(m.mu_img, a.lut_rows, nullptr, nullptr, nullptr, m.lut, N, STYLE, 18 * a.C, STYLE, 18 * a.C,
-                                 ACT_NONE, st), "lut gemv");
+                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s, m.mu_img, 0, bs), "fc_mu");
+                tm(fl, by, [&] {
+                    check(linear(m.mu_img, a.lut_rows, nullptr, nullptr, nullptr, lut_buf, N, STYLE, 18 * a.C, STYLE, 18 * a.C,
+                                 ACT_NONE, s), "lut gemv");
                 });
             } else if (m.use_sh16) {
                 // f16x3 LUT GEMM: 1x1 conv over the [npad/32 x 32] "image" of (sample, label) columns, C4 output
                 unsigned* mu_slot = m.amax_slots + 2 * a.index + 1;
                 for (int pass = 0; pass < 2; ++pass)     // second pass: returns at once unless the first one left the f16 window
-                    check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st, nullptr, 1, bs, SH16_ACT_SCALE, mu_slot, pass, m.terms == 2), "fc_mu");
+                    check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s, nullptr, 1, bs, SH16_ACT_SCALE, mu_slot, pass, m.terms == 2), "fc_mu");
                 ConvParams p{};
                 p.in = m.mu_img;
                 p.wpk = a.lut_wpk;
-                p.out = m.lut;
+                p.out = lut_buf;
                 p.B = 1;
                 p.Cin = STYLE;
                 p.H = npad / 32;
@@ -496,35 +541,67 @@ struct Runner {
                 p.in_scale_inv = 1.f / SH16_ACT_SCALE;
                 p.in_amax = mu_slot;
                 p.out_mul = a.out_scale;           // the ACE epilogue takes the LUT pre-multiplied by its output scale
-                p.partial = m.splitk_ws;           // K = 512 in 32 chunks on few tiles (C <= 512): split-K fills the chip
+                p.partial = splitk;                // K = 512 in 32 chunks on few tiles (C <= 512): split-K fills the chip
                 p.partial_cap = m.splitk_cap;
-                timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
-                      [&] { check(conv_sh16_plain(p, 1, st), "lut gemm"); });
-                lut_rs = npad;
-                lut_ns = 4;
+                tm(fl, by, [&] { check(conv_sh16_plain(p, 1, s), "lut gemm"); });
+                q.lut_rs = npad;
+                q.lut_ns = 4;
             } else {
-            check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, st), "fc_mu");
-            ConvParams p{};
-            p.in = m.mu_img;
-            p.wpk = a.lut_wpk;
-            p.out = m.lut;
-            p.B = 1;
-            p.Cin = STYLE;
-            p.H = npad / 32;
-            p.W = 32;
-            p.Mrows = 18 * a.C;
-            p.npix_valid = N;
-            p.pad = -1;
-            timed(2, 2.0 * 18 * a.C * STYLE * N, 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N),
-                  [&] { check(conv_nhwc1x1(p, st), "lut gemm"); });
+                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s), "fc_mu");
+                ConvParams p{};
+                p.in = m.mu_img;
+                p.wpk = a.lut_wpk;
+                p.out = lut_buf;
+                p.B = 1;
+                p.Cin = STYLE;
+                p.H = npad / 32;
+                p.W = 32;
+                p.Mrows = 18 * a.C;
+                p.npix_valid = N;
+                p.pad = -1;
+                tm(fl, by, [&] { check(conv_nhwc1x1(p, s), "lut gemm"); });
             }
         }
         if (m.use_sh16)
-            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, a.actv_scale, st, m.terms == 2), "mlp_shared");
+            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2), "mlp_shared");
         else
-            check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, m.actv, B, r, r, HID, 1, st), "mlp_shared");
+            check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s), "mlp_shared");
+        return q;
+    }
+
+    // Small jobs (interactive renders: the chip is mostly empty) run every ACE's prepare step AHEAD on the model's side
+    // stream, into per-ACE buffers, while the main stream walks the dependent chain of convs; an event per ACE joins them.
+    bool ahead = false;
+    std::vector<AcePrep> prepared;
+    void prepare_all_ahead(const uint8_t* labfull, const float* codes) {
+        ahead = true;
+        prepared.assign(m.n_aces, AcePrep());
+        check(hipEventRecord(m.ev_fork, st), "fork");
+        check(hipStreamWaitEvent(m.side, m.ev_fork, 0), "fork wait");
+        for (const auto& b : m.blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
+                if (!a) continue;
+                prepared[a->index] = ace_prepare(*a, labfull, codes, m.side, m.actv_ahead[a->index], m.lut_ahead[a->index],
+                                                 m.splitk_side, false);
+                check(hipEventRecord(m.ev_join[a->index], m.side), "join record");
+            }
+    }
+
+    // one ACE: SPADE hidden activations (label LUT) -> fused gamma/beta conv + modulation -> h
+    void ace(const AceW& a, const uint8_t* labfull, const float* codes, const float* noise, size_t nf, size_t noff,
+             const float* x, int x_up, int act, float* hout) {
+        const int r = S / a.res_div;
+        const uint8_t* lab = labels_at(labfull, a.res_div);
+        const double npix = (double)B * r * r;
+        AcePrep q;
+        if (ahead) {
+            q = prepared[a.index];
+            check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
+        } else {
+            q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true);
+        }
         ConvParams p{};
-        p.in = m.actv;
+        p.in = q.actv;
         p.wpk = a.spade_wpk;
         p.out = hout;
         p.B = B;
@@ -543,10 +620,10 @@ struct Runner {
         p.noise = noise + noff;
         p.noise_bstride = (long long)nf;
         p.lab = lab;
-        p.lut = a.styled ? m.lut : nullptr;
-        p.lut_rs = lut_rs;
-        p.lut_ns = lut_ns;
-        p.lut_bs = lut_bs;
+        p.lut = q.lut;
+        p.lut_rs = q.lut_rs;
+        p.lut_ns = q.lut_ns;
+        p.lut_bs = q.lut_bs;
         p.act = act;
         p.pad = -1;
         p.dbg = m.dbg;
@@ -650,6 +727,8 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         }
         for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");
         if (use_sh16) R.check(hipMemsetAsync(amax_slots, 0, 64 * sizeof(unsigned), st), "amax slots");
+        // interactive-size jobs: everything that depends on labels / codes only runs ahead on the side stream
+        if (side && !prof_on && !(dbg & 4096) && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd);
 
         const int sw = S / 32;
         float* x = xa;

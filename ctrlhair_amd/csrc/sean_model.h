@@ -72,6 +72,14 @@ struct SeanModel {
     unsigned* amax_slots = nullptr;            // f16x3 path: recorded maxima of the dynamically scaled SH16 tensors (sh16.h)
     float *noise_ws = nullptr, *mu_img = nullptr, *lut = nullptr, *actv = nullptr;
     float *h0 = nullptr, *hs = nullptr, *dx = nullptr, *h1 = nullptr, *xs = nullptr, *xa = nullptr, *xb = nullptr;
+    // run-ahead mode of interactive-size jobs: label / style-only kernels of every ACE on a side stream (sean_model.cpp)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
+    std::vector<float*> actv_ahead, lut_ahead;
+    float* splitk_side = nullptr;
+    long long ahead_pixels = 0;
+    int n_aces = 0;
     std::map<std::string, float*> taps;
     // profiling
     bool prof_on = false;

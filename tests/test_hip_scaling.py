@@ -45,6 +45,20 @@ def _inputs(B, S, ngf):
     return P.blocky_labels(B, S, grid=8), P.style_codes(B), P.noise_planes(B, S, ngf)
 
 
+_oracle_cache = {}
+
+
+def _oracle(key, sd, labels, codes, noise, ngf, want_taps=False):
+    """CPU oracle forward, evaluated once per test variant (the `path` parametrisation re-uses it: the oracle at ngf=64,
+    256x256 takes tens of seconds)."""
+    from oracle import sean_oracle as O
+    if key not in _oracle_cache:
+        taps = {} if want_taps else None
+        ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf, taps=taps).numpy()
+        _oracle_cache[key] = (ref, taps)
+    return _oracle_cache[key]
+
+
 @pytest.mark.parametrize('path', PATHS)
 @pytest.mark.parametrize('f', [2.0 ** -13, 1e3])
 def test_weight_magnitudes(hip_lib, path, f):
@@ -72,8 +86,7 @@ def test_weight_magnitudes(hip_lib, path, f):
         for k in ('.weight', '.bias'):
             sd[f'{a0}.fc_mu{j}{k}'] = sd[f'{a0}.fc_mu{j}{k}'] / np.float32(f)
     labels, codes, noise = _inputs(B, S, ngf)
-    taps = {}
-    ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf, taps=taps).numpy()
+    ref, taps = _oracle(('weights', f), sd, labels, codes, noise, ngf, want_taps=True)
     gen = _gen(sd, path, 4, S)         # max_batch 4: the style LUT is built by the f16x3 GEMM (<= 3 would take the f32 GEMV)
     names = [blk + '.h0', blk + '.dx', blk + '.h1']
     img, got = _run(gen, labels, codes, noise, [(n, tuple(taps[n].shape)) for n in names])
@@ -104,8 +117,7 @@ def test_activation_magnitudes(hip_lib, path, target):
     ngf, S, B = 64, 256, 3
     base = P.sean_state_dict(0, ngf)
     labels, codes, noise = _inputs(B, S, ngf)
-    taps = {}
-    ref0 = O.generator_forward(O.to_torch(base), labels, codes, noise, ngf, taps=taps).numpy()
+    ref0, taps = _oracle(('base64', ), base, labels, codes, noise, ngf, want_taps=True)
     blk = 'up_2'
     sd = dict(base)
     plan = {'ace_s': ('hs', 'conv_s', 1.0), 'ace_0': ('h0', 'conv_0', 1.0), 'ace_1': ('h1', 'conv_1', 2.0 ** -10)}
@@ -130,7 +142,7 @@ def test_activation_magnitudes(hip_lib, path, target):
                 sd[f'{a}{pre}beta.weight'] = sd[f'{a}{pre}beta.weight'] * np.float32(F)
                 sd[f'{a}{pre}beta.bias'] = sd[f'{a}{pre}beta.bias'] * np.float32(F)
         sd[f'{blk}.{conv}.weight_u'] = (sd[f'{blk}.{conv}.weight_u'] * np.float32(F)).astype(np.float32)
-    ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf).numpy()
+    ref, _ = _oracle(('act', target), sd, labels, codes, noise, ngf)
     assert np.abs(ref - ref0).max() <= 1e-4        # the compensation is exact up to fp32 rounding
     gen = _gen(sd, path, 4, S)
     img, _ = _run(gen, labels, codes, noise)
@@ -157,8 +169,7 @@ def test_fused_shortcut_with_diverging_scales(hip_lib, path):
     ngf, S, B = 64, 256, 3
     base = P.sean_state_dict(0, ngf)
     labels, codes, noise = _inputs(B, S, ngf)
-    taps = {}
-    O.generator_forward(O.to_torch(base), labels, codes, noise, ngf, taps=taps)
+    _, taps = _oracle(('base64', ), base, labels, codes, noise, ngf, want_taps=True)
     sd = dict(base)
     F1 = float(2.0 ** np.round(np.log2(6e4 / float(taps['up_2.h1'].abs().max()))))
     F2 = float(2.0 ** np.round(np.log2(4e3 / float(taps['up_2.hs'].abs().max()))))
@@ -175,7 +186,7 @@ def test_fused_shortcut_with_diverging_scales(hip_lib, path):
         sd[a + '.running_mean'] = sd[a + '.running_mean'] * np.float32(F1)
         sd[a + '.running_var'] = sd[a + '.running_var'] * np.float32(F1) ** 2
         sd[f'up_3.{ace}.noise_var'] = sd[f'up_3.{ace}.noise_var'] * np.float32(F1)
-    ref = O.generator_forward(O.to_torch(sd), labels, codes, noise, ngf).numpy()
+    ref, _ = _oracle(('fused', ), sd, labels, codes, noise, ngf)
     assert 0.05 < ref.std() < 0.9                     # still an image, not a saturated one
     gen = _gen(sd, path, 4, S)
     img, _ = _run(gen, labels, codes, noise)
