@@ -64,10 +64,12 @@ class SeanGenerator:
         return out
 
     def capture(self, labels: torch.Tensor, codes: torch.Tensor, noise: Optional[torch.Tensor] = None, seed: int = 0):
-        """hipGraph capture of one generate() call at fixed shapes (interactive use: a 256x256 render is ~400 launches of
-        1-40 us, so eager mode is host-launch bound).  Returns (graph, out): refill `labels` / `codes` / `noise` IN PLACE,
-        then graph.replay() and read `out`.  The library allocates nothing and never synchronises inside generate, so the
-        stock torch.cuda.CUDAGraph capture applies (device-drawn noise keeps the seed of the capture)."""
+        """hipGraph capture of one generate() call at fixed shapes.  Returns (graph, out): refill `labels` / `codes` / `noise`
+        IN PLACE, then graph.replay() and read `out`.  The library allocates nothing and never synchronises inside generate,
+        so the stock torch.cuda.CUDAGraph capture applies (device-drawn noise keeps the seed of the capture; the library's
+        internal side stream joins the capture through its fork / join events).  Measured (tools/lat_b1.py): a replay is NOT
+        faster than eager launches -- the ~400 kernels of a render run back to back either way, and the graph executor
+        serialises the run-ahead side stream (3.4 ms vs 2.65 ms at 256x256).  Kept for callers that want one submission."""
         out = torch.empty(labels.shape[0], 3, labels.shape[-1], labels.shape[-1], dtype=torch.float32, device=labels.device)
         side = torch.cuda.Stream(labels.device)
         side.wait_stream(torch.cuda.current_stream(labels.device))

@@ -1,7 +1,7 @@
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/b1 -o t -- python /root/repo/tools/lat_b1.py 256 > /tmp/b1.log 2>&1
-python /root/repo/tools/rocprof_summary.py /tmp/b1/t_results.db | head -30
-python - <<'PY'
+mkdir -p /root/repo/gpurun_out/profiles_r02; python /root/repo/tools/rocprof_summary.py /tmp/b1/t_results.db > /root/repo/gpurun_out/profiles_r02/r02_b1_256_kernel_trace.md; head -30 /root/repo/gpurun_out/profiles_r02/r02_b1_256_kernel_trace.md
+python - >> /root/repo/gpurun_out/profiles_r02/r02_b1_256_kernel_trace.md <<'PY'
 import sqlite3
 c=sqlite3.connect('/tmp/b1/t_results.db')
 rows=c.execute("select start, end, name from kernels order by start").fetchall()
