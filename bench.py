@@ -86,7 +86,8 @@ class GeneratorJob:
         from ctrlhair_amd import procedural as P
         from ctrlhair_amd.sean.generator import SeanGenerator
         B, S, ngf = args.batch, args.size, args.ngf
-        self.gen = SeanGenerator(dev.index, f16x3=PATH_OPTION[path]).load_state_dict(sd, max_batch=B, max_size=S)
+        opts = {'sean.ahead': args.ahead} if args.ahead >= 0 else None
+        self.gen = SeanGenerator(dev.index, f16x3=PATH_OPTION[path], options=opts).load_state_dict(sd, max_batch=B, max_size=S)
         if args.dbg:
             self.gen.handle.set_option('sean.dbg', args.dbg)
         first = rank * B     # global sample index offset (SURVEY.md 8d Config 4)
@@ -261,6 +262,7 @@ def main():
                     help='arithmetic of the headline leg: f16x3 = 3-term split-operand f16 MFMA, f32 accumulate, f32-class '
                          '(default); f32 = exact-f32 MFMA; f16 / bf16 = single-term reduced-precision operands (configs[4])')
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--ahead', type=int, default=-1, help=argparse.SUPPRESS)       # option sean.ahead (experiments)
     ap.add_argument('--sync-gather', action='store_true',
                     help='N > 1: all-gather each step on the compute stream instead of overlapping it with the next step')
     ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)   # 1-rank process group: exercises the N > 1 code

@@ -13,11 +13,12 @@ from .. import lib as _lib
 
 
 class SeanGenerator:
-    def __init__(self, device: int = 0, f16x3=False):
+    def __init__(self, device: int = 0, f16x3=False, options: Optional[Dict[str, int]] = None):
         """f16x3: False/0 = exact-f32 MFMA convs (v_mfma_f32_32x32x2_f32); True/1 = 3-term split-operand f16 MFMA convs with
         f32 accumulation (conv_sh16.h): f32-class results (max |delta| vs the exact path 1.5e-5), ~3x faster; 2 = single-term
         f16 operands with f32 accumulation (reduced precision, tolerance 5e-2 -- BASELINE.json configs[4])."""
         self.f16x3 = f16x3
+        self.options = dict(options or {})          # extra ch_set_option(key, value) pairs applied before ch_finalize
         self.device_index = device
         self.device = torch.device('cuda', device)
         self.handle = _lib.Handle(device)
@@ -32,6 +33,8 @@ class SeanGenerator:
                 a = a.astype(np.float32)
             self.handle.load_tensor(_lib.MODEL_SEAN, k, a)
         self.handle.set_option('sean.f16x3', int(self.f16x3))
+        for k, v in self.options.items():
+            self.handle.set_option(k, int(v))
         self.handle.finalize(_lib.MODEL_SEAN, max_batch, max_size)
         self.max_batch, self.max_size = max_batch, max_size
         return self
