@@ -278,24 +278,53 @@ __global__ __launch_bounds__(256) void ln_partial_kernel(const float* __restrict
         o[2] = m2;
     }
 }
+// Merge of the (count, mean, M2) partials of one sample by the first wave of a block (Chan et al. pairwise, butterfly over
+// the lanes: a fixed association, so results are reproducible); every thread of the block receives (mean, 1 / (std + eps)),
+// std unbiased like the reference's x.view(B, -1).std(1) (my_torchlib/module.py:192-196).  nblk <= 128.
+__device__ __forceinline__ void ln_merge_partials(const float* __restrict__ part, int nblk, float eps, float& mean_out,
+                                                  float& inv_out) {
+    __shared__ float s_stat[2];
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int k = lane; k < nblk; k += 64) {
+            const float nb = part[k * 3 + 0], mb = part[k * 3 + 1], qb = part[k * 3 + 2];
+            if (nb > 0.f) {
+                const float nn = n + nb, d = mb - mean;
+                mean += d * nb / nn;
+                m2 += qb + d * d * n * nb / nn;
+                n = nn;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float nb = __shfl_xor(n, off, 64), mb = __shfl_xor(mean, off, 64), qb = __shfl_xor(m2, off, 64);
+            const float nn = n + nb;
+            if (nn > 0.f) {
+                // symmetric form (both partners must arrive at the same merged triple)
+                const float d = mb - mean;
+                const float merged_mean = (n * mean + nb * mb) / nn;
+                m2 = m2 + qb + d * d * n * nb / nn;
+                mean = merged_mean;
+                n = nn;
+            }
+        }
+        if (lane == 0) {
+            s_stat[0] = mean;
+            s_stat[1] = 1.f / (sqrtf(m2 / (n - 1.f)) + eps);
+        }
+    }
+    __syncthreads();
+    mean_out = s_stat[0];
+    inv_out = s_stat[1];
+}
+
 __global__ __launch_bounds__(256) void ln_apply_kernel(float* __restrict__ x, const float* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        long long N, int HW, int nblk, float eps, int act) {
     const int b = blockIdx.y;
-    // merge partials (every thread redundantly; nblk <= 256)
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        const float* o = part + ((long long)b * nblk + k) * 3;
-        const float nb = o[0], mb = o[1], qb = o[2];
-        if (nb > 0.f) {
-            const float nn = n + nb, d = mb - mean;
-            mean += d * nb / nn;
-            m2 += qb + d * d * n * nb / nn;
-            n = nn;
-        }
-    }
-    const float stdv = sqrtf(m2 / (n - 1.f));
-    const float inv = 1.f / (stdv + eps);
+    float mean, inv;
+    ln_merge_partials(part + (long long)b * nblk * 3, nblk, eps, mean, inv);
     float* p = x + (long long)b * N;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const int c = (int)(i / HW);
@@ -314,18 +343,8 @@ __global__ __launch_bounds__(256) void ln_apply_conv_kernel(const float* __restr
     typedef _Float16 half8v __attribute__((ext_vector_type(8)));
     sh16_mode_on();
     const int b = blockIdx.y;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        const float* o = part + ((long long)b * nblk + k) * 3;
-        const float nb = o[0], mb = o[1], qb = o[2];
-        if (nb > 0.f) {
-            const float nn = n + nb, d = mb - mean;
-            mean += d * nb / nn;
-            m2 += qb + d * d * n * nb / nn;
-            n = nn;
-        }
-    }
-    const float inv = 1.f / (sqrtf(m2 / (n - 1.f)) + eps);
+    float mean, inv;
+    ln_merge_partials(part + (long long)b * nblk * 3, nblk, eps, mean, inv);
     const int G = C >> 3;
     const long long items = (long long)G * HW;
     const float* xb = x + (long long)b * C * HW;
