@@ -8,6 +8,7 @@ hipError_t conv_plain3(const ConvParams& p, hipStream_t s) {
         return launch_conv<3, 1, 2, 32, 8, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
     }
     if (p.W > 8) return launch_conv<3, 1, 2, 16, 16, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
+    if (p.W <= 4 && p.H <= 4 && rows >= 256) return launch_conv<3, 1, 4, 4, 4, 8, CK_KS3, EPI_PLAIN>(p, rows, s);   // see conv_inst_s2.hip
     return launch_conv<3, 1, 2, 8, 8, 4, CK_KS3, EPI_PLAIN>(p, rows, s);
 }
 }  // namespace chk

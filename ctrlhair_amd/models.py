@@ -180,7 +180,7 @@ class ColorTextureModels:
         B = code.shape[0]
         out = torch.empty(B, 11, device=self.device)
         self.handle.call('ch_color_encode', code.data_ptr(), out.data_ptr(), B, _stream(self.device))
-        return {'adv': out[:, [0]], 'noise': out[:, 1:9], 'noise_curliness': out[:, 9:10]}
+        return {'adv': out[:, 0:1], 'noise': out[:, 1:9], 'noise_curliness': out[:, 9:10]}     # slices only: a list index is an H2D copy
 
     def _rgb(self, data):      # Predictor.forward, predictor_model.py:32-41 (predict_dict: rgb_mean 3, pca_std 1)
         code = self._f(data['code'])

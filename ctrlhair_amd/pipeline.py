@@ -26,6 +26,18 @@ _MEAN = (0.485, 0.456, 0.406)     # external_code/face_parsing/my_parsing_util.p
 _STD = (0.229, 0.224, 0.225)
 
 
+_HSV_TABLES: Dict[torch.device, tuple] = {}
+
+
+def _hsv_tables(device):
+    """OpenCV's division tables on `device`, uploaded once: a host-to-device copy from pageable memory inside the edit would
+    make the host wait for the stream to drain (tools/host_enqueue.py), i.e. serialise consecutive edits."""
+    t = _HSV_TABLES.get(device)
+    if t is None:
+        t = _HSV_TABLES[device] = (torch.as_tensor(U._SDIV).to(device), torch.as_tensor(U._HDIV).to(device))
+    return t
+
+
 def rgb_to_hsv_u8(rgb: torch.Tensor) -> torch.Tensor:
     """cv2.cvtColor(uint8 RGB, COLOR_RGB2HSV) on [N,3] uint8-valued tensors, on the tensor's device: the same 12-bit
     fixed-point arithmetic as hostutil.rgb_to_hsv_u8 (H in [0,180), S, V in [0,255])."""
@@ -33,8 +45,7 @@ def rgb_to_hsv_u8(rgb: torch.Tensor) -> torch.Tensor:
     r, g, b = a[:, 0], a[:, 1], a[:, 2]
     v = a.max(dim=1).values
     d = v - a.min(dim=1).values
-    sdiv = torch.as_tensor(U._SDIV, device=rgb.device)
-    hdiv = torch.as_tensor(U._HDIV, device=rgb.device)
+    sdiv, hdiv = _hsv_tables(rgb.device)
     half = 1 << (U._HSV_SHIFT - 1)
     h = torch.where(v == r, g - b, torch.where(v == g, b - r + 2 * d, r - g + 4 * d))
     h = (h * hdiv[d] + half) >> U._HSV_SHIFT
@@ -155,15 +166,20 @@ class EditPipeline:
             stages.update(lat, labels=labels, mask=mask, image=image)
         return image
 
-    def stage_times(self, img: torch.Tensor, reps: int = 3) -> Dict[str, float]:
+    STAGES = ('parse', 'shape_encode', 'zencoder', 'colour', 'shape_decode', 'generator')
+
+    def stage_times(self, img: torch.Tensor, reps: int = 3, before=None) -> Dict[str, float]:
         """ms per stage of one edit() over `img` (torch events on the current stream, averaged over `reps` runs; measurement
-        only -- edit() itself is never instrumented).  Keys: parse (BiSeNet), shape_encode, zencoder, colour (3 MLPs + sliders),
-        shape_decode, generator."""
+        only -- edit() itself is never instrumented).  Keys: STAGES = parse (BiSeNet), shape_encode, zencoder, colour (3 MLPs +
+        sliders), shape_decode, generator.  `before(name)`, if given, runs ahead of every stage (tools/stage_trace.py launches
+        a marker kernel there so that a rocprofv3 kernel trace can be cut into stages)."""
         m, S = self.models, img.shape[-1]
         acc: Dict[str, float] = {}
 
         def timed(name, fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if before is not None:
+                before(name)
             e0.record()
             r = fn()
             e1.record()
