@@ -374,13 +374,15 @@ std::string ShapeModel::decode(const float* hair_code, const float* face_code, f
 // =================================================================================================================
 namespace {
 // conv (no bias) + eval BN folded: w' = w * s[co], b' = shift[co]
+// sh16: stride-1 layers are packed for the f16x3 kernels instead
 ConvLayer conv_bn(Builder& B, const std::string& conv, const std::string& bn, int cout, int cin, int ks, int stride,
-                  int pad) {
+                  int pad, bool sh16 = false) {
     auto w = B.vec(conv + ".weight", (size_t)cout * cin * ks * ks);
     std::vector<float> sc, sh;
     bn_fold(B, bn, cout, sc, sh);
     for (int o = 0; o < cout; ++o)
         for (size_t i = 0; i < (size_t)cin * ks * ks; ++i) w[(size_t)o * cin * ks * ks + i] *= sc[o];
+    if (sh16 && stride == 1) return make_conv_sh16(B, w, sh, cout, cin, ks, pad);
     return make_conv(B, w, sh, cout, cin, ks, stride, pad);
 }
 }  // namespace
@@ -406,15 +408,15 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
             const int cin = i == 0 ? chans[L - 1] : chans[L], cout = chans[L];
             const int stride = (i == 0 && L > 1) ? 2 : 1;
             const std::string p = "cp.resnet.layer" + std::to_string(L) + "." + std::to_string(i);
-            bb.c1 = conv_bn(B, p + ".conv1", p + ".bn1", cout, cin, 3, stride, 1);
-            bb.c2 = conv_bn(B, p + ".conv2", p + ".bn2", cout, cout, 3, 1, 1);
+            bb.c1 = conv_bn(B, p + ".conv1", p + ".bn1", cout, cin, 3, stride, 1, use_sh16);
+            bb.c2 = conv_bn(B, p + ".conv2", p + ".bn2", cout, cout, 3, 1, 1, use_sh16);
             bb.has_down = (cin != cout || stride != 1);
-            if (bb.has_down) bb.down = conv_bn(B, p + ".downsample.0", p + ".downsample.1", cout, cin, 1, stride, 0);
+            if (bb.has_down) bb.down = conv_bn(B, p + ".downsample.0", p + ".downsample.1", cout, cin, 1, stride, 0, use_sh16);
         }
-    arm16_conv = conv_bn(B, "cp.arm16.conv.conv", "cp.arm16.conv.bn", 128, 256, 3, 1, 1);
-    arm32_conv = conv_bn(B, "cp.arm32.conv.conv", "cp.arm32.conv.bn", 128, 512, 3, 1, 1);
-    head32 = conv_bn(B, "cp.conv_head32.conv", "cp.conv_head32.bn", 128, 128, 3, 1, 1);
-    head16 = conv_bn(B, "cp.conv_head16.conv", "cp.conv_head16.bn", 128, 128, 3, 1, 1);
+    arm16_conv = conv_bn(B, "cp.arm16.conv.conv", "cp.arm16.conv.bn", 128, 256, 3, 1, 1, use_sh16);
+    arm32_conv = conv_bn(B, "cp.arm32.conv.conv", "cp.arm32.conv.bn", 128, 512, 3, 1, 1, use_sh16);
+    head32 = conv_bn(B, "cp.conv_head32.conv", "cp.conv_head32.bn", 128, 128, 3, 1, 1, use_sh16);
+    head16 = conv_bn(B, "cp.conv_head16.conv", "cp.conv_head16.bn", 128, 128, 3, 1, 1, use_sh16);
     {   // FFM convblk (1x1, 256 -> 256 on cat[fsp, fcp]) split into the two 128-channel halves (no concat buffer)
         auto w = B.vec("ffm.convblk.conv.weight", 256 * 256);
         std::vector<float> sc, sh;
@@ -425,11 +427,14 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
                 wa[(size_t)o * 128 + i] = w[(size_t)o * 256 + i] * sc[o];
                 wb[(size_t)o * 128 + i] = w[(size_t)o * 256 + 128 + i] * sc[o];
             }
-        ffm_a = make_conv(B, wa, std::vector<float>(), 256, 128, 1, 1, 0);
-        ffm_b = make_conv(B, wb, sh, 256, 128, 1, 1, 0);
+        ffm_a = use_sh16 ? make_conv_sh16(B, wa, std::vector<float>(), 256, 128, 1, 0) : make_conv(B, wa, std::vector<float>(), 256, 128, 1, 1, 0);
+        ffm_b = use_sh16 ? make_conv_sh16(B, wb, sh, 256, 128, 1, 0) : make_conv(B, wb, sh, 256, 128, 1, 1, 0);
     }
-    out_conv = conv_bn(B, "conv_out.conv.conv", "conv_out.conv.bn", 256, 256, 3, 1, 1);
-    out_cls = make_conv(B, B.vec("conv_out.conv_out.weight", 19 * 256), std::vector<float>(), 19, 256, 1, 1, 0);
+    out_conv = conv_bn(B, "conv_out.conv.conv", "conv_out.conv.bn", 256, 256, 3, 1, 1, use_sh16);
+    {   // classifier: 19 rows (f16x3 path: padded to 20 with a zero row, C4 output of 5 groups)
+        const auto wc = B.vec("conv_out.conv_out.weight", 19 * 256);
+        out_cls = use_sh16 ? make_conv_sh16(B, wc, std::vector<float>(), 19, 256, 1, 0) : make_conv(B, wc, std::vector<float>(), 19, 256, 1, 1, 0);
+    }
     auto vecconv = [&](const std::string& conv, const std::string& bn, int o, int i, float*& w, float*& sc, float*& sh) {
         w = B.upload(B.vec(conv + ".weight", (size_t)o * i));
         std::vector<float> s, t;
@@ -458,8 +463,9 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
     vec0 = B.falloc((size_t)mb * 512);
     vec1 = B.falloc((size_t)mb * 512);
     vec2 = B.falloc((size_t)mb * 512);
-    splitk_cap = (long long)8 << 20;
+    splitk_cap = (long long)16 << 20;
     splitk_ws = B.falloc((size_t)splitk_cap);
+    amax = static_cast<unsigned*>(B.dalloc(64 * sizeof(unsigned)));
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "device sync failed";
     ready = true;
@@ -467,10 +473,126 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
 }
 void BiSeNetModel::destroy() { free_all(allocs); ready = false; }
 
+// The f16x3 trunk: same graph as parse() below, activations in the C4 layout.  A tensor that feeds a conv carries the slot
+// its producer records max |value| in; the consuming conv derives the f16 scale from it while it stages the tensor.
+std::string BiSeNetModel::parse_sh16(const float* img, uint8_t* labels, float* logits, int Btot, int H, int W, hipStream_t st) {
+    struct T { float* p; unsigned* amax; };
+    for (int bo = 0; bo < Btot; bo += max_batch) {
+        const int B = std::min(max_batch, Btot - bo);
+        Ck ck;
+        ck(hipMemsetAsync(amax, 0, 64 * sizeof(unsigned), st), "amax reset");
+        int ns = 0;
+        auto mk = [&](float* ptr) { return T{ptr, amax + ns++}; };
+        const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8, h16 = H / 16, w16 = W / 16,
+                  h32 = H / 32, w32 = W / 32;
+        // stride-1 conv: f16x3 kernel over the C4 input
+        auto conv = [&](const ConvLayer& L, T in, T out, int hin, int win, int act, const float* res, int in_mode, const char* what) {
+            ConvParams p{};
+            p.in = in.p;
+            p.out = out.p;
+            p.B = B;
+            p.Cin = L.Cin;
+            p.in_mode = in_mode;
+            p.H = conv_out_size(L, hin, in_mode);
+            p.W = conv_out_size(L, win, in_mode);
+            p.Mrows = L.Cout;
+            p.bias = L.bias;
+            p.act = act;
+            p.res = res;
+            p.out_amax = out.amax;
+            p.partial = splitk_ws;
+            p.partial_cap = splitk_cap;
+            p.wpk = L.sh_wpk;
+            p.wscale = L.sh_wscale;
+            p.in_scale_inv = 1.f / SH16_ACT_SCALE;
+            p.in_amax = in.amax;
+            p.in_c4 = 1;
+            ck(conv_sh16_plain_c4(p, L.KS, st), what);
+        };
+        // stride-2 conv: exact-f32 kernel (NCHW in / out) between two layout conversions; scratch in the upper half of b0
+        float* s2_in = b0 + 2 * (size_t)B * 64 * h4 * w4;
+        float* s2_out = b0 + 3 * (size_t)B * 64 * h4 * w4;
+        auto conv_s2 = [&](const ConvLayer& L, const float* in_nchw, T out, int hin, int win, int act, const char* what) {
+            ConvOpts o;
+            o.act = act;
+            o.partial = splitk_ws;
+            o.partial_cap = splitk_cap;
+            ck(run_conv(L, in_nchw, s2_out, B, hin, win, o, st), what);
+            ck(nchw_to_c4(s2_out, out.p, out.amax, B, L.Cout, (hin / 2) * (win / 2), st), "nchw -> c4");
+        };
+        ck(stem7x7(img + (size_t)bo * 3 * H * W, stem_w, stem_b, b0, B, H, W, st), "stem");
+        T x = mk(b1);
+        ck(maxpool3x3s2_c4(b0, x.p, x.amax, B, 64, h2, w2, st), "maxpool");
+        float* t0 = b0;
+        float* t1 = b0 + (size_t)B * 64 * h4 * w4;
+        auto block = [&](const BasicBlockW& bb, T in, float* tmp, float* sc, float* outp, int hin, int win) {
+            T t = mk(tmp);
+            const int ho = hin / bb.c1.stride, wo = win / bb.c1.stride;
+            const float* shortcut = in.p;
+            if (bb.c1.stride == 2) {         // layers 2-4, first block: conv1 and the 1x1 shortcut are the stride-2 convs
+                ck(c4_to_nchw(in.p, s2_in, B, bb.c1.Cin, hin * win, st), "c4 -> nchw");
+                conv_s2(bb.c1, s2_in, t, hin, win, ACT_RELU, "bb conv1 (s2)");
+                conv_s2(bb.down, s2_in, T{sc, nullptr}, hin, win, ACT_NONE, "bb down (s2)");
+                shortcut = sc;
+            } else {
+                conv(bb.c1, in, t, hin, win, ACT_RELU, nullptr, IN_DIRECT, "bb conv1");
+            }
+            T o = mk(outp);
+            conv(bb.c2, t, o, ho, wo, ACT_RELU, shortcut, IN_DIRECT, "bb conv2");
+            return o;
+        };
+        x = block(blk[0], x, t0, nullptr, b2, h4, w4);
+        x = block(blk[1], x, t0, nullptr, b1, h4, w4);
+        x = block(blk[2], x, t0, t1, b2, h4, w4);
+        const T feat8 = block(blk[3], x, t0, nullptr, f8, h8, w8);
+        x = block(blk[4], feat8, t0, t1, b2, h8, w8);
+        const T feat16 = block(blk[5], x, t0, nullptr, f16, h16, w16);
+        x = block(blk[6], feat16, t0, t1, b2, h16, w16);
+        const T feat32 = block(blk[7], x, t0, nullptr, f32, h32, w32);
+        // ContextPath.forward (model.py:104-125)
+        ck(global_avg_pool_c4(feat32.p, vec0, B, 512, h32 * w32, st), "gap32");
+        ck(linear(vec0, avg_w, nullptr, avg_scale, avg_shift, vec1, B, 512, 128, 512, 128, ACT_RELU, st), "conv_avg");
+        T a = mk(t0);
+        conv(arm32_conv, feat32, a, h32, w32, ACT_RELU, nullptr, IN_DIRECT, "arm32 conv");
+        ck(global_avg_pool_c4(a.p, vec0, B, 128, h32 * w32, st), "arm32 gap");
+        ck(linear(vec0, att32_w, nullptr, att32_scale, att32_shift, vec2, B, 128, 128, 128, 128, ACT_SIGMOID, st), "arm32 atten");
+        T s32 = mk(t1);
+        ck(chan_affine_c4(a.p, vec2, 0.f, vec1, nullptr, s32.p, s32.amax, B, 128, h32 * w32, st), "feat32_sum");
+        T up32 = mk(b1);
+        conv(head32, s32, up32, h32, w32, ACT_RELU, nullptr, IN_UP2_NEAREST, "conv_head32");
+        a = mk(t0);
+        conv(arm16_conv, feat16, a, h16, w16, ACT_RELU, nullptr, IN_DIRECT, "arm16 conv");
+        ck(global_avg_pool_c4(a.p, vec0, B, 128, h16 * w16, st), "arm16 gap");
+        ck(linear(vec0, att16_w, nullptr, att16_scale, att16_shift, vec2, B, 128, 128, 128, 128, ACT_SIGMOID, st), "arm16 atten");
+        T s16 = mk(t1);
+        ck(chan_affine_c4(a.p, vec2, 0.f, nullptr, up32.p, s16.p, s16.amax, B, 128, h16 * w16, st), "feat16_sum");
+        T cp8 = mk(b2);
+        conv(head16, s16, cp8, h16, w16, ACT_RELU, nullptr, IN_UP2_NEAREST, "conv_head16");
+        // FeatureFusionModule (model.py:198-210): convblk(cat[feat8, feat_cp8]) as two 1x1 convs
+        conv(ffm_a, feat8, T{t0, nullptr}, h8, w8, ACT_NONE, nullptr, IN_DIRECT, "ffm a");
+        conv(ffm_b, cp8, T{t1, nullptr}, h8, w8, ACT_RELU, t0, IN_DIRECT, "ffm b");
+        ck(global_avg_pool_c4(t1, vec0, B, 256, h8 * w8, st), "ffm gap");
+        ck(linear(vec0, ffm1_w, nullptr, nullptr, nullptr, vec1, B, 256, 64, 256, 64, ACT_RELU, st), "ffm conv1");
+        ck(linear(vec1, ffm2_w, nullptr, nullptr, nullptr, vec2, B, 64, 256, 64, 256, ACT_SIGMOID, st), "ffm conv2");
+        T fo = mk(t0);
+        ck(chan_affine_c4(t1, vec2, 1.f, nullptr, nullptr, fo.p, fo.amax, B, 256, h8 * w8, st), "ffm out");
+        // BiSeNetOutput (model.py:43-46)
+        T oc = mk(t1);
+        conv(out_conv, fo, oc, h8, w8, ACT_RELU, nullptr, IN_DIRECT, "conv_out.conv");
+        conv(out_cls, oc, T{b1, nullptr}, h8, w8, ACT_NONE, nullptr, IN_DIRECT, "conv_out.conv_out");       // [B,5,h8,w8,4]
+        ck(bilinear_argmax(b1, labels + (size_t)bo * H * W, logits ? logits + (size_t)bo * 19 * H * W : nullptr, remap, B, h8,
+                           w8, H, W, st, 1), "bilinear argmax");
+        if (!ck.err.empty()) return ck.err;
+        if (ns > 64) return "BiSeNet: out of amax slots";
+    }
+    return "";
+}
+
 // BiSeNet.forward (model.py:241-254) -> [0] only (my_parsing_util.py:45), argmax + label swap (:46-54)
 std::string BiSeNetModel::parse(const float* img, uint8_t* labels, float* logits, int Btot, int H, int W, hipStream_t st) {
     if (!ready) return "BiSeNet not finalized";
     if (H % 32 || W % 32 || H > max_size || W > max_size || H < 64 || W < 64) return "H, W must be multiples of 32 within max_size";
+    if (use_sh16) return parse_sh16(img, labels, logits, Btot, H, W, st);
     for (int bo = 0; bo < Btot; bo += max_batch) {
         const int B = std::min(max_batch, Btot - bo);
         Ck ck;

@@ -76,12 +76,19 @@ struct BiSeNetModel {
     float *att32_w = nullptr, *att32_scale = nullptr, *att32_shift = nullptr;
     float *ffm1_w = nullptr, *ffm2_w = nullptr;
     uint8_t* remap = nullptr;
+    // f16x3 trunk (option "bisenet.f16x3", default on): every stride-1 conv on the split-operand f16 MFMA kernels with the
+    // f32 activations kept in the C4 layout and split while they are staged (conv_sh16.h, INC4); the stride-2 convs stay on
+    // the exact-f32 kernels (C4 in / out).  `amax`: one device slot per activation tensor (sh16.h).
+    bool use_sh16 = true;
+    unsigned* amax = nullptr;
     float *b0 = nullptr, *b1 = nullptr, *b2 = nullptr, *f8 = nullptr, *f16 = nullptr, *f32 = nullptr, *vec0 = nullptr,
           *vec1 = nullptr, *vec2 = nullptr, *splitk_ws = nullptr;
     long long splitk_cap = 0;
     std::string build(const TensorStore& ts, int max_batch, int max_size);
     std::string parse(const float* img, uint8_t* labels, float* logits, int B, int H, int W, hipStream_t st);
     void destroy();
+  private:
+    std::string parse_sh16(const float* img, uint8_t* labels, float* logits, int B, int H, int W, hipStream_t st);
 };
 
 }  // namespace chk

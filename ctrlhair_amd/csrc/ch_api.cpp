@@ -306,6 +306,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->shape.use_sh16 = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "bisenet.f16x3") == 0) {
+        if (h->bisenet.ready) return fail(h, CH_ERR_STATE, "ch_set_option(bisenet.f16x3) must precede ch_finalize");
+        h->bisenet.use_sh16 = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.ahead") == 0) {      // run-ahead mode up to `value` images of 512x512 per chunk (0 = off)
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.ahead) must precede ch_finalize");
         h->sean.ahead_pixels = (long long)value * 512 * 512;

@@ -88,6 +88,8 @@ struct ConvParams {
     unsigned* out_amax;     // EPI_ACE: slot receiving max |out * out_scale| (pass 0) / deciding the rescue (pass 1)
     int pass;               // EPI_ACE: 0 = write with out_scale and record the maximum; 1 = return unless the recorded
                             // maximum left the window, else rewrite with the corrected scale
+    int in_c4;              // set by callers of the INC4 instantiations of conv_sh16_kernel (documentation only: `in` is an f32
+                            // tensor in the C4 layout [B][C/4][H][W][4], split into f16 pairs while it is staged)
     int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over the persistent kernel)
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
     // EPI_NHWC

@@ -153,6 +153,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
         const float slope = act_slope(p.act);
         const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
         int pb_[4], pix_[4];
+        float amax = 0.f;              // max |out| (recorded in p.out_amax for consumers that split this f32 tensor: INC4)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
@@ -215,8 +216,14 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
                         v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
                     }
                     reinterpret_cast<float4*>(p.out)[((long long)b * C4n + (row0 >> 2)) * HW + pix_[n]] = v;
+                    amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
+                    amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
                 }
             }
+        if (p.out_amax && p.splitk <= 1) {
+            amax = sh16_wave_max(amax);
+            if (lane == 0) sh16_slot_max(p.out_amax, amax * SH16_ACT_SCALE);
+        }
     } else {  // EPI_ACE -> SH16 output.  Loop order: channel-run (rq) outer so that only one run's parameters
               // (5 float4) are live; pixel coordinates / noise / packed 3x3 label neighbourhoods are kept per n.
         const int C = p.C;
@@ -322,7 +329,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
             body(std::false_type{});
             if (p.out_amax) {
                 amax = sh16_wave_max(amax);
-                if (lane == 0) atomicMax(p.out_amax, __float_as_uint(amax));
+                if (lane == 0) sh16_slot_max(p.out_amax, amax);
             }
         }
     }
@@ -331,8 +338,14 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 // in : SH16 [B][Cin/8][2][H][W][8]   (Cin % 16 == 0; padding channels hold zeros)
 // EPI_PLAIN -> out f32 NCHW [B][Mrows][H][W] (bias / residual / act as conv_mfma)
 // EPI_ACE   -> out SH16 [B][ceil(C/8)][2][H][W][8]  (the fused ACE epilogue of conv_mfma.h, re-split for the next conv)
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false>
+// INC4: `in` is an f32 tensor in the C4 layout [B][Cin/4][H][W][4] (what the EPI_PLAIN epilogue writes) and is split into
+// f16 (hi, lo) units while it is staged: two float4 loads per (8-channel group, pixel) instead of two 16-byte SH16 units,
+// i.e. the same bytes and no separate conversion pass.  Scale: SH16_ACT_SCALE x the dynamic factor of the producer's
+// recorded maximum (p.in_amax; complete, because the producer is an earlier kernel), so the units always sit in the f16
+// window -- no second pass.  Used by the BiSeNet trunk (conv -> BN -> ReLU chains with residuals, all in C4).
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false>
 __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
+    static_assert(!(FUSE && INC4), "the fused second operand is an SH16 tensor");
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, NLOAD = Cfg::NLOAD, HALO = Cfg::HALO;
     constexpr int NT = KS * KS;
@@ -379,8 +392,39 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     // per-thread source offsets of its NLOAD patch units (chunk-invariant part), -1 = outside the image -> zeros.
     // Hoisted out of the chunk loop: the decode (3 div/mod per unit) was ~half of the kernel's VALU issue.
     int soff[NLOAD];
+    constexpr int NPAIR = (2 * PLANE + 255) / 256;             // INC4: (group, pixel) pairs per thread
+    float c4_scale = 1.f;
+    if constexpr (INC4) {
+        sh16_mode_on();
+        c4_scale = (p.in_scale_inv != 0.f ? 1.f / p.in_scale_inv : 1.f) * (p.in_amax ? sh16_dyn_extra(*p.in_amax) : 1.f);
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
+        for (int i = 0; i < NPAIR; ++i) {
+            const int q = tid + i * 256;
+            soff[i] = -1;
+            if (q < 2 * PLANE) {
+                const int g = q / PLANE, rem = q % PLANE;
+                const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
+                int y = y0 + py - HALO, x = x0 + px - HALO;
+                const int b = b0 + tb;
+                if (p.pad_mode == PAD_REFLECT) {
+                    y = y < 0 ? -y : (y >= p.H ? 2 * (p.H - 1) - y : y);
+                    x = x < 0 ? -x : (x >= p.W ? 2 * (p.W - 1) - x : x);
+                }
+                if (b < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                    // float4 index of the group's first C4 plane (4 planes per 16-channel chunk)
+                    if (p.in_mode == IN_UP2_NEAREST) {
+                        soff[i] = (b * (p.Cin >> 2) + g * 2) * HWi + (y >> 1) * (p.W >> 1) + (x >> 1);
+                    } else if (p.in_mode == IN_UP2_ZEROINS) {
+                        if (!((y | x) & 1)) soff[i] = (b * (p.Cin >> 2) + g * 2) * HWi + (y >> 1) * (p.W >> 1) + (x >> 1);
+                    } else {
+                        soff[i] = (b * (p.Cin >> 2) + g * 2) * HW + y * p.W + x;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (INC4 ? 0 : NLOAD); ++i) {
         const int u = tid + i * 256;
         soff[i] = -1;
         if (u < UNITS) {
@@ -422,6 +466,35 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         }
     };
     auto stage = [&](int chunk, int buf) {
+        if constexpr (INC4) {
+            float4 sa[NPAIR], sc[NPAIR];
+            const float4* src = reinterpret_cast<const float4*>(p.in) + (long long)chunk * 4 * HWi;
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) {
+                sa[i] = soff[i] >= 0 ? src[soff[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+                sc[i] = soff[i] >= 0 ? src[soff[i] + HWi] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            uint4* dst = smem_u + buf * UNITS;
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) {
+                const int q = tid + i * 256;
+                if (q < 2 * PLANE) {
+                    const int g = q / PLANE, rem = q - g * PLANE;
+                    const float v[8] = {sa[i].x, sa[i].y, sa[i].z, sa[i].w, sc[i].x, sc[i].y, sc[i].z, sc[i].w};
+                    half8 h, l;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        _Float16 he, le;
+                        sh16_split(v[e], c4_scale, he, le);
+                        h[e] = he;
+                        l[e] = le;
+                    }
+                    dst[(g * 2) * PLANE + rem] = __builtin_bit_cast(uint4, h);
+                    dst[(g * 2 + 1) * PLANE + rem] = __builtin_bit_cast(uint4, l);
+                }
+            }
+            return;
+        }
         // No scheduling fence in here on purpose: the compiler issues these loads early and sinks the LDS writes
         // below the chunk's MFMAs as far as registers allow, which is what overlaps staging with compute.
         uint4 stg[NLOAD];
@@ -913,7 +986,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     if constexpr (pre) {
         if (p.pass != 1 && p.out_amax) {                       // one atomic per consumer wave per launch
             amax = sh16_wave_max(amax);
-            if (lane == 0) atomicMax(p.out_amax, __float_as_uint(amax));
+            if (lane == 0) sh16_slot_max(p.out_amax, amax);
         }
     }
 }
@@ -957,6 +1030,7 @@ __global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
     const int C4n = (p.Mrows + 3) >> 2;
     const long long n = (long long)p.B * C4n * HW;       // float4 elements
     const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
+    float amax = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int s = 0; s < p.splitk; ++s) {
@@ -991,13 +1065,19 @@ __global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
             v.z = apply_act(v.z + rv.z, p.act); v.w = apply_act(v.w + rv.w, p.act);
         }
         reinterpret_cast<float4*>(p.out)[i] = v;
+        amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
+        amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
+    }
+    if (p.out_amax) {
+        amax = sh16_wave_max(amax);
+        if ((threadIdx.x & 63) == 0) sh16_slot_max(p.out_amax, amax * SH16_ACT_SCALE);
     }
 }
 
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false>
 hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
-    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE>;
+    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE, INC4>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1072,6 +1152,16 @@ hipError_t dispatch_sh16_plain(const ConvParams& p, hipStream_t s) {
     if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN, TERMS>(p, p.Mrows, s);
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, TERMS>(p, p.Mrows, s);
 }
+
+// f32 C4 input, split while staged (conv_sh16_kernel<..., INC4 = true>): the BiSeNet trunk
+template <int KS>
+hipError_t dispatch_sh16_plain_c4(const ConvParams& p, hipStream_t s) {
+    if (p.in2) return hipErrorInvalidValue;
+    if (p.W >= 32) return launch_sh16<KS, 32, 16, 1, EPI_PLAIN, 3, false, true>(p, p.Mrows, s);
+    if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN, 3, false, true>(p, p.Mrows, s);
+    return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, 3, false, true>(p, p.Mrows, s);
+}
+hipError_t conv_sh16_plain_c4(const ConvParams& p, int KS, hipStream_t s);   // f32 C4 in -> f32 C4 out (KS 1 or 3)
 
 // p.terms == 1 / 2 selects the single-term instantiations (operands rounded to f16 / bf16, f32 accumulate: BASELINE configs[4])
 hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s);   // SH16 in -> f32 C4 out

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws2_kernel(const ConvParams 
     }
     if (p.pass != 1 && p.out_amax) {                           // one atomic per consumer wave per launch
         amax = sh16_wave_max(amax);
-        if (lane == 0) atomicMax(p.out_amax, __float_as_uint(amax));
+        if (lane == 0) sh16_slot_max(p.out_amax, amax);
     }
 }
 

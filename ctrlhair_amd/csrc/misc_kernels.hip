@@ -569,6 +569,137 @@ hipError_t chan_affine(const float* in, const float* sc, float sc_add, const flo
     return hipGetLastError();
 }
 
+// ---- C4-layout ([B][C/4][H][W][4] f32) variants for the f16x3 BiSeNet trunk.  Producers of tensors that feed an INC4 conv
+// (conv_sh16.h) also record max |out| * SH16_ACT_SCALE in `amax` (sh16.h slot convention).
+__device__ __forceinline__ void amax_commit(unsigned* slot, float amax) {
+    amax = sh16_wave_max(amax);
+    if (slot && (threadIdx.x & 63) == 0) sh16_slot_max(slot, amax * SH16_ACT_SCALE);
+}
+// layout conversions around the exact-f32 stride-2 convs (NCHW kernels) of the otherwise-C4 trunk
+__global__ void c4_to_nchw_kernel(const float4* __restrict__ in, float* __restrict__ out, long long groups, int HW) {
+    const long long n = groups * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i / HW;
+        const int px = (int)(i - g * HW);
+        const float4 v = in[i];
+        float* o = out + g * 4 * HW + px;
+        o[0] = v.x; o[HW] = v.y; o[2LL * HW] = v.z; o[3LL * HW] = v.w;
+    }
+}
+hipError_t c4_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
+    const long long groups = (long long)B * (C >> 2), n = groups * HW;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(c4_to_nchw_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(in), out, groups, HW);
+    return hipGetLastError();
+}
+__global__ void nchw_to_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, long long groups,
+                                  int HW) {
+    const long long n = groups * HW;
+    float amax = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i / HW;
+        const int px = (int)(i - g * HW);
+        const float* q = in + g * 4 * HW + px;
+        const float4 v = make_float4(q[0], q[HW], q[2LL * HW], q[3LL * HW]);
+        out[i] = v;
+        amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
+        amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
+    }
+    amax_commit(amax_slot, amax);
+}
+hipError_t nchw_to_c4(const float* in, float* out, unsigned* amax, int B, int C, int HW, hipStream_t s) {
+    const long long groups = (long long)B * (C >> 2), n = groups * HW;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nchw_to_c4_kernel, dim3(grid), dim3(256), 0, s, in, reinterpret_cast<float4*>(out), amax, groups, HW);
+    return hipGetLastError();
+}
+// nn.MaxPool2d(3, 2, 1) (resnet.py:75): NCHW in -> C4 out
+__global__ void maxpool3x3s2_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, int B, int C,
+                                       int H, int W, int Ho, int Wo) {
+    const long long n = (long long)B * (C >> 2) * Ho * Wo;
+    float amax = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+        const long long bg = i / ((long long)Wo * Ho);            // b * C/4 + group
+        float m[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* p = in + (bg * 4 + e) * H * W;
+            float v = -3.4e38f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = 2 * y + dy, xx = 2 * x + dx;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = fmaxf(v, p[yy * W + xx]);
+                }
+            m[e] = v;
+            amax = fmaxf(amax, fabsf(v));
+        }
+        out[i] = make_float4(m[0], m[1], m[2], m[3]);
+    }
+    amax_commit(amax_slot, amax);
+}
+hipError_t maxpool3x3s2_c4(const float* in, float* out, unsigned* amax, int B, int C, int H, int W, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long n = (long long)B * (C >> 2) * Ho * Wo;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool3x3s2_c4_kernel, dim3(grid), dim3(256), 0, s, in, reinterpret_cast<float4*>(out), amax, B, C, H, W,
+                       Ho, Wo);
+    return hipGetLastError();
+}
+// F.avg_pool2d(x, x.size()[2:]) on a C4 tensor: one wave per (sample, 4-channel group) -> out[b*C + c]
+__global__ __launch_bounds__(256) void gap_c4_kernel(const float4* __restrict__ in, float* __restrict__ out, int groups, int HW) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= groups) return;
+    const float4* p = in + (long long)g * HW;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < HW; i += 64) {
+        const float4 v = p[i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    a.x = wave_sum(a.x); a.y = wave_sum(a.y); a.z = wave_sum(a.z); a.w = wave_sum(a.w);
+    if (lane == 0) *reinterpret_cast<float4*>(out + (long long)g * 4) = make_float4(a.x / HW, a.y / HW, a.z / HW, a.w / HW);
+}
+hipError_t global_avg_pool_c4(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
+    const int groups = B * (C >> 2);
+    hipLaunchKernelGGL(gap_c4_kernel, dim3((groups + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float4*>(in), out, groups, HW);
+    return hipGetLastError();
+}
+// chan_affine on C4 tensors: out = in * (sc[b,c] + sc_add) + (sh ? sh[b,c] : 0) + (other ? other : 0)
+__global__ void chan_affine_c4_kernel(const float4* __restrict__ in, const float* __restrict__ sc, float sc_add,
+                                      const float* __restrict__ sh, const float4* __restrict__ other, float4* __restrict__ out,
+                                      unsigned* amax_slot, long long groups, int HW) {
+    const long long n = groups * HW;
+    float amax = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i / HW;
+        const float4 a = *reinterpret_cast<const float4*>(sc + g * 4);
+        float4 v = in[i];
+        v.x *= a.x + sc_add; v.y *= a.y + sc_add; v.z *= a.z + sc_add; v.w *= a.w + sc_add;
+        if (sh) {
+            const float4 t = *reinterpret_cast<const float4*>(sh + g * 4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (other) {
+            const float4 t = other[i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        out[i] = v;
+        amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
+        amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
+    }
+    amax_commit(amax_slot, amax);
+}
+hipError_t chan_affine_c4(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,
+                          unsigned* amax, int B, int C, int HW, hipStream_t s) {
+    const long long groups = (long long)B * (C >> 2), n = groups * HW;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(chan_affine_c4_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(in), sc, sc_add, sh,
+                       reinterpret_cast<const float4*>(other), reinterpret_cast<float4*>(out), amax, groups, HW);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // ResNet-18 stem (resnet.py:61,72-73): conv 7x7 s2 p3, 3 -> 64, eval-BN folded into (w, bias), ReLU.
 // Direct VALU conv (K = 147 only): block = 16x16 output pixels; input patch 37x37x3 and all weights in LDS;
@@ -661,9 +792,10 @@ hipError_t stem7x7(const float* in, const float* w, const float* bias, float* ou
 // BiSeNet tail (model.py:250 + my_parsing_util.py:45-54): bilinear align_corners=True up-sampling of the 19
 // logit planes to (H,W), argmax over classes, remap BiSeNet ids -> CelebAMask-HQ ids with a 19-entry LUT.
 // logits_out (optional) receives the up-sampled logits [B,19,H,W] for tests.
+// c4 != 0: `lg` is the C4 tensor [B][5][h][w][4] (19 classes + one padding row) written by the f16x3 classifier conv.
 __global__ void bilinear_argmax_kernel(const float* __restrict__ lg, uint8_t* __restrict__ out,
                                        float* __restrict__ logits_out, const uint8_t* __restrict__ remap, int B, int h,
-                                       int w, int H, int W) {
+                                       int w, int H, int W, int c4) {
     const long long n = (long long)B * H * W;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
@@ -677,10 +809,11 @@ __global__ void bilinear_argmax_kernel(const float* __restrict__ lg, uint8_t* __
         float best = -3.4e38f;
         int bi = 0;
         for (int c = 0; c < 19; ++c) {
-            const float* p = lg + ((long long)b * 19 + c) * h * w;
+            const float* p = c4 ? lg + ((long long)b * 5 + (c >> 2)) * h * w * 4 + (c & 3) : lg + ((long long)b * 19 + c) * h * w;
+            const int es = c4 ? 4 : 1;                     // element stride between neighbouring pixels
             // same association as ATen's upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
-            const float v = (1.f - ly) * ((1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1]) +
-                            ly * ((1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+            const float v = (1.f - ly) * ((1.f - lx) * p[(y0 * w + x0) * es] + lx * p[(y0 * w + x1) * es]) +
+                            ly * ((1.f - lx) * p[(y1 * w + x0) * es] + lx * p[(y1 * w + x1) * es]);
             if (logits_out) logits_out[(((long long)b * 19 + c) * H + y) * W + x] = v;
             if (v > best) { best = v; bi = c; }
         }
@@ -688,10 +821,10 @@ __global__ void bilinear_argmax_kernel(const float* __restrict__ lg, uint8_t* __
     }
 }
 hipError_t bilinear_argmax(const float* lg, uint8_t* out, float* logits_out, const uint8_t* remap, int B, int h, int w,
-                           int H, int W, hipStream_t s) {
+                           int H, int W, hipStream_t s, int c4) {
     const long long n = (long long)B * H * W;
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(bilinear_argmax_kernel, dim3(grid), dim3(256), 0, s, lg, out, logits_out, remap, B, h, w, H, W);
+    hipLaunchKernelGGL(bilinear_argmax_kernel, dim3(grid), dim3(256), 0, s, lg, out, logits_out, remap, B, h, w, H, W, c4);
     return hipGetLastError();
 }
 

@@ -172,6 +172,8 @@ struct ConvLayer {
     float* wpk = nullptr;
     float* bias = nullptr;
     int Cout = 0, Cin = 0, KS = 0, stride = 1, pad = 0;
+    float* sh_wpk = nullptr;       // f16x3 packing (make_conv_sh16): split-operand A fragments + per-row inverse scales
+    float* sh_wscale = nullptr;
 };
 
 // w: [Cout][Cin][KS][KS] (already folded: BN / spectral norm / flips), bias may be empty
@@ -189,6 +191,28 @@ inline ConvLayer make_conv(Builder& B, const std::vector<float>& w, const std::v
         return wp[((size_t)row * cin + ci) * ks * ks + t];
     }));
     if (!bias.empty()) L.bias = B.upload(bias);
+    return L;
+}
+
+// stride-1 conv for the f16x3 kernels (conv_sh16.h): rows padded to a multiple of 4 with zero rows (C4 output runs)
+inline ConvLayer make_conv_sh16(Builder& B, const std::vector<float>& w, const std::vector<float>& bias, int cout, int cin,
+                                int ks, int pad) {
+    ConvLayer L;
+    L.Cout = (cout + 3) & ~3;
+    L.Cin = cin;
+    L.KS = ks;
+    L.stride = 1;
+    L.pad = pad;
+    const float* wp = w.data();
+    auto getw = [&](int row, int ci, int t) { return row < cout ? wp[((size_t)row * cin + ci) * ks * ks + t] : 0.f; };
+    const auto kexp = sh16_row_exponents(L.Cout, cin, ks, getw);
+    L.sh_wpk = B.upload(pack_A_sh16(L.Cout, cin, ks, getw, kexp));
+    L.sh_wscale = B.upload(sh16_wscale(kexp));
+    if (!bias.empty()) {
+        std::vector<float> b(L.Cout, 0.f);
+        std::copy(bias.begin(), bias.end(), b.begin());
+        L.bias = B.upload(b);
+    }
     return L;
 }
 

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
                     }
         }
     }
-    if (sh16 && amax && pass == 0 && lane == 0) atomicMax(amax, __float_as_uint(vmax));
+    if (sh16 && amax && pass == 0 && lane == 0) sh16_slot_max(amax, vmax);
 }
 
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad,

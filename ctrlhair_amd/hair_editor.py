@@ -55,7 +55,8 @@ class HipModels:
                                                                           weights['color_rgb'], max_batch=max(max_batch, 16))
         self.mask_generator = ShapeGenerator(h, dev).load_state_dict(weights['shape'], max_batch=max(max_batch, 1),
                                                                      f16x3=bool(f16x3))      # exact f32 everywhere when f16x3=False
-        self.face_parsing = FaceParsing(h, dev).load_state_dict(weights['bisenet'], max_batch=max(max_batch, 1), max_size=512)
+        self.face_parsing = FaceParsing(h, dev).load_state_dict(weights['bisenet'], max_batch=max(max_batch, 1), max_size=512,
+                                                                f16x3=bool(f16x3))
         from .blending import PoissonBlender
         self.blender = PoissonBlender(h, dev)       # blending step after the generator (Backend(blending=True))
 

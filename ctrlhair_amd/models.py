@@ -211,7 +211,10 @@ class FaceParsing:
     def __init__(self, handle: _lib.Handle, device: torch.device):
         self.handle, self.device = handle, device
 
-    def load_state_dict(self, sd: Dict[str, object], max_batch: int = 8, max_size: int = 512):
+    def load_state_dict(self, sd: Dict[str, object], max_batch: int = 8, max_size: int = 512, f16x3: bool = True):
+        """f16x3: the stride-1 convs on the split-operand f16 MFMA kernels (f32-class; default) or, False, every conv on the
+        exact-f32 kernels (option bisenet.f16x3 of the library)."""
+        self.handle.set_option('bisenet.f16x3', 1 if f16x3 else 0)
         for k, v in sd.items():
             if k.startswith('conv_out16.') or k.startswith('conv_out32.'):
                 continue     # auxiliary heads: outputs discarded at inference (my_parsing_util.py:45 takes [0])

@@ -89,7 +89,8 @@ def test_stages_against_reference_fixture(pipe):
 
 def test_end_to_end_batch8(pipe):
     """B=8 through edit(): samples 0-1 are the fixture's portraits (labels / image agree with it wherever no argmax tie is
-    involved), every sample equals the same sample run alone (no cross-sample op), output finite and tanh-bounded."""
+    involved), every sample equals the same sample run alone up to argmax near-ties (no cross-sample op), output finite and
+    tanh-bounded."""
     from ctrlhair_amd import procedural as P
     z = _fixture()
     S, ngf, dev = 512, 64, pipe.device
@@ -105,7 +106,17 @@ def test_end_to_end_batch8(pipe):
     assert not ((lab != z['labels']) & ~low).any()
     if np.array_equal(lab, z['labels']) and np.array_equal(st['mask'].cpu().numpy()[:2], z['mask']):
         assert _img_err(z, out[:2]) <= TOL           # no tie anywhere: the un-forced run reproduces the reference image
-    one = pipe.edit(img[5:6], noise=nz[5:6]).cpu().numpy()
+    # sample 5 alone.  The networks are per-sample, but split-K follows the grid size, i.e. the batch: logits move in the last
+    # bits, so the two parsings / decoded masks may differ at argmax near-ties (and only there) ...
+    st1 = {}
+    pipe.edit(img[5:6], noise=nz[5:6], stages=st1)
+    x = ((img[5:6] * 0.5 + 0.5) - pipe.mean) / pipe.std
+    lg = pipe.models.face_parsing.parse_tensor(x, want_logits=True)[1]
+    top2 = torch.topk(lg, 2, dim=1).values
+    flip = st1['labels'][0] != st['labels'][5]
+    assert not (flip & ((top2[0, 0] - top2[0, 1]) > 1e-3)).any()
+    # ... and with the batch run's parsing and mask forced, the rest of the edit is the same image
+    one = pipe.edit(img[5:6], noise=nz[5:6], labels=st['labels'][5:6], mask=st['mask'][5:6]).cpu().numpy()
     assert np.abs(one[0] - out[5]).max() <= 1e-5
 
 
