@@ -392,13 +392,14 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
     if (ms % 32 != 0 || ms < 64) return "BiSeNet max_size must be a multiple of 32 (>= 64)";
     max_batch = mb;
     max_size = ms;
-    {   // stem (resnet.py:61-62): 7x7 s2 conv + BN folded, VALU kernel layout [64][3*49]
+    {   // stem (resnet.py:61-62): 7x7 s2 conv + BN folded, VALU kernel layout [3*49][64]
         auto w = B.vec("cp.resnet.conv1.weight", 64 * 147);
         std::vector<float> sc, sh;
         bn_fold(B, "cp.resnet.bn1", 64, sc, sh);
+        std::vector<float> wt((size_t)147 * 64);            // [tap = (c, ky, kx)][output channel]: stem7x7_kernel's scalar loads
         for (int o = 0; o < 64; ++o)
-            for (int i = 0; i < 147; ++i) w[o * 147 + i] *= sc[o];
-        stem_w = B.upload(w);
+            for (int i = 0; i < 147; ++i) wt[(size_t)i * 64 + o] = w[o * 147 + i] * sc[o];
+        stem_w = B.upload(wt);
         stem_b = B.upload(sh);
     }
     const int chans[5] = {64, 64, 128, 256, 512};

@@ -1025,7 +1025,7 @@ hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
 
 // split-K reduce for the C4 layout: out = act(sum_s partial[s] + bias (+ res)), fixed summation order (reproducible)
 template <int DUMMY>
-__global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
+__global__ __launch_bounds__(1024) void sh16_splitk_reduce_kernel(const ConvParams p) {
     const long long HW = (long long)p.H * p.W;
     const int C4n = (p.Mrows + 3) >> 2;
     const long long n = (long long)p.B * C4n * HW;       // float4 elements
@@ -1068,10 +1068,7 @@ __global__ void sh16_splitk_reduce_kernel(const ConvParams p) {
         amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
         amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
     }
-    if (p.out_amax) {
-        amax = sh16_wave_max(amax);
-        if ((threadIdx.x & 63) == 0) sh16_slot_max(p.out_amax, amax * SH16_ACT_SCALE);
-    }
+    if (p.out_amax) sh16_block_slot_max(p.out_amax, amax * SH16_ACT_SCALE);       // uniform branch: every thread gets here
 }
 
 template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false>
@@ -1107,8 +1104,12 @@ hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid * p.splitk), dim3(256), Cfg::LDS_BYTES, stream, p);
     if (p.splitk > 1) {
         const long long n = (long long)p.B * ((p.Mrows + 3) / 4) * p.H * p.W;
-        const int rg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(sh16_splitk_reduce_kernel<0>, dim3(rg), dim3(256), 0, stream, p);
+        if (p.out_amax) {      // few, large blocks: one slot atomic per block (sh16.h)
+            hipLaunchKernelGGL(sh16_splitk_reduce_kernel<0>, dim3(sh16_ew_grid(n)), dim3(SH16_EW_THREADS), 0, stream, p);
+        } else {
+            const int rg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+            hipLaunchKernelGGL(sh16_splitk_reduce_kernel<0>, dim3(rg), dim3(256), 0, stream, p);
+        }
     }
     return hipGetLastError();
 }

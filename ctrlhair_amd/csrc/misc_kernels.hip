@@ -571,9 +571,8 @@ hipError_t chan_affine(const float* in, const float* sc, float sc_add, const flo
 
 // ---- C4-layout ([B][C/4][H][W][4] f32) variants for the f16x3 BiSeNet trunk.  Producers of tensors that feed an INC4 conv
 // (conv_sh16.h) also record max |out| * SH16_ACT_SCALE in `amax` (sh16.h slot convention).
-__device__ __forceinline__ void amax_commit(unsigned* slot, float amax) {
-    amax = sh16_wave_max(amax);
-    if (slot && (threadIdx.x & 63) == 0) sh16_slot_max(slot, amax * SH16_ACT_SCALE);
+__device__ __forceinline__ void amax_commit(unsigned* slot, float amax) {      // whole block; see sh16_block_slot_max
+    sh16_block_slot_max(slot, amax * SH16_ACT_SCALE);
 }
 // layout conversions around the exact-f32 stride-2 convs (NCHW kernels) of the otherwise-C4 trunk
 __global__ void c4_to_nchw_kernel(const float4* __restrict__ in, float* __restrict__ out, long long groups, int HW) {
@@ -592,7 +591,7 @@ hipError_t c4_to_nchw(const float* in, float* out, int B, int C, int HW, hipStre
     hipLaunchKernelGGL(c4_to_nchw_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(in), out, groups, HW);
     return hipGetLastError();
 }
-__global__ void nchw_to_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, long long groups,
+__global__ __launch_bounds__(1024) void nchw_to_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, long long groups,
                                   int HW) {
     const long long n = groups * HW;
     float amax = 0.f;
@@ -609,12 +608,11 @@ __global__ void nchw_to_c4_kernel(const float* __restrict__ in, float4* __restri
 }
 hipError_t nchw_to_c4(const float* in, float* out, unsigned* amax, int B, int C, int HW, hipStream_t s) {
     const long long groups = (long long)B * (C >> 2), n = groups * HW;
-    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(nchw_to_c4_kernel, dim3(grid), dim3(256), 0, s, in, reinterpret_cast<float4*>(out), amax, groups, HW);
+    hipLaunchKernelGGL(nchw_to_c4_kernel, dim3(sh16_ew_grid(n)), dim3(SH16_EW_THREADS), 0, s, in, reinterpret_cast<float4*>(out), amax, groups, HW);
     return hipGetLastError();
 }
 // nn.MaxPool2d(3, 2, 1) (resnet.py:75): NCHW in -> C4 out
-__global__ void maxpool3x3s2_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, int B, int C,
+__global__ __launch_bounds__(1024) void maxpool3x3s2_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, int B, int C,
                                        int H, int W, int Ho, int Wo) {
     const long long n = (long long)B * (C >> 2) * Ho * Wo;
     float amax = 0.f;
@@ -643,8 +641,7 @@ __global__ void maxpool3x3s2_c4_kernel(const float* __restrict__ in, float4* __r
 hipError_t maxpool3x3s2_c4(const float* in, float* out, unsigned* amax, int B, int C, int H, int W, hipStream_t s) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long n = (long long)B * (C >> 2) * Ho * Wo;
-    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(maxpool3x3s2_c4_kernel, dim3(grid), dim3(256), 0, s, in, reinterpret_cast<float4*>(out), amax, B, C, H, W,
+    hipLaunchKernelGGL(maxpool3x3s2_c4_kernel, dim3(sh16_ew_grid(n)), dim3(SH16_EW_THREADS), 0, s, in, reinterpret_cast<float4*>(out), amax, B, C, H, W,
                        Ho, Wo);
     return hipGetLastError();
 }
@@ -667,7 +664,7 @@ hipError_t global_avg_pool_c4(const float* in, float* out, int B, int C, int HW,
     return hipGetLastError();
 }
 // chan_affine on C4 tensors: out = in * (sc[b,c] + sc_add) + (sh ? sh[b,c] : 0) + (other ? other : 0)
-__global__ void chan_affine_c4_kernel(const float4* __restrict__ in, const float* __restrict__ sc, float sc_add,
+__global__ __launch_bounds__(1024) void chan_affine_c4_kernel(const float4* __restrict__ in, const float* __restrict__ sc, float sc_add,
                                       const float* __restrict__ sh, const float4* __restrict__ other, float4* __restrict__ out,
                                       unsigned* amax_slot, long long groups, int HW) {
     const long long n = groups * HW;
@@ -694,24 +691,25 @@ __global__ void chan_affine_c4_kernel(const float4* __restrict__ in, const float
 hipError_t chan_affine_c4(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,
                           unsigned* amax, int B, int C, int HW, hipStream_t s) {
     const long long groups = (long long)B * (C >> 2), n = groups * HW;
-    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(chan_affine_c4_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(in), sc, sc_add, sh,
+    hipLaunchKernelGGL(chan_affine_c4_kernel, dim3(sh16_ew_grid(n)), dim3(SH16_EW_THREADS), 0, s, reinterpret_cast<const float4*>(in), sc, sc_add, sh,
                        reinterpret_cast<const float4*>(other), reinterpret_cast<float4*>(out), amax, groups, HW);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // ResNet-18 stem (resnet.py:61,72-73): conv 7x7 s2 p3, 3 -> 64, eval-BN folded into (w, bias), ReLU.
-// Direct VALU conv (K = 147 only): block = 16x16 output pixels; input patch 37x37x3 and all weights in LDS;
-// each thread computes 64 outputs for one pixel in 4 passes of 16 channels.
-__global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ in, const float* __restrict__ w,
+// Direct VALU conv (K = 147 is too short for the matrix cores): block = 16x16 output pixels, one pixel per thread, all 64
+// output channels in registers; the 37x37x3 input patch in LDS (one read per tap); the weights, transposed on the host to
+// [tap][64], arrive through wave-uniform scalar loads and enter the packed FMAs (v_pk_fma_f32) as SGPR operands -- no LDS
+// traffic for them (the previous version read 16 weights from LDS per 16 FMAs and was LDS-issue bound: 0.48 ms -> see
+// DESIGN.md for the measured time at B=8, 512x512).
+typedef float stem_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                       const float* __restrict__ bias, float* __restrict__ out, int H,
                                                       int W, int Ho, int Wo) {
     __shared__ float patch[3][37][38];
-    __shared__ float ws[64 * 147];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16, b = blockIdx.z;
-    for (int e = threadIdx.x; e < 64 * 147; e += 256) ws[e] = w[e];
     for (int e = threadIdx.x; e < 3 * 37 * 37; e += 256) {
         const int c = e / (37 * 37), r = e % (37 * 37), py = r / 37, px = r % 37;
         const int y = oy0 * 2 - 3 + py, x = ox0 * 2 - 3 + px;
@@ -720,26 +718,31 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ 
                                : 0.f;
     }
     __syncthreads();
+    stem_f2 acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = stem_f2{0.f, 0.f};
+#pragma unroll 1
+    for (int cky = 0; cky < 21; ++cky) {                  // (channel, kernel row)
+        const int c = cky / 7, ky = cky % 7;
+        const float* prow = &patch[c][ty * 2 + ky][tx * 2];
+        const stem_f2* wrow = reinterpret_cast<const stem_f2*>(wt + (size_t)cky * 7 * 64);
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const float v = prow[kx];
+            const stem_f2 vv = stem_f2{v, v};
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc[k] += wrow[kx * 32 + k] * vv;
+        }
+    }
     const int ox = ox0 + tx, oy = oy0 + ty;
-    for (int co0 = 0; co0 < 64; co0 += 16) {
-        float acc[16];
+    if (ox < Wo && oy < Ho) {
+        float* o = out + (((long long)b * 64) * Ho + oy) * Wo + ox;
+        const long long cs = (long long)Ho * Wo;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        for (int c = 0; c < 3; ++c)
-            for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    const float v = patch[c][ty * 2 + ky][tx * 2 + kx];
-                    const int wi = (c * 7 + ky) * 7 + kx;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) acc[k] += ws[(co0 + k) * 147 + wi] * v;
-                }
-        if (ox < Wo && oy < Ho) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float v = acc[k] + bias[co0 + k];
-                out[(((long long)b * 64 + co0 + k) * Ho + oy) * Wo + ox] = v > 0.f ? v : 0.f;
-            }
+        for (int k = 0; k < 32; ++k) {
+            const float v0 = acc[k].x + bias[2 * k], v1 = acc[k].y + bias[2 * k + 1];
+            o[(2 * k) * cs] = v0 > 0.f ? v0 : 0.f;
+            o[(2 * k + 1) * cs] = v1 > 0.f ? v1 : 0.f;
         }
     }
 }

@@ -78,4 +78,23 @@ __device__ __forceinline__ void sh16_slot_max(unsigned* slot, float v) {
     if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
 }
 
+// One commit per BLOCK (every thread of the block must call it): elementwise producers launch few, large blocks
+// (SH16_EW_BLOCKS x SH16_EW_THREADS, grid-stride) so that a kernel issues a few hundred atomics, not tens of thousands.
+constexpr int SH16_EW_THREADS = 1024, SH16_EW_BLOCKS = 512;
+__device__ __forceinline__ void sh16_block_slot_max(unsigned* slot, float v) {
+    __shared__ float s_wmax[16];
+    v = sh16_wave_max(v);
+    if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0 && slot) {
+        float m = 0.f;
+        for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) m = fmaxf(m, s_wmax[w]);
+        sh16_slot_max(slot, m);
+    }
+}
+inline int sh16_ew_grid(long long n) {
+    const long long b = (n + SH16_EW_THREADS - 1) / SH16_EW_THREADS;
+    return (int)(b < SH16_EW_BLOCKS ? (b > 0 ? b : 1) : SH16_EW_BLOCKS);
+}
+
 }  // namespace chk
