@@ -374,7 +374,7 @@ std::string ShapeModel::decode(const float* hair_code, const float* face_code, f
 // =================================================================================================================
 namespace {
 // conv (no bias) + eval BN folded: w' = w * s[co], b' = shift[co]
-// sh16: stride-1 layers are packed for the f16x3 kernels instead
+// sh16: packed for the f16x3 kernels instead (stride 2: in the space-to-depth form)
 ConvLayer conv_bn(Builder& B, const std::string& conv, const std::string& bn, int cout, int cin, int ks, int stride,
                   int pad, bool sh16 = false) {
     auto w = B.vec(conv + ".weight", (size_t)cout * cin * ks * ks);
@@ -383,6 +383,7 @@ ConvLayer conv_bn(Builder& B, const std::string& conv, const std::string& bn, in
     for (int o = 0; o < cout; ++o)
         for (size_t i = 0; i < (size_t)cin * ks * ks; ++i) w[(size_t)o * cin * ks * ks + i] *= sc[o];
     if (sh16 && stride == 1) return make_conv_sh16(B, w, sh, cout, cin, ks, pad);
+    if (sh16) return make_conv_s2d(B, w, sh, cout, cin, ks);        // stride 2: space-to-depth form
     return make_conv(B, w, sh, cout, cin, ks, stride, pad);
 }
 }  // namespace
@@ -486,7 +487,7 @@ std::string BiSeNetModel::parse_sh16(const float* img, uint8_t* labels, float* l
         auto mk = [&](float* ptr) { return T{ptr, amax + ns++}; };
         const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8, h16 = H / 16, w16 = W / 16,
                   h32 = H / 32, w32 = W / 32;
-        // stride-1 conv: f16x3 kernel over the C4 input
+        // one conv on the f16x3 kernels over the C4 input (stride 2: conv_sh16.h S2D)
         auto conv = [&](const ConvLayer& L, T in, T out, int hin, int win, int act, const float* res, int in_mode, const char* what) {
             ConvParams p{};
             p.in = in.p;
@@ -508,18 +509,15 @@ std::string BiSeNetModel::parse_sh16(const float* img, uint8_t* labels, float* l
             p.in_scale_inv = 1.f / SH16_ACT_SCALE;
             p.in_amax = in.amax;
             p.in_c4 = 1;
-            ck(conv_sh16_plain_c4(p, L.KS, st), what);
-        };
-        // stride-2 conv: exact-f32 kernel (NCHW in / out) between two layout conversions; scratch in the upper half of b0
-        float* s2_in = b0 + 2 * (size_t)B * 64 * h4 * w4;
-        float* s2_out = b0 + 3 * (size_t)B * 64 * h4 * w4;
-        auto conv_s2 = [&](const ConvLayer& L, const float* in_nchw, T out, int hin, int win, int act, const char* what) {
-            ConvOpts o;
-            o.act = act;
-            o.partial = splitk_ws;
-            o.partial_cap = splitk_cap;
-            ck(run_conv(L, in_nchw, s2_out, B, hin, win, o, st), what);
-            ck(nchw_to_c4(s2_out, out.p, out.amax, B, L.Cout, (hin / 2) * (win / 2), st), "nchw -> c4");
+            if (L.stride == 2) {           // space-to-depth form: output at half the input size
+                p.H = hin / 2;
+                p.W = win / 2;
+                p.s2d_cr = L.s2d_cr;
+                p.s2d_phase0 = L.s2d_phase0;
+                ck(conv_sh16_s2d_c4(p, L.KS, st), what);
+            } else {
+                ck(conv_sh16_plain_c4(p, L.KS, st), what);
+            }
         };
         ck(stem7x7(img + (size_t)bo * 3 * H * W, stem_w, stem_b, b0, B, H, W, st), "stem");
         T x = mk(b1);
@@ -530,13 +528,10 @@ std::string BiSeNetModel::parse_sh16(const float* img, uint8_t* labels, float* l
             T t = mk(tmp);
             const int ho = hin / bb.c1.stride, wo = win / bb.c1.stride;
             const float* shortcut = in.p;
-            if (bb.c1.stride == 2) {         // layers 2-4, first block: conv1 and the 1x1 shortcut are the stride-2 convs
-                ck(c4_to_nchw(in.p, s2_in, B, bb.c1.Cin, hin * win, st), "c4 -> nchw");
-                conv_s2(bb.c1, s2_in, t, hin, win, ACT_RELU, "bb conv1 (s2)");
-                conv_s2(bb.down, s2_in, T{sc, nullptr}, hin, win, ACT_NONE, "bb down (s2)");
+            conv(bb.c1, in, t, hin, win, ACT_RELU, nullptr, IN_DIRECT, "bb conv1");
+            if (bb.has_down) {               // layers 2-4, first block: conv1 and the 1x1 shortcut are the stride-2 convs
+                conv(bb.down, in, T{sc, nullptr}, hin, win, ACT_NONE, nullptr, IN_DIRECT, "bb down");
                 shortcut = sc;
-            } else {
-                conv(bb.c1, in, t, hin, win, ACT_RELU, nullptr, IN_DIRECT, "bb conv1");
             }
             T o = mk(outp);
             conv(bb.c2, t, o, ho, wo, ACT_RELU, shortcut, IN_DIRECT, "bb conv2");

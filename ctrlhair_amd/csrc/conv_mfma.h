@@ -90,6 +90,8 @@ struct ConvParams {
                             // maximum left the window, else rewrite with the corrected scale
     int in_c4;              // set by callers of the INC4 instantiations of conv_sh16_kernel (documentation only: `in` is an f32
                             // tensor in the C4 layout [B][C/4][H][W][4], split into f16 pairs while it is staged)
+    int s2d_cr, s2d_phase0; // S2D instantiations of conv_sh16_kernel (stride-2 convs): real input channels (Cin = phases x s2d_cr)
+                            // and the first phase (0: 2x2-tap form of a k3 / k4 pad-1 kernel; 3: 1x1 stride-2 conv)
     int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over the persistent kernel)
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
     // EPI_NHWC

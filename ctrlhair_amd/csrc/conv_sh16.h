@@ -343,9 +343,17 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 // i.e. the same bytes and no separate conversion pass.  Scale: SH16_ACT_SCALE x the dynamic factor of the producer's
 // recorded maximum (p.in_amax; complete, because the producer is an earlier kernel), so the units always sit in the f16
 // window -- no second pass.  Used by the BiSeNet trunk (conv -> BN -> ReLU chains with residuals, all in C4).
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false>
+// S2D (stride-2 convs, KS = 2 or 1): the conv runs at the OUTPUT resolution over the space-to-depth view of the input.
+// With the k x k, stride 2, pad 1 kernel indexed by ky = 2 dy + py (dy in {0,1}, py in {0,1}), output pixel y reads physical
+// row 2 (y + dy) + py - 1: a 2x2-tap stride-1 conv over 4 "phase" copies of the input channels (phase = (py, px); k = 4:
+// all 16 (tap, phase) pairs carry a weight, k = 3: 9 of 16).  The view is address arithmetic in the staging: chunk ->
+// (phase, 16 real channels), unit -> physical pixel 2 (y, x) + phase - 1, zero outside the image.  KS = 1: the 1x1 stride-2
+// shortcut convs (phase (1,1) only = physical pixel 2 (y, x)).  p.Cin = phases x p.s2d_cr, p.H / p.W = output size.
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false, bool S2D = false>
 __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     static_assert(!(FUSE && INC4), "the fused second operand is an SH16 tensor");
+    static_assert(!S2D || (!FUSE && EPI == EPI_PLAIN && (KS == 2 || KS == 1)), "S2D: plain 2x2-tap / 1x1 convs only");
+    static_assert(S2D || KS != 2, "2x2 taps exist for the space-to-depth view only");
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, NLOAD = Cfg::NLOAD, HALO = Cfg::HALO;
     constexpr int NT = KS * KS;
@@ -388,7 +396,21 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     const uint4* gin = reinterpret_cast<const uint4*>(p.in);
     // physical plane size of the input: ConvTranspose2d(k3,s2,p1,op1) runs as a conv over the zero-inserted x2 view
     // (IN_UP2_NEAREST: the shape decoder's nearest x2 up-sampling, shape_branch/model.py:128, as address arithmetic)
-    const int HWi = p.in_mode != IN_DIRECT ? (p.H >> 1) * (p.W >> 1) : HW;
+    const int HWi = S2D ? 4 * HW : (p.in_mode != IN_DIRECT ? (p.H >> 1) * (p.W >> 1) : HW);
+    // S2D: validity of a patch position per phase (bit ph set = physical pixel 2 (y, x) + (ph >> 1, ph & 1) - 1 lies in the
+    // image); soff then holds the (possibly negative) offset of phase (0, 0) and is only used under a set bit
+    [[maybe_unused]] int sval[NLOAD];
+    [[maybe_unused]] const int Wp = 2 * p.W, Hp = 2 * p.H, ncr = S2D ? p.s2d_cr >> 4 : 1;
+    auto s2d_mask = [&](int y, int x, int b, int py, int px) {
+        int m = 0;
+        if (b < p.B && (KS == 1 || (py >= 1 && px >= 1)))           // KS == 2: patch row / column 0 is never addressed
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int yy = 2 * y - 1 + (ph >> 1), xx = 2 * x - 1 + (ph & 1);
+                if ((unsigned)yy < (unsigned)Hp && (unsigned)xx < (unsigned)Wp) m |= 1 << ph;
+            }
+        return m;
+    };
     // per-thread source offsets of its NLOAD patch units (chunk-invariant part), -1 = outside the image -> zeros.
     // Hoisted out of the chunk loop: the decode (3 div/mod per unit) was ~half of the kernel's VALU issue.
     int soff[NLOAD];
@@ -401,11 +423,17 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         for (int i = 0; i < NPAIR; ++i) {
             const int q = tid + i * 256;
             soff[i] = -1;
+            if constexpr (S2D) sval[i] = 0;
             if (q < 2 * PLANE) {
                 const int g = q / PLANE, rem = q % PLANE;
                 const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
                 int y = y0 + py - HALO, x = x0 + px - HALO;
                 const int b = b0 + tb;
+                if constexpr (S2D) {
+                    sval[i] = s2d_mask(y, x, b, py, px);
+                    soff[i] = (b * (p.s2d_cr >> 2) + g * 2) * HWi + (2 * y - 1) * Wp + (2 * x - 1);
+                    continue;
+                }
                 if (p.pad_mode == PAD_REFLECT) {
                     y = y < 0 ? -y : (y >= p.H ? 2 * (p.H - 1) - y : y);
                     x = x < 0 ? -x : (x >= p.W ? 2 * (p.W - 1) - x : x);
@@ -427,11 +455,17 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     for (int i = 0; i < (INC4 ? 0 : NLOAD); ++i) {
         const int u = tid + i * 256;
         soff[i] = -1;
+        if constexpr (S2D) sval[i] = 0;
         if (u < UNITS) {
             const int gh = u / PLANE, rem = u % PLANE;          // gh = group*2 + hl
             const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
             int y = y0 + py - HALO, x = x0 + px - HALO;
             const int b = b0 + tb;
+            if constexpr (S2D) {
+                sval[i] = (TERMS != 3 && (gh & 1)) ? 0 : s2d_mask(y, x, b, py, px);
+                soff[i] = ((b * (p.s2d_cr >> 3) + (gh >> 1)) * 2 + (gh & 1)) * HWi + (2 * y - 1) * Wp + (2 * x - 1);
+                continue;
+            }
             if (p.pad_mode == PAD_REFLECT) {      // nn.ReflectionPad2d (Zencoder, architecture.py:174)
                 y = y < 0 ? -y : (y >= p.H ? 2 * (p.H - 1) - y : y);
                 x = x < 0 ? -x : (x >= p.W ? 2 * (p.W - 1) - x : x);
@@ -468,11 +502,19 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     auto stage = [&](int chunk, int buf) {
         if constexpr (INC4) {
             float4 sa[NPAIR], sc[NPAIR];
-            const float4* src = reinterpret_cast<const float4*>(p.in) + (long long)chunk * 4 * HWi;
+            int phase = 0, rc = chunk;
+            if constexpr (S2D) {
+                phase = chunk / ncr;
+                rc = chunk - phase * ncr;
+                phase += p.s2d_phase0;
+            }
+            const float4* src = reinterpret_cast<const float4*>(p.in) + (long long)rc * 4 * HWi + (S2D ? (phase >> 1) * Wp + (phase & 1) : 0);
 #pragma unroll
             for (int i = 0; i < NPAIR; ++i) {
-                sa[i] = soff[i] >= 0 ? src[soff[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
-                sc[i] = soff[i] >= 0 ? src[soff[i] + HWi] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bool ok = soff[i] >= 0;
+                if constexpr (S2D) ok = (sval[i] >> phase) & 1;
+                sa[i] = ok ? src[soff[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+                sc[i] = ok ? src[soff[i] + HWi] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             uint4* dst = smem_u + buf * UNITS;
 #pragma unroll
@@ -498,9 +540,16 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         // No scheduling fence in here on purpose: the compiler issues these loads early and sinks the LDS writes
         // below the chunk's MFMAs as far as registers allow, which is what overlaps staging with compute.
         uint4 stg[NLOAD];
-        const uint4* src = gin + (long long)chunk * 4 * HWi;      // 2 groups x (hi, lo) planes per chunk
+        if constexpr (S2D) {
+            const int ph0 = chunk / ncr, phase = ph0 + p.s2d_phase0;
+            const uint4* src = gin + (long long)(chunk - ph0 * ncr) * 4 * HWi + (phase >> 1) * Wp + (phase & 1);
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NLOAD; ++i) stg[i] = ((sval[i] >> phase) & 1) ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+        } else {
+            const uint4* src = gin + (long long)chunk * 4 * HWi;      // 2 groups x (hi, lo) planes per chunk
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) stg[i] = soff[i] >= 0 ? src[soff[i]] : make_uint4(0, 0, 0, 0);
+        }
         if constexpr (FUSE) {
             if (mul1 != 1.f) rescale(stg, mul1);
         }
@@ -555,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a_nxt[q] = Ac[((t + 1) * 4 + q) * 64];
             }
-            const int koff = (t / KS) * PW + (t % KS);
+            const int koff = KS == 2 ? (1 + t / 2) * PW + (1 + t % 2) : (t / KS) * PW + (t % KS);   // KS 2: window (y, x)..(y+1, x+1)
             asm volatile("" ::: "memory");          // no cross-tap CSE of LDS reads
             uint4 bh[4], bl[4];
 #pragma unroll
@@ -1071,10 +1120,10 @@ __global__ __launch_bounds__(1024) void sh16_splitk_reduce_kernel(const ConvPara
     if (p.out_amax) sh16_block_slot_max(p.out_amax, amax * SH16_ACT_SCALE);       // uniform branch: every thread gets here
 }
 
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false, bool S2D = false>
 hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
-    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE, INC4>;
+    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE, INC4, S2D>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1163,6 +1212,17 @@ hipError_t dispatch_sh16_plain_c4(const ConvParams& p, hipStream_t s) {
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, 3, false, true>(p, p.Mrows, s);
 }
 hipError_t conv_sh16_plain_c4(const ConvParams& p, int KS, hipStream_t s);   // f32 C4 in -> f32 C4 out (KS 1 or 3)
+
+// stride-2 convs over the space-to-depth view (conv_sh16_kernel<..., S2D = true>); KS = 2 (k = 3 / 4 kernels) or 1
+template <int KS, bool INC4>
+hipError_t dispatch_sh16_s2d(const ConvParams& p, hipStream_t s) {
+    if (p.in2 || p.s2d_cr % 16 != 0 || p.Cin % p.s2d_cr != 0) return hipErrorInvalidValue;
+    if (p.W >= 32) return launch_sh16<KS, 32, 16, 1, EPI_PLAIN, 3, false, INC4, true>(p, p.Mrows, s);
+    if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN, 3, false, INC4, true>(p, p.Mrows, s);
+    return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, 3, false, INC4, true>(p, p.Mrows, s);
+}
+hipError_t conv_sh16_s2d(const ConvParams& p, int KS, hipStream_t s);        // SH16 in
+hipError_t conv_sh16_s2d_c4(const ConvParams& p, int KS, hipStream_t s);     // f32 C4 in
 
 // p.terms == 1 / 2 selects the single-term instantiations (operands rounded to f16 / bf16, f32 accumulate: BASELINE configs[4])
 hipError_t conv_sh16_plain(const ConvParams& p, int KS, hipStream_t s);   // SH16 in -> f32 C4 out

@@ -42,8 +42,6 @@ hipError_t conv3x3_c3_reflect(const float* in, const float* w, const float* bias
 hipError_t bilinear_argmax(const float* lg, uint8_t* out, float* logits_out, const uint8_t* remap, int B, int h, int w,
                            int H, int W, hipStream_t s, int c4 = 0);
 // C4-layout variants (f16x3 BiSeNet trunk); `amax`: device slot receiving max |out| * SH16_ACT_SCALE, or null
-hipError_t c4_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
-hipError_t nchw_to_c4(const float* in, float* out, unsigned* amax, int B, int C, int HW, hipStream_t s);
 hipError_t maxpool3x3s2_c4(const float* in_nchw, float* out_c4, unsigned* amax, int B, int C, int H, int W, hipStream_t s);
 hipError_t global_avg_pool_c4(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 hipError_t chan_affine_c4(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,

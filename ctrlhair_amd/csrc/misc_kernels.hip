@@ -574,43 +574,6 @@ hipError_t chan_affine(const float* in, const float* sc, float sc_add, const flo
 __device__ __forceinline__ void amax_commit(unsigned* slot, float amax) {      // whole block; see sh16_block_slot_max
     sh16_block_slot_max(slot, amax * SH16_ACT_SCALE);
 }
-// layout conversions around the exact-f32 stride-2 convs (NCHW kernels) of the otherwise-C4 trunk
-__global__ void c4_to_nchw_kernel(const float4* __restrict__ in, float* __restrict__ out, long long groups, int HW) {
-    const long long n = groups * HW;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const long long g = i / HW;
-        const int px = (int)(i - g * HW);
-        const float4 v = in[i];
-        float* o = out + g * 4 * HW + px;
-        o[0] = v.x; o[HW] = v.y; o[2LL * HW] = v.z; o[3LL * HW] = v.w;
-    }
-}
-hipError_t c4_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
-    const long long groups = (long long)B * (C >> 2), n = groups * HW;
-    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(c4_to_nchw_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(in), out, groups, HW);
-    return hipGetLastError();
-}
-__global__ __launch_bounds__(1024) void nchw_to_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, long long groups,
-                                  int HW) {
-    const long long n = groups * HW;
-    float amax = 0.f;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const long long g = i / HW;
-        const int px = (int)(i - g * HW);
-        const float* q = in + g * 4 * HW + px;
-        const float4 v = make_float4(q[0], q[HW], q[2LL * HW], q[3LL * HW]);
-        out[i] = v;
-        amax = fmaxf(fmaxf(amax, fabsf(v.x)), fabsf(v.y));
-        amax = fmaxf(fmaxf(amax, fabsf(v.z)), fabsf(v.w));
-    }
-    amax_commit(amax_slot, amax);
-}
-hipError_t nchw_to_c4(const float* in, float* out, unsigned* amax, int B, int C, int HW, hipStream_t s) {
-    const long long groups = (long long)B * (C >> 2), n = groups * HW;
-    hipLaunchKernelGGL(nchw_to_c4_kernel, dim3(sh16_ew_grid(n)), dim3(SH16_EW_THREADS), 0, s, in, reinterpret_cast<float4*>(out), amax, groups, HW);
-    return hipGetLastError();
-}
 // nn.MaxPool2d(3, 2, 1) (resnet.py:75): NCHW in -> C4 out
 __global__ __launch_bounds__(1024) void maxpool3x3s2_c4_kernel(const float* __restrict__ in, float4* __restrict__ out, unsigned* amax_slot, int B, int C,
                                        int H, int W, int Ho, int Wo) {

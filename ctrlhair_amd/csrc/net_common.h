@@ -172,8 +172,9 @@ struct ConvLayer {
     float* wpk = nullptr;
     float* bias = nullptr;
     int Cout = 0, Cin = 0, KS = 0, stride = 1, pad = 0;
-    float* sh_wpk = nullptr;       // f16x3 packing (make_conv_sh16): split-operand A fragments + per-row inverse scales
+    float* sh_wpk = nullptr;       // f16x3 packing (make_conv_sh16 / make_conv_s2d): split-operand A fragments + per-row inverse scales
     float* sh_wscale = nullptr;
+    int s2d_cr = 0, s2d_phase0 = 0; // make_conv_s2d: real (padded) input channels and first phase of the space-to-depth form
 };
 
 // w: [Cout][Cin][KS][KS] (already folded: BN / spectral norm / flips), bias may be empty
@@ -207,6 +208,40 @@ inline ConvLayer make_conv_sh16(Builder& B, const std::vector<float>& w, const s
     auto getw = [&](int row, int ci, int t) { return row < cout ? wp[((size_t)row * cin + ci) * ks * ks + t] : 0.f; };
     const auto kexp = sh16_row_exponents(L.Cout, cin, ks, getw);
     L.sh_wpk = B.upload(pack_A_sh16(L.Cout, cin, ks, getw, kexp));
+    L.sh_wscale = B.upload(sh16_wscale(kexp));
+    if (!bias.empty()) {
+        std::vector<float> b(L.Cout, 0.f);
+        std::copy(bias.begin(), bias.end(), b.begin());
+        L.bias = B.upload(b);
+    }
+    return L;
+}
+
+// stride-2, pad-(ks > 1) conv in the space-to-depth form of conv_sh16_kernel<S2D> (conv_sh16.h): a 2x2-tap (ks 3 / 4) or
+// 1x1 (ks 1) stride-1 conv at the output resolution over `phases` copies of the input channels.  Virtual channel
+// vc = phase * cr + c; tap (dy, dx) of phase (py, px) carries the original weight at (ky, kx) = (2 dy + py, 2 dx + px)
+// (zero where that index leaves the ks x ks kernel).  cr = cin rounded up to a multiple of 16 (padding channels: zeros).
+// L.Cin = phases * cr, L.KS = 2 or 1, L.stride = 2 (marker), L.Cout padded to a multiple of 4.
+inline ConvLayer make_conv_s2d(Builder& B, const std::vector<float>& w, const std::vector<float>& bias, int cout, int cin, int ks) {
+    ConvLayer L;
+    const int cr = (cin + 15) & ~15, phases = ks == 1 ? 1 : 4;
+    L.Cout = (cout + 3) & ~3;
+    L.Cin = phases * cr;
+    L.KS = ks == 1 ? 1 : 2;
+    L.stride = 2;
+    L.pad = ks == 1 ? 0 : 1;
+    L.s2d_cr = cr;
+    L.s2d_phase0 = ks == 1 ? 3 : 0;
+    const float* wp = w.data();
+    auto getw = [&](int row, int vc, int t) {
+        const int c = vc % cr;
+        if (row >= cout || c >= cin) return 0.f;
+        if (ks == 1) return wp[(size_t)row * cin + c];
+        const int ph = vc / cr, ky = 2 * (t / 2) + (ph >> 1), kx = 2 * (t % 2) + (ph & 1);
+        return (ky < ks && kx < ks) ? wp[(((size_t)row * cin + c) * ks + ky) * ks + kx] : 0.f;
+    };
+    const auto kexp = sh16_row_exponents(L.Cout, L.Cin, L.KS, getw);
+    L.sh_wpk = B.upload(pack_A_sh16(L.Cout, L.Cin, L.KS, getw, kexp));
     L.sh_wscale = B.upload(sh16_wscale(kexp));
     if (!bias.empty()) {
         std::vector<float> b(L.Cout, 0.f);
