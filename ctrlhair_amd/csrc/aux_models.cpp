@@ -150,10 +150,20 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
         for (int l = 0; l < 7; ++l) {
             const int cout = std::min(2048, 32 << l);
             const std::string p = std::string(side[w]) + "_encoder.layers." + std::to_string(l);
-            enc[w][l] = make_conv(B, B.vec(p + ".conv.weight", (size_t)cout * cin * 16), B.vec(p + ".conv.bias", cout), cout,
-                                  cin, 4, 2, 1);
-            enc_ln[w][l].gamma = B.upload(B.vec(p + ".norm.gamma", cout));
-            enc_ln[w][l].beta = B.upload(B.vec(p + ".norm.beta", cout));
+            const auto gam = B.vec(p + ".norm.gamma", cout), bet = B.vec(p + ".norm.beta", cout);
+            if (use_sh16 && l < 4) {
+                enc_s2d[w][l] = make_conv_s2d(B, B.vec(p + ".conv.weight", (size_t)cout * cin * 16), B.vec(p + ".conv.bias", cout),
+                                              cout, cin, 4);
+                float gm = 0.f, bm = 0.f;
+                for (int c = 0; c < cout; ++c) { gm = std::max(gm, std::fabs(gam[c])); bm = std::max(bm, std::fabs(bet[c])); }
+                const int sz = S >> (l + 1);          // output side of layer l; |LN output| <= sqrt(N) max|gamma| + max|beta|
+                enc_ln_scale[w][l] = sh16_scale_for_bound(std::sqrt((float)cout * sz * sz) * gm + bm);
+            } else {
+                enc[w][l] = make_conv(B, B.vec(p + ".conv.weight", (size_t)cout * cin * 16), B.vec(p + ".conv.bias", cout), cout,
+                                      cin, 4, 2, 1);
+            }
+            enc_ln[w][l].gamma = B.upload(gam);
+            enc_ln[w][l].beta = B.upload(bet);
             cin = cout;
         }
         const int odim = w == 0 ? HAIR_DIM : FACE_DIM;
@@ -218,8 +228,8 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
         pos = B.upload(pe);
     }
     const size_t HW = (size_t)S * S;
-    in_hair = B.falloc(mb * 41 * HW);
-    in_face = B.falloc(mb * 58 * HW);
+    in_hair = B.falloc(mb * 48 * HW);      // f16x3 path: SH16 with the channels padded to 48 / 64 (4 bytes per element either way)
+    in_face = B.falloc(mb * 64 * HW);
     bufa = B.falloc((size_t)mb * (8192 + 19 * HW));   // decoder input vector + temporary logits
     bufb = B.falloc(mb * 32 * HW);                      // ping-pong activations (largest: 32 ch at 256^2)
     bufc = B.falloc(mb * 32 * HW);
@@ -240,7 +250,41 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
     const float* x = in;
     float* bufs[2] = {bufb, bufc};
     int size = S;
-    for (int l = 0; l < 7; ++l) {
+    int l0 = 0;
+    if (use_sh16) {
+        // layers 0..3: SH16 -> f16x3 stride-2 conv (space-to-depth form) -> C4 -> LayerNorm + lrelu -> SH16 (layer 3: NCHW f32)
+        float s_in = ENC_IN_SCALE;
+        for (int l = 0; l < 4; ++l) {
+            const ConvLayer& L = enc_s2d[w][l];
+            ConvParams p{};
+            p.in = x;
+            p.wpk = L.sh_wpk;
+            p.wscale = L.sh_wscale;
+            p.in_scale_inv = 1.f / s_in;
+            p.out = bufc;
+            p.B = B;
+            p.Cin = L.Cin;
+            p.s2d_cr = L.s2d_cr;
+            p.s2d_phase0 = L.s2d_phase0;
+            size /= 2;
+            p.H = size;
+            p.W = size;
+            p.Mrows = L.Cout;
+            p.bias = L.bias;
+            p.act = ACT_NONE;
+            p.partial = splitk_ws;
+            p.partial_cap = splitk_cap;
+            ck(conv_sh16_s2d(p, L.KS, st), "shape enc conv (f16x3)");
+            ck(layernorm_act_conv(bufc, 1, bufb, l < 3 ? 1 : 0, enc_ln_scale[w][l], enc_ln[w][l].gamma, enc_ln[w][l].beta, lnpart, B,
+                                  L.Cout, size * size, 1e-5f, ACT_LRELU, st), "shape enc ln");
+            x = bufb;
+            s_in = enc_ln_scale[w][l];
+        }
+        l0 = 4;
+        bufs[0] = bufc;              // layer 4 reads bufb
+        bufs[1] = bufb;
+    }
+    for (int l = l0; l < 7; ++l) {
         float* y = bufs[l & 1];
         ConvOpts eo;
         eo.partial = splitk_ws;
@@ -262,7 +306,8 @@ std::string ShapeModel::encode(const uint8_t* labels, float* hair_code, float* f
     for (int bo = 0; bo < Btot; bo += max_batch) {
         const int B = std::min(max_batch, Btot - bo);
         Ck ck;
-        ck(shape_inputs(labels + (size_t)bo * S * S, pos, in_hair, in_face, B, S * S, st), "shape inputs");
+        if (use_sh16) ck(shape_inputs_sh16(labels + (size_t)bo * S * S, pos, in_hair, in_face, B, S * S, ENC_IN_SCALE, st), "shape inputs");
+        else ck(shape_inputs(labels + (size_t)bo * S * S, pos, in_hair, in_face, B, S * S, st), "shape inputs");
         if (!ck.err.empty()) return ck.err;
         std::string e;
         if (hair_code) e = run_encoder(0, in_hair, hair_code + (size_t)bo * HAIR_DIM, B, st);

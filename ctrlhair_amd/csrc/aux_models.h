@@ -44,6 +44,11 @@ struct ShapeModel {
     bool use_sh16 = true;
     float *dec_sh[2][7] = {}, *dec_ws[2][7] = {};
     float dec_ln_scale[2][7] = {};
+    // encoder layers 0..3 (k4 s2 convs at 128^2 .. 16^2) in the space-to-depth form of the f16x3 kernels (conv_sh16.h S2D):
+    // SH16 inputs (scale 2^14: one-hot and sin / cos channels), LayerNorm outputs SH16 with their static scales
+    ConvLayer enc_s2d[2][4];
+    float enc_ln_scale[2][4] = {};
+    static constexpr float ENC_IN_SCALE = 16384.f;
     float* pos = nullptr;      // [40][S*S]
     float *in_hair = nullptr, *in_face = nullptr, *bufa = nullptr, *bufb = nullptr, *bufc = nullptr, *lnpart = nullptr,
           *codecat = nullptr, *splitk_ws = nullptr;

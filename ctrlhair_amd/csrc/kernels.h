@@ -49,6 +49,8 @@ hipError_t chan_affine_c4(const float* in, const float* sc, float sc_add, const 
 hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW, hipStream_t s);
 hipError_t shape_inputs(const uint8_t* lab, const float* pos, float* hair_in, float* face_in, int B, int HW,
                         hipStream_t s);
+hipError_t shape_inputs_sh16(const uint8_t* lab, const float* pos, void* hair_in, void* face_in, int B, int HW, float scale,
+                             hipStream_t s);      // SH16, 48 / 64 channels
 hipError_t linear(const float* x, const float* W, const float* bias, const float* scale, const float* shift, float* out,
                   int B, int K, int O, int ldx, int ldo, int act, hipStream_t s);
 hipError_t subspace_add(float* h, const float* z, int zld, const float* U, const float* L, const float* mu, int B, int D,

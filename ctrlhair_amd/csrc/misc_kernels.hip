@@ -5,6 +5,8 @@
 
 namespace chk {
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -850,6 +852,59 @@ __global__ void shape_inputs_kernel(const uint8_t* __restrict__ lab, const float
             f[(long long)(18 + k) * HW] = v;
         }
     }
+}
+// The same inputs as SH16 tensors (f16x3 shape encoder): channels padded to 48 / 64 with zeros, scale 2^14 (|value| <= 1)
+__global__ void shape_inputs_sh16_kernel(const uint8_t* __restrict__ lab, const float* __restrict__ pos,
+                                         uint4* __restrict__ hair_in, uint4* __restrict__ face_in, int B, int HW, float scale) {
+    sh16_mode_on();
+    const long long n = (long long)B * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW), p = (int)(i % HW);
+        const int l = lab[i];
+        float pe[40];
+#pragma unroll
+        for (int k = 0; k < 40; ++k) pe[k] = pos[(long long)k * HW + p];
+        auto put = [&](uint4* base, int G, int g, const float (&v)[8]) {
+            half8 h, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 he, le;
+                sh16_split(v[e], scale, he, le);
+                h[e] = he;
+                lo[e] = le;
+            }
+            base[(((long long)b * G + g) * 2 + 0) * HW + p] = __builtin_bit_cast(uint4, h);
+            base[(((long long)b * G + g) * 2 + 1) * HW + p] = __builtin_bit_cast(uint4, lo);
+        };
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {                   // hair: [one-hot of class 13][40 positional][7 zeros]
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = g * 8 + e;
+                v[e] = c == 0 ? (l == 13 ? 1.f : 0.f) : (c <= 40 ? pe[c - 1] : 0.f);
+            }
+            put(hair_in, 6, g, v);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                   // face: [18 one-hot][40 positional][6 zeros]
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = g * 8 + e;
+                v[e] = c < 18 ? ((l == (c < 13 ? c : c + 1)) ? 1.f : 0.f) : (c < 58 ? pe[c - 18] : 0.f);
+            }
+            put(face_in, 8, g, v);
+        }
+    }
+}
+hipError_t shape_inputs_sh16(const uint8_t* lab, const float* pos, void* hair_in, void* face_in, int B, int HW, float scale,
+                             hipStream_t s) {
+    const long long n = (long long)B * HW;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(shape_inputs_sh16_kernel, dim3(grid), dim3(256), 0, s, lab, pos, static_cast<uint4*>(hair_in),
+                       static_cast<uint4*>(face_in), B, HW, scale);
+    return hipGetLastError();
 }
 hipError_t shape_inputs(const uint8_t* lab, const float* pos, float* hair_in, float* face_in, int B, int HW,
                         hipStream_t s) {
