@@ -23,8 +23,12 @@ hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s);
 // misc_kernels.hip
 // instance-norm outputs are bounded by sqrt(HW): their SH16 scale is instnorm_sh16_scale(HW), no saturation possible
 float instnorm_sh16_scale(int HW);
-hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16 = nullptr, int C = 0);
-hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s);
+// scratch (optional, >= 64 KiB of floats): enables the sliced two-kernel form for tensors with few (sample, 8-channel group)
+// pairs and large planes, where one block per pair would leave most CUs idle
+hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16 = nullptr, int C = 0,
+                        float* scratch = nullptr);
+hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s,
+                               float* scratch = nullptr);
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
                          int act, hipStream_t s);
 // LayerNorm + activation with layout conversion: in NCHW / C4 -> out SH16 (scaled) / NCHW f32 (shape decoder, f16x3 convs)

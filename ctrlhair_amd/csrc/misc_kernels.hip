@@ -228,19 +228,139 @@ __global__ __launch_bounds__(1024) void instnorm_c4_sh16_kernel(const float4* __
     }
 }
 
+// Few (sample, channel group) pairs and large planes (Zencoder, 32 / 64 channels at 512^2 / 256^2): one block per pair leaves
+// most CUs idle, so each pair's pixels are cut into NS slices -- kernel 1: per-slice (mean, M2) of the 8 channels (two-pass
+// inside the slice); kernel 2: every block merges the NS partials of its pair (Chan et al., fixed order) and normalises,
+// activates and splits its own slice.  stats: [pairs][NS][8][2] floats.
+template <bool IN_C4>
+__device__ __forceinline__ void instnorm_load8(const float* __restrict__ x, long long b, int g, int C, int HW, int i, float (&v)[8]) {
+    if (IN_C4) {
+        const float4* p0 = reinterpret_cast<const float4*>(x) + (b * (C >> 2) + g * 2) * HW;
+        const float4 a = p0[i], c = p0[HW + i];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+        const float* base = x + (b * C + g * 8) * HW + i;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = base[(long long)c * HW];
+    }
+}
+template <bool IN_C4>
+__global__ __launch_bounds__(1024) void instnorm_slice_stats_kernel(const float* __restrict__ x, int HW, int C, int per,
+                                                                    float* __restrict__ stats) {
+    __shared__ float red[16];
+    const int G = C >> 3, b = blockIdx.x / G, g = blockIdx.x % G, k = blockIdx.y, NS = gridDim.y;
+    const int lo = k * per, hi = lo + per < HW ? lo + per : HW;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+        float v[8];
+        instnorm_load8<IN_C4>(x, b, g, C, HW, i, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+    const float cnt = (float)(hi - lo);
+    float mean[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mean[e] = block_sum1024(s[e], red) / cnt;
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+        float v[8];
+        instnorm_load8<IN_C4>(x, b, g, C, HW, i, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = v[e] - mean[e];
+            q[e] += d * d;
+        }
+    }
+    float* o = stats + ((long long)blockIdx.x * NS + k) * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float m2 = block_sum1024(q[e], red);
+        if (threadIdx.x == 0) {
+            o[e * 2] = mean[e];
+            o[e * 2 + 1] = m2;
+        }
+    }
+}
+template <bool IN_C4>
+__global__ __launch_bounds__(1024) void instnorm_slice_apply_kernel(const float* __restrict__ x, int HW, int C, int per, float eps,
+                                                                    int act, const float* __restrict__ stats,
+                                                                    uint4* __restrict__ sh16, float scale) {
+    sh16_mode_on();
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    __shared__ float mean_s[8], rstd_s[8];
+    const int G = C >> 3, b = blockIdx.x / G, g = blockIdx.x % G, k = blockIdx.y, NS = gridDim.y;
+    if (threadIdx.x < 8) {
+        const int e = threadIdx.x;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int j = 0; j < NS; ++j) {
+            const int lo = j * per, hi = lo + per < HW ? lo + per : HW;
+            const float nb = (float)(hi - lo);
+            const float* o = stats + ((long long)blockIdx.x * NS + j) * 16 + e * 2;
+            const float nn = n + nb, d = o[0] - mean;
+            mean += d * nb / nn;
+            m2 += o[1] + d * d * n * nb / nn;
+            n = nn;
+        }
+        mean_s[e] = mean;
+        rstd_s[e] = 1.f / sqrtf(m2 / HW + eps);          // biased variance (nn.InstanceNorm2d)
+    }
+    __syncthreads();
+    const int lo = k * per, hi = lo + per < HW ? lo + per : HW;
+    uint4* oh = sh16 + ((long long)b * G + g) * 2 * HW;
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+        float v[8];
+        instnorm_load8<IN_C4>(x, b, g, C, HW, i, v);
+        half8v vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float o = act_fn((v[e] - mean_s[e]) * rstd_s[e], act);
+            _Float16 h, l;
+            sh16_split(o, scale, h, l);
+            vh[e] = h;
+            vl[e] = l;
+        }
+        oh[i] = __builtin_bit_cast(uint4, vh);
+        oh[HW + i] = __builtin_bit_cast(uint4, vl);
+    }
+}
+// returns true (and launches) when the sliced form applies: scratch given, few pairs, large planes
+static bool instnorm_sliced(const float* x, bool in_c4, int B, int C, int HW, float eps, int act, void* sh16, float* scratch,
+                            hipStream_t s) {
+    const int pairs = B * (C >> 3);
+    if (!scratch || pairs >= 128 || HW < 16384) return false;
+    int NS = (512 + pairs - 1) / pairs;
+    if (NS > HW / 4096) NS = HW / 4096;
+    if (NS > 64) NS = 64;
+    const int per = (HW + NS - 1) / NS;
+    const float sc = instnorm_sh16_scale(HW);
+    if (in_c4) {
+        hipLaunchKernelGGL(instnorm_slice_stats_kernel<true>, dim3(pairs, NS), dim3(1024), 0, s, x, HW, C, per, scratch);
+        hipLaunchKernelGGL(instnorm_slice_apply_kernel<true>, dim3(pairs, NS), dim3(1024), 0, s, x, HW, C, per, eps, act, scratch,
+                           static_cast<uint4*>(sh16), sc);
+    } else {
+        hipLaunchKernelGGL(instnorm_slice_stats_kernel<false>, dim3(pairs, NS), dim3(1024), 0, s, x, HW, C, per, scratch);
+        hipLaunchKernelGGL(instnorm_slice_apply_kernel<false>, dim3(pairs, NS), dim3(1024), 0, s, x, HW, C, per, eps, act, scratch,
+                           static_cast<uint4*>(sh16), sc);
+    }
+    return true;
+}
+
 // |(x - mean) / sqrt(var + eps)| <= sqrt(HW - 1) for any plane, and the activations used here (none / leaky / relu) do not
 // increase magnitudes: the scale below can never saturate
 float instnorm_sh16_scale(int HW) { return sh16_scale_for_bound(sqrtf((float)HW)); }
 
-hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s) {
+hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s,
+                               float* scratch) {
     if (C & 7) return hipErrorInvalidValue;
+    if (instnorm_sliced(x_c4, true, B, C, HW, eps, act, sh16, scratch, s)) return hipGetLastError();
     hipLaunchKernelGGL(instnorm_c4_sh16_kernel, dim3(B * (C >> 3)), dim3(1024), 0, s, reinterpret_cast<const float4*>(x_c4), HW,
                        eps, act, static_cast<uint4*>(sh16), C, instnorm_sh16_scale(HW));
     return hipGetLastError();
 }
 
-hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16, int C) {
+hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16, int C, float* scratch) {
     const float sc = instnorm_sh16_scale(HW);
+    if (sh16 && (C & 7) == 0 && instnorm_sliced(x, false, planes / C, C, HW, eps, act, sh16, scratch, s)) return hipGetLastError();
     if (sh16 && (C & 7) == 0 && (HW & 3) == 0 && HW >= 4096) {
         hipLaunchKernelGGL(instnorm_act_sh16_kernel, dim3(planes / 8), dim3(1024), 0, s, x, HW, eps, act, static_cast<uint4*>(sh16), C, sc);
         return hipGetLastError();
@@ -259,18 +379,27 @@ hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStr
 // normalises its slice.  part: [B][nblk][3].
 __global__ __launch_bounds__(256) void ln_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                          long long N, int nblk) {
+    // N % 4 == 0 and `per` is a multiple of 4: float4 loads, several in flight per thread (the scalar one-load-per-iteration
+    // version was latency bound: ~20 us for a 16k-element slice); the second pass re-reads the slice from L1 / L2
     __shared__ float red[4];
     const int b = blockIdx.y, k = blockIdx.x;
-    const long long per = (N + nblk - 1) / nblk, lo = k * per, hi = (lo + per < N) ? lo + per : N;
-    const float* p = x + (long long)b * N;
+    const long long per = (((N + nblk - 1) / nblk) + 3) & ~3LL, lo = k * per, hi = (lo + per < N) ? lo + per : N;
+    const float4* p4 = reinterpret_cast<const float4*>(x + (long long)b * N);
+    const long long lo4 = lo >> 2, hi4 = hi >> 2;
     float s = 0.f;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+#pragma unroll 4
+    for (long long i = lo4 + threadIdx.x; i < hi4; i += 256) {
+        const float4 v = p4[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
     const float cnt = (float)(hi > lo ? hi - lo : 0);
     const float mean = cnt > 0 ? block_sum(s, red) / cnt : 0.f;
     float q = 0.f;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const float d = p[i] - mean;
-        q += d * d;
+#pragma unroll 4
+    for (long long i = lo4 + threadIdx.x; i < hi4; i += 256) {
+        const float4 v = p4[i];
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
     const float m2 = block_sum(q, red);
     if (threadIdx.x == 0) {
@@ -386,8 +515,8 @@ __global__ __launch_bounds__(256) void ln_apply_conv_kernel(const float* __restr
 hipError_t layernorm_act_conv(const float* x, int in_c4, void* out, int out_sh16, float out_scale, const float* gamma,
                               const float* beta, float* part, int B, int C, int HW, float eps, int act, hipStream_t s) {
     if (C & 7) return hipErrorInvalidValue;
-    const long long N = (long long)C * HW;
-    int nblk = (int)((N + 16383) / 16384);
+    const long long N = (long long)C * HW;      // a multiple of 8
+    int nblk = (int)((N + 4095) / 4096);
     if (nblk > 128) nblk = 128;
     if (nblk < 1) nblk = 1;
     hipLaunchKernelGGL(ln_partial_kernel, dim3(nblk, B), dim3(256), 0, s, x, part, N, nblk);
@@ -406,7 +535,8 @@ hipError_t layernorm_act_conv(const float* x, int in_c4, void* out, int out_sh16
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,
                          int act, hipStream_t s) {
     const long long N = (long long)C * HW;
-    int nblk = (int)((N + 16383) / 16384);
+    if (N & 3) return hipErrorInvalidValue;      // ln_partial_kernel reads float4
+    int nblk = (int)((N + 4095) / 4096);
     if (nblk > 128) nblk = 128;
     if (nblk < 1) nblk = 1;
     hipLaunchKernelGGL(ln_partial_kernel, dim3(nblk, B), dim3(256), 0, s, x, part, N, nblk);

@@ -331,6 +331,9 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             const auto k10 = sh16_row_exponents(256, 128, 3, g10);
             z10_sh = B.upload(pack_A_sh16(256, 128, 3, g10, k10));
             z10_ws = B.upload(sh16_wscale(k10));
+            // and the two stride-2 convs (space-to-depth form)
+            z4_s2d = make_conv_s2d(B, B.vec("Zencoder.model.4.weight", (size_t)64 * 32 * 9), B.vec("Zencoder.model.4.bias", 64), 64, 32, 3);
+            z7_s2d = make_conv_s2d(B, B.vec("Zencoder.model.7.weight", (size_t)128 * 64 * 9), B.vec("Zencoder.model.7.bias", 128), 128, 64, 3);
         }
         if (!B.err.empty()) return B.err;
         has_zencoder = true;
@@ -798,14 +801,41 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         last.act = ACT_TANH;
         const int h2 = S / 2, h4 = S / 4;
         ck(conv3x3_c3_reflect(x, z1_w, z1.bias, hs, B, 32, S, S, st), "zenc conv1");
-        ck(instnorm_act(hs, B * 32, S * S, 1e-5f, ACT_LRELU, st), "zenc in1");
-        ck(run_conv(z4, hs, dx, B, S, S, zero, st), "zenc conv2");
-        ck(instnorm_act(dx, B * 64, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in2");
-        ck(run_conv(z7, dx, h1, B, h2, h2, zero, st), "zenc conv3");
-        if (use_sh16 && h4 * h4 >= 4096) {
-            // InstanceNorm + lrelu -> SH16 -> ConvTranspose as an f16x3 conv over the zero-inserted view -> C4 ->
-            // InstanceNorm + lrelu -> SH16 -> f16x3 conv (reflection pad, tanh) -> C4
-            ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st, dx, 128), "zenc in3");
+        const bool f16path = use_sh16 && h4 * h4 >= 4096;
+        if (f16path) {
+            // every conv after the stem on the f16x3 kernels: InstanceNorm + lrelu -> SH16 -> stride-2 conv (space-to-depth
+            // form) -> C4, twice; then the ConvTranspose (f16x3 conv over the zero-inserted view) and the reflection-padded
+            // 3x3 conv with tanh.  Instance-norm outputs are bounded by sqrt(HW): static scales (instnorm_sh16_scale).
+            auto s2d = [&](const ConvLayer& L, const float* in, float* out, int hin, const char* what) {
+                ConvParams q{};
+                q.in = in;
+                q.wpk = L.sh_wpk;
+                q.wscale = L.sh_wscale;
+                q.in_scale_inv = 1.f / instnorm_sh16_scale(hin * hin);
+                q.out = out;
+                q.B = B;
+                q.Cin = L.Cin;
+                q.s2d_cr = L.s2d_cr;
+                q.s2d_phase0 = L.s2d_phase0;
+                q.H = hin / 2;
+                q.W = hin / 2;
+                q.Mrows = L.Cout;
+                q.bias = L.bias;
+                q.act = ACT_NONE;
+                ck(conv_sh16_s2d(q, L.KS, st), what);
+            };
+            ck(instnorm_act(hs, B * 32, S * S, 1e-5f, ACT_LRELU, st, h0, 32, splitk_ws), "zenc in1");
+            s2d(z4_s2d, h0, dx, S, "zenc conv2 (f16x3)");
+            ck(instnorm_c4_to_sh16(dx, B, 64, h2 * h2, 1e-5f, ACT_LRELU, h1, st, splitk_ws), "zenc in2");
+            s2d(z7_s2d, h1, hs, h2, "zenc conv3 (f16x3)");
+            ck(instnorm_c4_to_sh16(hs, B, 128, h4 * h4, 1e-5f, ACT_LRELU, dx, st, splitk_ws), "zenc in3");
+        } else {
+            ck(instnorm_act(hs, B * 32, S * S, 1e-5f, ACT_LRELU, st), "zenc in1");
+            ck(run_conv(z4, hs, dx, B, S, S, zero, st), "zenc conv2");
+            ck(instnorm_act(dx, B * 64, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in2");
+            ck(run_conv(z7, dx, h1, B, h2, h2, zero, st), "zenc conv3");
+        }
+        if (f16path) {
             ConvParams t{};
             t.in = dx;
             t.wpk = z10_sh;

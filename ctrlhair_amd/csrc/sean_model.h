@@ -66,6 +66,7 @@ struct SeanModel {
     ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
     float *z14_sh = nullptr, *z10_sh = nullptr;        // z14 / the ConvTranspose packed for the f16x3 kernel
     float *z14_ws = nullptr, *z10_ws = nullptr;        // their per-row inverse weight scales
+    ConvLayer z4_s2d, z7_s2d;                          // the two stride-2 convs in the space-to-depth form (conv_sh16.h S2D)
     std::vector<void*> allocs;                         // everything to hipFree
     // workspace
     uint8_t* lab_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // res_div 32,16,8,4,2 (index by log2) ; [0] unused
