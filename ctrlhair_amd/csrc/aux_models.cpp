@@ -205,8 +205,12 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
             ci = co;
         }
         const int oc = w == 0 ? 1 : 18;
-        dec_out[w] = make_conv(B, B.vec(d + ".out_layer.conv.weight", (size_t)oc * 32 * 9), B.vec(d + ".out_layer.conv.bias", oc),
-                               oc, 32, 3, 1, 1);
+        if (use_sh16)
+            dec_out_sh[w] = make_conv_sh16(B, B.vec(d + ".out_layer.conv.weight", (size_t)oc * 32 * 9),
+                                           B.vec(d + ".out_layer.conv.bias", oc), oc, 32, 3, 1);
+        else
+            dec_out[w] = make_conv(B, B.vec(d + ".out_layer.conv.weight", (size_t)oc * 32 * 9), B.vec(d + ".out_layer.conv.bias", oc),
+                                   oc, 32, 3, 1, 1);
         if (!B.err.empty()) return B.err;
     }
     // generate_pos_embedding (shape_branch/model.py:18-30): sin/cos(2^k pi u) for u in {x, y} grids, order 10.
@@ -230,7 +234,7 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
     const size_t HW = (size_t)S * S;
     in_hair = B.falloc(mb * 48 * HW);      // f16x3 path: SH16 with the channels padded to 48 / 64 (4 bytes per element either way)
     in_face = B.falloc(mb * 64 * HW);
-    bufa = B.falloc((size_t)mb * (8192 + 19 * HW));   // decoder input vector + temporary logits
+    bufa = B.falloc((size_t)mb * (8192 + 24 * HW));   // decoder input vector + temporary logits (f16x3 path: C4, 4 + 20 rows)
     bufb = B.falloc(mb * 32 * HW);                      // ping-pong activations (largest: 32 ch at 256^2)
     bufc = B.falloc(mb * 32 * HW);
     lnpart = B.falloc((size_t)mb * 128 * 3);
@@ -331,7 +335,7 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
     up.partial_cap = splitk_cap;
     if (use_sh16) {
         // layer 0 (2x2 -> 4x4, input straight from the Linear) on the exact-f32 kernel; its LayerNorm writes SH16.  Layers 1-6:
-        // f16x3 conv over the nearest-x2 view (SH16 in, C4 out) -> LayerNorm + lrelu (C4 in, SH16 out; the last one NCHW f32).
+        // f16x3 conv over the nearest-x2 view (SH16 in, C4 out) -> LayerNorm + lrelu (C4 in, SH16 out); output conv -> C4 logits.
         ck(run_conv(dec[w][0], x, bufc, B, size, size, up, st), "shape dec conv0");
         size *= 2;
         ck(layernorm_act_conv(bufc, 0, bufb, 1, dec_ln_scale[w][0], dec_ln[w][0].gamma, dec_ln[w][0].beta, lnpart, B,
@@ -355,11 +359,26 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
             p.partial_cap = splitk_cap;
             ck(conv_sh16_plain(p, 3, st), "shape dec conv (f16x3)");
             size *= 2;
-            const bool last = l == 6;
-            ck(layernorm_act_conv(bufc, 1, bufb, last ? 0 : 1, dec_ln_scale[w][l], dec_ln[w][l].gamma, dec_ln[w][l].beta, lnpart, B,
+            ck(layernorm_act_conv(bufc, 1, bufb, 1, dec_ln_scale[w][l], dec_ln[w][l].gamma, dec_ln[w][l].beta, lnpart, B,
                                   dec[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st), "shape dec ln");
         }
-        ck(run_conv(dec_out[w], bufb, logit, B, size, size, ConvOpts(), st), "shape dec out");
+        {   // output conv (32 -> 1 / 18 rows, padded): C4 logits
+            const ConvLayer& L = dec_out_sh[w];
+            ConvParams p{};
+            p.in = bufb;
+            p.wpk = L.sh_wpk;
+            p.wscale = L.sh_wscale;
+            p.in_scale_inv = 1.f / dec_ln_scale[w][6];
+            p.out = logit;
+            p.B = B;
+            p.Cin = 32;
+            p.H = size;
+            p.W = size;
+            p.Mrows = L.Cout;
+            p.bias = L.bias;
+            p.act = ACT_NONE;
+            ck(conv_sh16_plain(p, 3, st), "shape dec out (f16x3)");
+        }
         return ck.err;
     }
     for (int l = 0; l < 7; ++l) {
@@ -390,9 +409,10 @@ std::string ShapeModel::decode(const float* hair_code, const float* face_code, f
     const size_t HW = (size_t)S * S;
     for (int bo = 0; bo < Btot; bo += max_batch) {
         const int B = std::min(max_batch, Btot - bo);
-        // logits: caller buffers when given, else the tail of bufa (the decoder only uses bufa's first B*8192 floats)
-        float* hl = hair_logit ? hair_logit + bo * HW : bufa + (size_t)B * 8192;
-        float* fl = face_logit ? face_logit + bo * 18 * HW : bufa + (size_t)B * 8192 + B * HW;
+        // logits: caller buffers when given, else the tail of bufa (the decoder only uses bufa's first B*8192 floats).
+        // f16x3 path: the decoders write C4 logits (4 / 20 padded rows) into that tail; callers' NCHW buffers are filled from it
+        float* hl = hair_logit && !use_sh16 ? hair_logit + bo * HW : bufa + (size_t)B * 8192;
+        float* fl = face_logit && !use_sh16 ? face_logit + bo * 18 * HW : bufa + (size_t)B * 8192 + (use_sh16 ? 4 : 1) * B * HW;
         std::string e;
         if (hair_code) {
             Ck ck;
@@ -406,7 +426,14 @@ std::string ShapeModel::decode(const float* hair_code, const float* face_code, f
         }
         e = run_decoder(1, face_code + (size_t)bo * FACE_DIM, FACE_DIM, fl, B, st);
         if (!e.empty()) return e;
-        if (labels && hair_code) {
+        if (use_sh16) {
+            Ck ck;
+            if (hair_code && hair_logit) ck(c4_rows_to_nchw(hl, hair_logit + bo * HW, B, 1, 4, (int)HW, st), "hair logits");
+            if (face_logit) ck(c4_rows_to_nchw(fl, face_logit + bo * 18 * HW, B, 18, 20, (int)HW, st), "face logits");
+            if (labels && hair_code)
+                ck(shape_softmax(hl, fl, labels + bo * HW, probs ? probs + bo * 19 * HW : nullptr, B, (int)HW, st, 1), "shape softmax");
+            if (!ck.err.empty()) return ck.err;
+        } else if (labels && hair_code) {
             e = combine(hl, fl, labels + bo * HW, probs ? probs + bo * 19 * HW : nullptr, B, st);
             if (!e.empty()) return e;
         }

@@ -46,6 +46,7 @@ struct ShapeModel {
     float dec_ln_scale[2][7] = {};
     // encoder layers 0..3 (k4 s2 convs at 128^2 .. 16^2) in the space-to-depth form of the f16x3 kernels (conv_sh16.h S2D):
     // SH16 inputs (scale 2^14: one-hot and sin / cos channels), LayerNorm outputs SH16 with their static scales
+    ConvLayer dec_out_sh[2];        // the output convs (32 -> 1 / 18, rows padded to 4 / 20) for the f16x3 kernels: C4 logits
     ConvLayer enc_s2d[2][4];
     float enc_ln_scale[2][4] = {};
     static constexpr float ENC_IN_SCALE = 16384.f;
@@ -63,6 +64,7 @@ struct ShapeModel {
     void destroy();
   private:
     std::string run_encoder(int which, const float* in, float* code, int B, hipStream_t st);
+    // logit: NCHW [B][1 | 18][S*S]; f16x3 path: C4 [B][1 | 5][S*S][4] (rows padded)
     std::string run_decoder(int which, const float* code, int code_dim, float* logit, int B, hipStream_t st);
 };
 

@@ -50,7 +50,9 @@ hipError_t maxpool3x3s2_c4(const float* in_nchw, float* out_c4, unsigned* amax, 
 hipError_t global_avg_pool_c4(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 hipError_t chan_affine_c4(const float* in, const float* sc, float sc_add, const float* sh, const float* other, float* out,
                           unsigned* amax, int B, int C, int HW, hipStream_t s);
-hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW, hipStream_t s);
+hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW, hipStream_t s,
+                         int c4 = 0);
+hipError_t c4_rows_to_nchw(const float* in, float* out, int B, int C, int Cpad, int HW, hipStream_t s);
 hipError_t shape_inputs(const uint8_t* lab, const float* pos, float* hair_in, float* face_in, int B, int HW,
                         hipStream_t s);
 hipError_t shape_inputs_sh16(const uint8_t* lab, const float* pos, void* hair_in, void* face_in, int B, int HW, float scale,

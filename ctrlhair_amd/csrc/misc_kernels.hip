@@ -929,16 +929,28 @@ hipError_t bilinear_argmax(const float* lg, uint8_t* out, float* logits_out, con
 // ---------------------------------------------------------------------------------------------------------
 // Shape decoder tail (shape_branch/model.py:184-187 + shape_util.py:17-20): insert the hair logit at class 13,
 // softmax over 19, argmax -> uint8 label.  probs (optional) receives the softmax [B,19,H,W].
+// c4 != 0: the logits are the C4 tensors the f16x3 output convs write (hair [B][1][HW][4], face [B][5][HW][4]; rows padded)
 __global__ void shape_softmax_kernel(const float* __restrict__ hair, const float* __restrict__ face,
-                                     uint8_t* __restrict__ lab, float* __restrict__ probs, int B, int HW) {
+                                     uint8_t* __restrict__ lab, float* __restrict__ probs, int B, int HW, int c4) {
     const long long n = (long long)B * HW;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(i / HW), p = (int)(i % HW);
         float v[19];
+        if (c4) {
+            float f[20];
 #pragma unroll
-        for (int c = 0; c < 19; ++c)
-            v[c] = c == 13 ? hair[(long long)b * HW + p]
-                           : face[((long long)b * 18 + (c < 13 ? c : c - 1)) * HW + p];
+            for (int g = 0; g < 5; ++g) {
+                const float4 t = reinterpret_cast<const float4*>(face)[((long long)b * 5 + g) * HW + p];
+                f[g * 4] = t.x; f[g * 4 + 1] = t.y; f[g * 4 + 2] = t.z; f[g * 4 + 3] = t.w;
+            }
+#pragma unroll
+            for (int c = 0; c < 19; ++c) v[c] = c == 13 ? hair[((long long)b * HW + p) * 4] : f[c < 13 ? c : c - 1];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 19; ++c)
+                v[c] = c == 13 ? hair[(long long)b * HW + p]
+                               : face[((long long)b * 18 + (c < 13 ? c : c - 1)) * HW + p];
+        }
         float m = v[0];
         int bi = 0;
 #pragma unroll
@@ -956,10 +968,24 @@ __global__ void shape_softmax_kernel(const float* __restrict__ hair, const float
     }
 }
 hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW,
-                         hipStream_t s) {
+                         hipStream_t s, int c4) {
     const long long n = (long long)B * HW;
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(shape_softmax_kernel, dim3(grid), dim3(256), 0, s, hair, face, lab, probs, B, HW);
+    hipLaunchKernelGGL(shape_softmax_kernel, dim3(grid), dim3(256), 0, s, hair, face, lab, probs, B, HW, c4);
+    return hipGetLastError();
+}
+// first C channels of a C4 tensor with Cpad channels -> NCHW [B][C][HW]
+__global__ void c4_rows_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int Cpad, int HW) {
+    const long long n = (long long)B * C * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW), c = (int)((i / HW) % C), b = (int)(i / ((long long)HW * C));
+        out[i] = in[(((long long)b * (Cpad >> 2) + (c >> 2)) * HW + p) * 4 + (c & 3)];
+    }
+}
+hipError_t c4_rows_to_nchw(const float* in, float* out, int B, int C, int Cpad, int HW, hipStream_t s) {
+    const long long n = (long long)B * C * HW;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(c4_rows_to_nchw_kernel, dim3(grid), dim3(256), 0, s, in, out, B, C, Cpad, HW);
     return hipGetLastError();
 }
 
