@@ -134,8 +134,8 @@ class PipelineJob:
             if k in self.STAGE_GFLOP:
                 tf = self.STAGE_GFLOP[k] * self.images / t            # GFLOP per ms = TFLOP/s
                 # matrix-core path of the stage's dominant convs: exact-f32 MFMA, or 3 executed f16 products per f32 product
-                f16 = path != 'f32' and k in ('generator', 'zencoder', 'shape_decode')
-                terms = 3.0 if (f16 and (path == 'f16x3' or k != 'generator')) else 1.0     # (Zencoder / shape decoder: always f16x3)
+                f16 = path != 'f32'          # every stage's convs run on the f16 matrix cores unless the strict-f32 path is on
+                terms = 3.0 if (f16 and (path == 'f16x3' or k != 'generator')) else 1.0     # (aux networks: always the 3-term split)
                 peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
                 row.update({'algorithmic_tflops': round(tf, 1), 'bound': 'mfma', 'peak_tflops': peak,
                             'frac': round(terms * tf / peak, 4)})

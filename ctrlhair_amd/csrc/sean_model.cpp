@@ -851,7 +851,7 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             t.act = ACT_NONE;
             t.in_mode = IN_UP2_ZEROINS;
             ck(conv_sh16_plain(t, 3, st), "zenc convT (f16x3)");
-            ck(instnorm_c4_to_sh16(hs, B, 256, h2 * h2, 1e-5f, ACT_LRELU, h1, st), "zenc in4");
+            ck(instnorm_c4_to_sh16(hs, B, 256, h2 * h2, 1e-5f, ACT_LRELU, h1, st, splitk_ws), "zenc in4");
         } else {
             ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
             ck(run_conv(z10, h1, hs, B, h4, h4, zins, st), "zenc convT");
