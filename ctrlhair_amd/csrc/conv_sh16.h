@@ -136,7 +136,11 @@ __device__ __forceinline__ uint4 sh16_pair_swap(const uint4& w) {
     return make_uint4(r0[0], r1[0], r0[1], r1[1]);
 }
 
-template <int TW, int TH, int TB, int EPI, bool BF = false>
+// D2S (EPI_PLAIN): depth-to-space store.  GEMM row = phase * C + channel (C = Mrows / 4, phase = (py, px)); pixel (y, x) of the
+// conv grid lands at (2y + py, 2x + px) of the C-channel, 2H x 2W output: ConvTranspose2d(k3, s2, p1, op1) as ONE 2x2-tap
+// conv at the input resolution (each output phase only sees the taps that reach it: 9 of the 16 (tap, phase) weights are
+// non-zero, against 9 of 36 positions for a 3x3 conv over the zero-inserted x2 view).  bias is indexed by channel.
+template <int TW, int TH, int TB, int EPI, bool BF = false, bool D2S = false>
 __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)[2][4], int mtile64, int wn, int lane,
                                               int x0, int y0, int b0, int ks = 0) {
     const int HW = p.H * p.W;
@@ -160,7 +164,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
             const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
             const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
             pb_[n] = (b < p.B && y < p.H && x < p.W) ? b : -1;
-            pix_[n] = y * p.W + x;
+            pix_[n] = D2S ? 4 * y * p.W + 2 * x : y * p.W + x;
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -168,6 +172,27 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
             for (int rq = 0; rq < 4; ++rq) {
                 const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
                 if (row0 >= p.Mrows) continue;                  // Mrows % 4 == 0
+                if constexpr (D2S) {
+                    const int Cr = p.Mrows >> 2, ph = row0 / Cr, co0 = row0 - ph * Cr;
+                    const int poff = (ph >> 1) * 2 * p.W + (ph & 1);
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(isi, isi, isi, isi);
+                    if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + co0);
+                    if (p.wscale) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.wscale + row0);
+                        s4 = make_float4(t.x * isi, t.y * isi, t.z * isi, t.w * isi);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (pb_[n] < 0) continue;
+                        float4 v;
+                        v.x = acc[m][n][rq * 4 + 0] * s4.x + b4.x; v.y = acc[m][n][rq * 4 + 1] * s4.y + b4.y;
+                        v.z = acc[m][n][rq * 4 + 2] * s4.z + b4.z; v.w = acc[m][n][rq * 4 + 3] * s4.w + b4.w;
+                        v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+                        v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+                        reinterpret_cast<float4*>(p.out)[((long long)pb_[n] * (Cr >> 2) + (co0 >> 2)) * (4 * HW) + pix_[n] + poff] = v;
+                    }
+                    continue;
+                }
                 if (p.splitk > 1) {                              // split-K: raw partial sums to this slice's C4 slab
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
@@ -349,11 +374,13 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 // all 16 (tap, phase) pairs carry a weight, k = 3: 9 of 16).  The view is address arithmetic in the staging: chunk ->
 // (phase, 16 real channels), unit -> physical pixel 2 (y, x) + phase - 1, zero outside the image.  KS = 1: the 1x1 stride-2
 // shortcut convs (phase (1,1) only = physical pixel 2 (y, x)).  p.Cin = phases x p.s2d_cr, p.H / p.W = output size.
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false, bool S2D = false>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false, bool S2D = false,
+          bool D2S = false>
 __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
+    static_assert(!D2S || (KS == 2 && EPI == EPI_PLAIN && !FUSE && !S2D), "D2S: the 2x2-tap form of ConvTranspose2d(k3, s2)");
     static_assert(!(FUSE && INC4), "the fused second operand is an SH16 tensor");
     static_assert(!S2D || (!FUSE && EPI == EPI_PLAIN && (KS == 2 || KS == 1)), "S2D: plain 2x2-tap / 1x1 convs only");
-    static_assert(S2D || KS != 2, "2x2 taps exist for the space-to-depth view only");
+    static_assert(S2D || D2S || KS != 2, "2x2 taps exist for the space-to-depth / depth-to-space forms only");
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, NLOAD = Cfg::NLOAD, HALO = Cfg::HALO;
     constexpr int NT = KS * KS;
@@ -665,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     }
 
     if (p.dbg & 4) return;
-    sh16_epilogue<TW, TH, TB, EPI, TERMS == 2>(p, acc, mtile64, wn, lane, x0, y0, b0, ks);
+    sh16_epilogue<TW, TH, TB, EPI, TERMS == 2, D2S>(p, acc, mtile64, wn, lane, x0, y0, b0, ks);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1120,10 +1147,11 @@ __global__ __launch_bounds__(1024) void sh16_splitk_reduce_kernel(const ConvPara
     if (p.out_amax) sh16_block_slot_max(p.out_amax, amax * SH16_ACT_SCALE);       // uniform branch: every thread gets here
 }
 
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false, bool S2D = false>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = false, bool INC4 = false, bool S2D = false,
+          bool D2S = false>
 hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
-    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE, INC4, S2D>;
+    auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE, INC4, S2D, D2S>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1221,6 +1249,7 @@ hipError_t dispatch_sh16_s2d(const ConvParams& p, hipStream_t s) {
     if (p.W > 8) return launch_sh16<KS, 16, 16, 2, EPI_PLAIN, 3, false, INC4, true>(p, p.Mrows, s);
     return launch_sh16<KS, 8, 8, 8, EPI_PLAIN, 3, false, INC4, true>(p, p.Mrows, s);
 }
+hipError_t conv_sh16_d2s(const ConvParams& p, hipStream_t s);                // SH16 in, 2x2 taps, depth-to-space C4 out (W >= 32)
 hipError_t conv_sh16_s2d(const ConvParams& p, int KS, hipStream_t s);        // SH16 in
 hipError_t conv_sh16_s2d_c4(const ConvParams& p, int KS, hipStream_t s);     // f32 C4 in
 

@@ -331,6 +331,16 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             const auto k10 = sh16_row_exponents(256, 128, 3, g10);
             z10_sh = B.upload(pack_A_sh16(256, 128, 3, g10, k10));
             z10_ws = B.upload(sh16_wscale(k10));
+            {   // depth-to-space form of the same ConvTranspose: out[2y+py][2x+px] += x[y+dy][x+dx] * Wt[ci][co][py+1-2dy][px+1-2dx]
+                auto gd = [&](int row, int ci, int t) {
+                    const int ph = row / 256, co = row % 256;
+                    const int ky = (ph >> 1) + 1 - 2 * (t / 2), kx = (ph & 1) + 1 - 2 * (t % 2);
+                    return (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) ? w10[((size_t)ci * 256 + co) * 9 + ky * 3 + kx] : 0.f;
+                };
+                const auto kd = sh16_row_exponents(1024, 128, 2, gd);
+                z10_d2s = B.upload(pack_A_sh16(1024, 128, 2, gd, kd));
+                z10_d2s_ws = B.upload(sh16_wscale(kd));
+            }
             // and the two stride-2 convs (space-to-depth form)
             z4_s2d = make_conv_s2d(B, B.vec("Zencoder.model.4.weight", (size_t)64 * 32 * 9), B.vec("Zencoder.model.4.bias", 64), 64, 32, 3);
             z7_s2d = make_conv_s2d(B, B.vec("Zencoder.model.7.weight", (size_t)128 * 64 * 9), B.vec("Zencoder.model.7.bias", 128), 128, 64, 3);
@@ -838,19 +848,28 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         if (f16path) {
             ConvParams t{};
             t.in = dx;
-            t.wpk = z10_sh;
             t.out = hs;
             t.B = B;
             t.Cin = 128;
-            t.H = h2;
-            t.W = h2;
-            t.Mrows = 256;
             t.bias = z10.bias;
-            t.wscale = z10_ws;
             t.in_scale_inv = 1.f / instnorm_sh16_scale(h4 * h4);
             t.act = ACT_NONE;
-            t.in_mode = IN_UP2_ZEROINS;
-            ck(conv_sh16_plain(t, 3, st), "zenc convT (f16x3)");
+            if (dbg & 16384) {           // the earlier form, kept for comparison: 3x3 conv over the zero-inserted x2 view
+                t.wpk = z10_sh;
+                t.wscale = z10_ws;
+                t.H = h2;
+                t.W = h2;
+                t.Mrows = 256;
+                t.in_mode = IN_UP2_ZEROINS;
+                ck(conv_sh16_plain(t, 3, st), "zenc convT (f16x3)");
+            } else {                     // 2x2-tap conv at the input resolution, depth-to-space store
+                t.wpk = z10_d2s;
+                t.wscale = z10_d2s_ws;
+                t.H = h4;
+                t.W = h4;
+                t.Mrows = 1024;
+                ck(conv_sh16_d2s(t, st), "zenc convT (f16x3, depth-to-space)");
+            }
             ck(instnorm_c4_to_sh16(hs, B, 256, h2 * h2, 1e-5f, ACT_LRELU, h1, st, splitk_ws), "zenc in4");
         } else {
             ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
