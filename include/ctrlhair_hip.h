@@ -64,8 +64,12 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  * "sean.ahead" (default 4): run-ahead mode -- when a batch chunk holds at most `value` x 512x512 pixels, the kernels of the
  *   18 ACE layers that depend only on the label map and the style codes (label tables, fc_mu, style LUTs) run on an internal
  *   side stream into per-layer buffers, joined to `stream` by events (interactive latency: 3.3 -> 2.65 ms at 256x256); 0 = off.
- * "shape.f16x3" (default 1): the shape decoder's 3x3 convs from 4x4 resolution up run on the same f16x3 split-operand
- *   kernels (LayerNorm outputs are bounded, so their scales are static); 0 = every conv on the exact-f32 kernels. */
+ * "shape.f16x3" (default 1): the shape VAE's convs run on the same f16x3 split-operand kernels -- encoder layers 0-3 (k4,
+ *   stride 2: space-to-depth staging), decoder layers 1-6 and the output convs; LayerNorm outputs and the one-hot / sin-cos
+ *   inputs are bounded, so their scales are static; 0 = every conv on the exact-f32 kernels.
+ * "bisenet.f16x3" (default 1): BiSeNet's convs on the f16x3 kernels; its f32 activations stay in the C4 layout and are split
+ *   into f16 pairs while staged, with the scale derived from the maximum the producing kernel recorded; 0 = exact-f32 kernels.
+ *   (The Zencoder follows "sean.f16x3".) */
 int  ch_set_option(ch_handle* h, const char* key, int value);
 
 /* Fold + pack + upload the loaded tensors: spectral-norm sigma (torch spectral_norm eval semantics,

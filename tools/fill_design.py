@@ -20,6 +20,11 @@ def main(gen_path, pipe_path):
         'HBMFRAC': f"{100 * g['roofline']['hbm_contract']['frac']:.1f}",
         'PIPE': f"{p['value']:.1f}", 'PIPEMS': f"{p['ms_per_step']:.1f}", 'PIPEF32': f"{p['strict_fp32']['value']:.1f} images/s",
     }
+    st = p.get('stages', {})
+    for k, row in st.items():
+        vals['ST_' + k] = f"{row['ms']:.2f}" if row['ms'] < 3 else f"{row['ms']:.1f}"
+    if st:
+        vals['ST_aux'] = f"{sum(r['ms'] for k, r in st.items() if k != 'generator'):.1f}"
     path = ROOT + '/DESIGN.md'
     s = open(path).read()
     for k, v in vals.items():

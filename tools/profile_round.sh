@@ -26,3 +26,6 @@ python $R/tools/rocprof_summary.py $D/trace/t_results.db > $OUT/${TAG}_pipeline_
 tail -1 $OUT/pipe_run.log > $OUT/${TAG}_pipeline_bench_line.json
 rm -rf $D
 ls -la $OUT
+bash $R/tools/stage_trace.sh ${TAG} > $OUT/stage_run.log 2>&1
+cp $R/gpurun_out/${TAG}_aux_kernel_trace.md $OUT/${TAG}_aux_kernel_trace.md
+ls -la $OUT
