@@ -16,8 +16,9 @@ hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, f
 hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* mu_img, int B, int Npad, hipStream_t s,
                  float* mu_rows = nullptr, int sh16 = 0, int bs = 19, float scale = 1.f, unsigned* amax = nullptr,
                  int pass = 0, int bf16 = 0);
+// w4 (C4 path): the same weights packed [Cin/4][tap][co][4 channels] for scalar loads
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
-                         hipStream_t s, int c4 = 0);
+                         hipStream_t s, int c4 = 0, const float* w4 = nullptr);
 hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hipStream_t s);
 hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s);
 // misc_kernels.hip

@@ -345,24 +345,18 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
 
 // Same op for the C4 activation layout [B][Cin/4][H][W][4] (f16x3 path): one float4 = 4 channels of a pixel, so the
 // staging loads are 16 B per lane and every LDS read feeds 12 FMAs.  Channel groups are double-buffered in LDS with the
-// next group's loads in flight during the current group's FMAs; weights sit in LDS as [group][tap][co] float4 and are
-// read with wave-uniform (broadcast) addresses.  HBM-read bound: x is read once (+ halo).
-constexpr int CI4_MAXG = 16;
-__global__ __launch_bounds__(256) void conv_img_c4_kernel(const float4* __restrict__ x, const float* __restrict__ w,
+// next group's loads in flight during the current group's FMAs; the weights, packed on the host as [group][tap][co] float4
+// (w4), arrive through wave-uniform scalar loads and enter the FMAs as SGPR operands (as LDS broadcasts they took 27 of the
+// 36 LDS reads per group and made the kernel LDS-issue bound).  HBM-read bound: x is read once (+ halo).
+__global__ __launch_bounds__(256) void conv_img_c4_kernel(const float4* __restrict__ x, const float4* __restrict__ w4,
                                                           const float* __restrict__ bias, float* __restrict__ out, int B,
                                                           int Cin, int H, int W) {
     constexpr int PW = CI_TW + 2, PH = CI_TH + 2, NP = PW * PH;
     __shared__ float4 patch[2][NP];
-    __shared__ float4 ws4[CI4_MAXG * 9 * 3];
     const int G = Cin >> 2;
     const int tx = threadIdx.x % CI_TW, ty = threadIdx.x / CI_TW;
     const int x0 = blockIdx.x * CI_TW, y0 = blockIdx.y * CI_TH, b = blockIdx.z;
     const long long HW = (long long)H * W;
-    for (int e = threadIdx.x; e < G * 9 * 3; e += 256) {
-        const int g = e / 27, t = (e / 3) % 9, co = e % 3;
-        const float* wp = w + ((long long)co * Cin + g * 4) * 9 + t;
-        ws4[e] = make_float4(wp[0], wp[9], wp[18], wp[27]);
-    }
     int off[2];                       // this thread's (up to) two patch elements: pixel offset or -1 (outside / none)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -398,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_img_c4_kernel(const float4* __restri
     for (int g = 0; g < G; ++g) {
         if (g + 1 < G) fetch(g + 1);
         const float4* pp = patch[g & 1] + ty * PW + tx;
-        const float4* wg = ws4 + g * 27;
+        const float4* wg = w4 + g * 27;                  // wave-uniform: scalar loads
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float4 v = pp[(t / 3) * PW + t % 3];
@@ -420,11 +414,11 @@ __global__ __launch_bounds__(256) void conv_img_c4_kernel(const float4* __restri
 }
 
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
-                         hipStream_t s, int c4) {
+                         hipStream_t s, int c4, const float* w4) {
     dim3 grid((W + CI_TW - 1) / CI_TW, (H + CI_TH - 1) / CI_TH, B);
-    if (c4 && Cin % 4 == 0 && Cin <= 4 * CI4_MAXG) {
-        hipLaunchKernelGGL(conv_img_c4_kernel, grid, dim3(256), 0, s, reinterpret_cast<const float4*>(x), w, bias, out, B,
-                           Cin, H, W);
+    if (c4 && w4 && Cin % 4 == 0) {
+        hipLaunchKernelGGL(conv_img_c4_kernel, grid, dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<const float4*>(w4), bias, out, B, Cin, H, W);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(conv_img_kernel, grid, dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, c4);

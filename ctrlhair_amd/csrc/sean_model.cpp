@@ -63,6 +63,15 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         auto b = B.get("conv_img.bias", 3);
         if (!w || !b) return B.err;
         img_w = B.upload(std::vector<float>(w->f32(), w->f32() + 3 * ngf * 9));
+        {
+            std::vector<float> w4((size_t)(ngf / 4) * 27 * 4);
+            for (int g = 0; g < ngf / 4; ++g)
+                for (int t = 0; t < 9; ++t)
+                    for (int co = 0; co < 3; ++co)
+                        for (int e = 0; e < 4; ++e)
+                            w4[(((size_t)g * 9 + t) * 3 + co) * 4 + e] = w->f32()[((size_t)co * ngf + g * 4 + e) * 9 + t];
+            img_w4 = B.upload(w4);
+        }
         img_b = B.upload(std::vector<float>(b->f32(), b->f32() + 3));
     }
 
@@ -785,7 +794,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             R.tap_c4(b.name, y, b.fout, rr);
             std::swap(x, y);
         }
-        R.check(conv_img_tanh(x, img_w, img_b, out + (size_t)bo * 3 * S * S, B, ngf, S, S, st, use_sh16 ? 1 : 0), "conv_img");
+        R.check(conv_img_tanh(x, img_w, img_b, out + (size_t)bo * 3 * S * S, B, ngf, S, S, st, use_sh16 ? 1 : 0, img_w4), "conv_img");
         if (!R.err.empty()) return R.err;
     }
     return "";

@@ -61,6 +61,7 @@ struct SeanModel {
     std::vector<BlockW> blocks;
     float *fc_table = nullptr, *fc_bias = nullptr;     // fc conv as label LUT [19*9][16ngf]
     float *img_w = nullptr, *img_b = nullptr;          // conv_img raw [3][ngf][3][3]
+    float* img_w4 = nullptr;                           // the same, [ngf/4][tap][co][4] (conv_img_c4_kernel's scalar loads)
     bool has_zencoder = false;
     float* z1_w = nullptr;                             // Zencoder stem weights, unpacked (direct VALU conv)
     ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
