@@ -1218,7 +1218,13 @@ template <int KS, int TERMS>
 hipError_t dispatch_sh16_plain(const ConvParams& p, hipStream_t s) {
     // dbg bit 64: wave-specialised persistent kernel (measured slower than the 2-blocks-per-CU kernel for the plain
     // epilogue, whose residual loads it cannot hide; kept selectable for profiling)
-    if ((p.dbg & 64) && p.W >= 32 && !(p.partial && p.mtiles_hint_small) && !p.in2)
+    // Default: layers with 2..8 rounds of tiles per CU (the generator's 3x3 convs up to 128x128 at B = 16) run 6-12 % faster
+    // on it (measured per layer, B = 16: 762 -> 672 us, 1478 -> 1330, 1454 -> 1368); with more tiles -- the 256^2 / 512^2
+    // layers, HBM-heavy -- it is level or slower (1463 -> 1430, 1574 -> 1626) and the 2-blocks-per-CU kernel stays.
+    const long long ntiles = (long long)((p.Mrows + 63) / 64) * ((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+    const bool ws_auto = KS == 3 && !(p.dbg & 128) && ntiles >= 512 && ntiles <= 2048 && p.Cin >= 48 && p.in_mode == IN_DIRECT &&
+                         p.pad_mode == PAD_ZERO;
+    if (((p.dbg & 64) || ws_auto) && p.W >= 32 && !(p.partial && p.mtiles_hint_small) && !p.in2)
         return launch_sh16_ws<KS, 32, 16, 1, EPI_PLAIN, TERMS>(p, p.Mrows, s);
     if (p.in2) {        // 3x3 conv with a fused 1x1 second operand (ResBlock shortcut): 32x16 tiles only
         if constexpr (KS == 3) {
