@@ -219,3 +219,52 @@ def test_labels_outside_the_class_range(hip_lib, path):
     print(f'{path}: labels with 19/200/255: max |delta| {d:.3e}')
     assert np.isfinite(img).all() and d <= TOL
     gen.handle.close()
+
+
+def _bisenet_scaled(F):
+    """BiSeNet weights whose every feature map is F times the original while the logits are unchanged: the network is
+    positively homogeneous up to its BN shifts, so the first BN scales its output (gamma, beta x F), every later BN on the
+    feature path shifts with it (running_mean, beta x F) and the three places that squash features into attention weights
+    or logits divide F out again (conv_atten, ffm.conv1, conv_out.conv_out x 1/F)."""
+    from ctrlhair_amd import procedural as P
+    sd = {k: np.array(v, copy=True) for k, v in P.bisenet_state_dict(0).items()}
+    F = np.float32(F)
+    for k in list(sd):
+        if k.startswith('conv_out16.') or k.startswith('conv_out32.') or 'bn_atten' in k:
+            continue
+        if k == 'cp.resnet.bn1.weight' or k == 'cp.resnet.bn1.bias':
+            sd[k] = sd[k] * F
+        elif k.startswith('cp.resnet.bn1.'):
+            continue
+        elif k.endswith('.running_mean') or (k.endswith('.bias') and ('bn' in k.split('.')[-2] or k.split('.')[-2] == '1')):
+            sd[k] = sd[k] * F                          # BN running_mean / beta (downsample.1 is a BN too)
+    for k in ('cp.arm16.conv_atten.weight', 'cp.arm32.conv_atten.weight', 'ffm.conv1.weight', 'conv_out.conv_out.weight'):
+        sd[k] = sd[k] / F
+    return sd
+
+
+@pytest.mark.parametrize('F', [3e4, 1e-5])
+def test_bisenet_activation_magnitudes(hip_lib, F):
+    """The BiSeNet trunk keeps f32 activations and splits them into f16 pairs while a conv stages them, at the scale the
+    producer's recorded maximum dictates (conv_sh16.h INC4).  With every feature map x 3e4 (maxima beyond 65504 / 8) or x 1e-5
+    (far below the first-pass window) the logits must still match the oracle on the same weights."""
+    from ctrlhair_amd import lib, models
+    from ctrlhair_amd import procedural as P
+    from oracle import aux_oracle as A
+    from oracle import sean_oracle as O
+    sd = _bisenet_scaled(F)
+    img = P.synthetic_images(2, 128, seed=77)
+    rl, rlab = A.bisenet_forward(O.to_torch(sd), img)
+    base, _ = A.bisenet_forward(O.to_torch(P.bisenet_state_dict(0)), img)
+    assert float((rl - base).abs().max()) <= 1e-3          # the construction leaves the function unchanged (f32 round-off)
+    dev = torch.device('cuda', 0)
+    for f16x3 in (True, False):
+        fp = models.FaceParsing(lib.Handle(0), dev).load_state_dict(sd, max_batch=2, max_size=128, f16x3=f16x3)
+        lab, lg = fp.parse_tensor(torch.from_numpy(img).to(dev), want_logits=True)
+        torch.cuda.synchronize()
+        d = float((lg.cpu() - rl).abs().max())
+        print(f'F={F:g} f16x3={f16x3}: max |logit delta| vs oracle {d:.3e}')
+        assert d <= TOL
+        top2 = torch.topk(rl, 2, dim=1).values
+        assert not ((lab.cpu() != rlab) & ((top2[:, 0] - top2[:, 1]) > 1e-3)).any()
+        fp.handle.close()
