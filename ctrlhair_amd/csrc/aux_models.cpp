@@ -151,7 +151,7 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
             const int cout = std::min(2048, 32 << l);
             const std::string p = std::string(side[w]) + "_encoder.layers." + std::to_string(l);
             const auto gam = B.vec(p + ".norm.gamma", cout), bet = B.vec(p + ".norm.beta", cout);
-            if (use_sh16 && l < 4) {
+            if (use_sh16 && l < ENC_S2D) {
                 enc_s2d[w][l] = make_conv_s2d(B, B.vec(p + ".conv.weight", (size_t)cout * cin * 16), B.vec(p + ".conv.bias", cout),
                                               cout, cin, 4);
                 float gm = 0.f, bm = 0.f;
@@ -256,9 +256,9 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
     int size = S;
     int l0 = 0;
     if (use_sh16) {
-        // layers 0..3: SH16 -> f16x3 stride-2 conv (space-to-depth form) -> C4 -> LayerNorm + lrelu -> SH16 (layer 3: NCHW f32)
+        // layers 0..ENC_S2D-1: SH16 -> f16x3 stride-2 conv (space-to-depth form) -> C4 -> LayerNorm + lrelu -> SH16 (last: NCHW f32)
         float s_in = ENC_IN_SCALE;
-        for (int l = 0; l < 4; ++l) {
+        for (int l = 0; l < ENC_S2D; ++l) {
             const ConvLayer& L = enc_s2d[w][l];
             ConvParams p{};
             p.in = x;
@@ -279,12 +279,12 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
             p.partial = splitk_ws;
             p.partial_cap = splitk_cap;
             ck(conv_sh16_s2d(p, L.KS, st), "shape enc conv (f16x3)");
-            ck(layernorm_act_conv(bufc, 1, bufb, l < 3 ? 1 : 0, enc_ln_scale[w][l], enc_ln[w][l].gamma, enc_ln[w][l].beta, lnpart, B,
+            ck(layernorm_act_conv(bufc, 1, bufb, l < ENC_S2D - 1 ? 1 : 0, enc_ln_scale[w][l], enc_ln[w][l].gamma, enc_ln[w][l].beta, lnpart, B,
                                   L.Cout, size * size, 1e-5f, ACT_LRELU, st), "shape enc ln");
             x = bufb;
             s_in = enc_ln_scale[w][l];
         }
-        l0 = 4;
+        l0 = ENC_S2D;
         bufs[0] = bufc;              // layer 4 reads bufb
         bufs[1] = bufb;
     }

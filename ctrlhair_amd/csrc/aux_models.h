@@ -44,11 +44,12 @@ struct ShapeModel {
     bool use_sh16 = true;
     float *dec_sh[2][7] = {}, *dec_ws[2][7] = {};
     float dec_ln_scale[2][7] = {};
-    // encoder layers 0..3 (k4 s2 convs at 128^2 .. 16^2) in the space-to-depth form of the f16x3 kernels (conv_sh16.h S2D):
+    // encoder layers (k4 s2 convs, 128^2 .. 2^2 outputs) in the space-to-depth form of the f16x3 kernels (conv_sh16.h S2D):
     // SH16 inputs (scale 2^14: one-hot and sin / cos channels), LayerNorm outputs SH16 with their static scales
     ConvLayer dec_out_sh[2];        // the output convs (32 -> 1 / 18, rows padded to 4 / 20) for the f16x3 kernels: C4 logits
-    ConvLayer enc_s2d[2][4];
-    float enc_ln_scale[2][4] = {};
+    static constexpr int ENC_S2D = 7;          // layers 0 .. ENC_S2D-1 on the S2D kernels (the rest on the exact-f32 kernels)
+    ConvLayer enc_s2d[2][7];
+    float enc_ln_scale[2][7] = {};
     static constexpr float ENC_IN_SCALE = 16384.f;
     float* pos = nullptr;      // [40][S*S]
     float *in_hair = nullptr, *in_face = nullptr, *bufa = nullptr, *bufb = nullptr, *bufc = nullptr, *lnpart = nullptr,
