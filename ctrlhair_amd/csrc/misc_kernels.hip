@@ -1134,10 +1134,81 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
         }
     }
 }
+// One BLOCK per 2 output rows: its 4 waves split K (interleaved float4 slices when K % 4 == 0), partial sums meet in LDS and are
+// added in wave order (deterministic); up to LIN_BT samples per pass.  (One wave per row pair left an 8192 -> 16 layer with 8
+// waves on the whole GPU, each walking K in 32 dependent steps: 85 us for 0.5 MB of weights.)
+// x row stride = ldx (allows reading a slice / concatenation handled by the caller), out row stride = ldo.
+__global__ __launch_bounds__(256) void linear_ksplit_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ out, int B,
+                                                     int K, int O, int ldx, int ldo, int act) {
+    __shared__ float part[4][2][LIN_BT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o0 = blockIdx.x * 2;
+    const bool two = o0 + 1 < O;
+    const float* w0 = W + (long long)o0 * K;
+    const float* w1 = W + (long long)(two ? o0 + 1 : o0) * K;
+    for (int bb = 0; bb < B; bb += LIN_BT) {
+        float a0[LIN_BT], a1[LIN_BT];
+#pragma unroll
+        for (int t = 0; t < LIN_BT; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+        if ((K & 3) == 0) {
+#pragma unroll 2
+            for (int k = threadIdx.x * 4; k < K; k += 1024) {
+                const float4 u0 = *reinterpret_cast<const float4*>(w0 + k);
+                const float4 u1 = *reinterpret_cast<const float4*>(w1 + k);
+#pragma unroll
+                for (int t = 0; t < LIN_BT; ++t)
+                    if (bb + t < B) {
+                        const float4 v = *reinterpret_cast<const float4*>(x + (long long)(bb + t) * ldx + k);
+                        a0[t] += u0.x * v.x + u0.y * v.y + u0.z * v.z + u0.w * v.w;
+                        a1[t] += u1.x * v.x + u1.y * v.y + u1.z * v.z + u1.w * v.w;
+                    }
+            }
+        } else {
+            for (int k = threadIdx.x; k < K; k += 256) {
+                const float u0 = w0[k], u1 = w1[k];
+#pragma unroll
+                for (int t = 0; t < LIN_BT; ++t)
+                    if (bb + t < B) {
+                        const float v = x[(long long)(bb + t) * ldx + k];
+                        a0[t] += u0 * v;
+                        a1[t] += u1 * v;
+                    }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < LIN_BT; ++t) {
+            a0[t] = wave_sum(a0[t]);
+            a1[t] = wave_sum(a1[t]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < LIN_BT; ++t) {
+                part[wave][0][t] = a0[t];
+                part[wave][1][t] = a1[t];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * LIN_BT) {
+            const int r = threadIdx.x / LIN_BT, t = threadIdx.x % LIN_BT, o = o0 + r;
+            if (bb + t < B && o < O) {
+                float v = ((part[0][r][t] + part[1][r][t]) + part[2][r][t]) + part[3][r][t];
+                v += bias ? bias[o] : 0.f;
+                if (scale) v = v * scale[o] + shift[o];
+                out[(long long)(bb + t) * ldo + o] = act_fn(v, act);
+            }
+        }
+        __syncthreads();
+    }
+}
 hipError_t linear(const float* x, const float* W, const float* bias, const float* scale, const float* shift, float* out,
                   int B, int K, int O, int ldx, int ldo, int act, hipStream_t s) {
-    hipLaunchKernelGGL(linear_kernel, dim3((O + 7) / 8), dim3(256), 0, s, x, W, bias, scale, shift, out, B, K, O, ldx, ldo,
-                       act);
+    // few rows and a long reduction (shape-encoder heads: 8192 -> 16 / 1024): the K-split form fills more of the chip
+    if (K >= 2048 && O <= 2048)
+        hipLaunchKernelGGL(linear_ksplit_kernel, dim3((O + 1) / 2), dim3(256), 0, s, x, W, bias, scale, shift, out, B, K, O, ldx, ldo, act);
+    else
+        hipLaunchKernelGGL(linear_kernel, dim3((O + 7) / 8), dim3(256), 0, s, x, W, bias, scale, shift, out, B, K, O, ldx, ldo, act);
     return hipGetLastError();
 }
 
