@@ -161,3 +161,25 @@ def test_shape_decoder_exact_f32_path_matches_golden_too(hip_lib):
     print('shape decoder f16x3 vs exact f32: max |delta| of the logits', d, ' |logit| max', float(fl.abs().max()))
     assert d <= 2e-4
     h.close()
+
+
+def test_bisenet_non_square_and_exact_f32_option(hip_lib):
+    """H != W (256 x 384: partial tiles in both the 32x16 and the 16x16 / 8x8 tilings, stride-2 space-to-depth staging with
+    different strides per axis), on the default f16x3 trunk and with option bisenet.f16x3 = 0 (exact-f32 kernels): both
+    against the oracle."""
+    from ctrlhair_amd import lib, models
+    from ctrlhair_amd import procedural as P
+    from oracle import aux_oracle as A
+    from oracle import sean_oracle as O
+    e = env()
+    sd = P.bisenet_state_dict(0)
+    img = np.ascontiguousarray(P.synthetic_images(2, 384, seed=123)[:, :, :256, :])         # [2, 3, 256, 384]
+    rl, rlab = A.bisenet_forward(O.to_torch(sd), img)
+    top2 = torch.topk(rl, 2, dim=1).values
+    for f16x3 in (True, False):
+        fp = models.FaceParsing(lib.Handle(0), e['dev']).load_state_dict(sd, max_batch=2, max_size=512, f16x3=f16x3)
+        lab, lg = fp.parse_tensor(torch.from_numpy(img).to(e['dev']), want_logits=True)
+        torch.cuda.synchronize()
+        assert float((lg.cpu() - rl).abs().max()) <= TOL
+        assert not ((lab.cpu() != rlab) & ((top2[:, 0] - top2[:, 1]) > 1e-3)).any()
+        fp.handle.close()

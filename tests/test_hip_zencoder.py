@@ -54,3 +54,17 @@ def test_golden(hip_lib, name, path):
     # absent regions are exactly zero rows (architecture.py:199)
     absent = np.abs(c.codes).sum(-1) == 0
     assert (out[absent] == 0).all()
+
+
+def test_size_not_a_multiple_of_the_tiles(hip_lib):
+    """S = 288: every stage of the f16 path (space-to-depth stride-2 convs at 144 / 72, depth-to-space ConvTranspose at 72,
+    sliced instance norms) meets partial tiles and slices; bar: the oracle on the same inputs."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    g = gen('f16x3')
+    B, S = 2, 288
+    lab, img = P.blocky_labels(B, S, grid=9, seed=19), P.synthetic_images(B, S, seed=20)
+    ref = O.zencoder_forward(O.to_torch(P.sean_state_dict(0, 16)), img, lab).numpy()
+    codes = g.encode(torch.from_numpy(img).to(g.device), torch.from_numpy(lab).to(g.device))
+    torch.cuda.synchronize()
+    assert float(np.abs(codes.cpu().numpy() - ref).max()) <= TOL
