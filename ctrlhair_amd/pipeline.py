@@ -85,6 +85,8 @@ class EditPipeline:
         import os
         med = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'mean_style_code.npz'))['median']
         self.median = torch.from_numpy(med.astype(np.float32)).to(self.device)
+        self.side = torch.cuda.Stream(self.device)      # edit(): the shape branch runs here, underneath the Zencoder
+        self.overlap = True
         self.mean = torch.tensor(_MEAN, device=self.device).view(1, 3, 1, 1)
         self.std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1)
 
@@ -111,9 +113,16 @@ class EditPipeline:
         return {'shape': shape, 'face': face, 'codes': codes, 'rgb_mean': stats['rgb_mean'], 'pca_std': stats['pca_std'],
                 'texture': lat['noise'], 'curliness': lat['noise_curliness']}
 
-    def apply_sliders(self, lat: dict, sliders: dict) -> dict:
-        """Backend.change_curliness / change_texture / change_shape / change_color on every sample."""
+    def apply_sliders(self, lat: dict, sliders: dict, only_shape: bool = False) -> dict:
+        """Backend.change_curliness / change_texture / change_shape / change_color on every sample.  only_shape: just the
+        shape direction (what edit() runs on its side stream; `lat` then only needs 'shape')."""
         out = dict(lat)
+        move = lambda cur, d, val: cur + (val - cur @ d)[:, None] * d[None]                     # continue_change_with_direction
+        if only_shape:
+            if sliders.get('shape') is not None:
+                idx, val = sliders['shape']
+                out['shape'] = move(lat['shape'], self.shape_dirs[idx], val)
+            return out
         # colour lives as uint8 HSV in the reference (ui/backend.py:100: the predicted mean RGB is truncated to uint8)
         hsv = rgb_to_hsv_u8(lat['rgb_mean'].clamp(0, 255).floor())
         if sliders.get('hsv_gaussian') is not None:
@@ -124,7 +133,6 @@ class EditPipeline:
         out['rgb'] = hsv_to_rgb_u8(hsv)                                                         # tensor_hsv_to_rgb (:108-115)
         if sliders.get('curliness') is not None:
             out['curliness'] = torch.full_like(lat['curliness'], float(sliders['curliness']))
-        move = lambda cur, d, val: cur + (val - cur @ d)[:, None] * d[None]                     # continue_change_with_direction
         if sliders.get('texture') is not None:
             idx, val = sliders['texture']
             out['texture'] = move(lat['texture'], self.texture_dirs[idx], val)
@@ -159,8 +167,34 @@ class EditPipeline:
         sliders = DEFAULT_SLIDERS if sliders is None else sliders
         if labels is None:
             labels = self.parse(img)
-        lat = self.analyse(img, labels)
-        lat = self.apply_sliders(lat, sliders)
+        if not self.overlap:
+            lat = self.analyse(img, labels)
+            lat = self.apply_sliders(lat, sliders)
+            image, mask = self.render(lat, noise=noise, seed=seed, out=out, mask=mask)
+            if stages is not None:
+                stages.update(lat, labels=labels, mask=mask, image=image)
+            return image
+        # The shape branch (encoders -> shape slider -> decoders -> mask) depends on the parsing only, the appearance branch
+        # (Zencoder -> colour MLPs -> sliders -> colour generator) on image + parsing: they meet at the generator.  The
+        # shape branch is a chain of small, latency-bound kernels, so it runs on a side stream underneath the Zencoder's
+        # large convs instead of in front of them (same kernels, same results; ~2 ms per 8 edits).
+        m, S = self.models, img.shape[-1]
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            lab256 = labels if S == 256 else labels[:, ::S // 256, ::S // 256].contiguous()
+            shape, face = m.mask_generator.encode_labels(lab256)
+            shape_new = self.apply_sliders({'shape': shape}, sliders, only_shape=True)['shape']
+            if mask is None:
+                mask = m.mask_generator.decode_labels(shape_new, face)
+        codes = m.generator.encode(img, labels)
+        hair = codes[:, HAIR_IDX].contiguous()
+        stats = m.solver_feature.rgb_model({'code': hair})
+        enc = m.solver_feature.dis({'code': hair})
+        lat = {'shape': shape_new, 'face': face, 'codes': codes, 'rgb_mean': stats['rgb_mean'], 'pca_std': stats['pca_std'],
+               'texture': enc['noise'], 'curliness': enc['noise_curliness']}
+        lat = self.apply_sliders(lat, {k: v for k, v in sliders.items() if k != 'shape'})
+        main.wait_stream(self.side)
         image, mask = self.render(lat, noise=noise, seed=seed, out=out, mask=mask)
         if stages is not None:
             stages.update(lat, labels=labels, mask=mask, image=image)
