@@ -364,7 +364,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     n_aces = ace_index;
     // Run-ahead mode of small jobs (Runner::prepare_all_ahead): a side stream, one join event and one set of buffers per ACE.
     // Only when the handle is sized for interactive work -- for large batches the convs own every CU and nothing co-schedules.
-    if (ahead_pixels < 0) ahead_pixels = (long long)4 * 512 * 512;        // default; option "sean.ahead" overrides (0 = never)
+    if (ahead_pixels < 0) ahead_pixels = (long long)8 * 512 * 512;        // default; option "sean.ahead" overrides (0 = never)
     if (ahead_pixels > 0 && (long long)mb * ms * ms <= ahead_pixels) {
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess)
             return "side stream creation failed";

@@ -88,7 +88,7 @@ struct SeanModel {
     std::vector<hipEvent_t> ev_join;
     std::vector<float*> actv_ahead, lut_ahead;
     float* splitk_side = nullptr;
-    long long ahead_pixels = -1;               // largest B*S*S served in run-ahead mode (-1: default 4 x 512^2)
+    long long ahead_pixels = -1;               // largest B*S*S served in run-ahead mode (-1: default 8 x 512^2)
     int n_aces = 0;
     std::map<std::string, float*> taps;
     // profiling
