@@ -185,6 +185,33 @@ int ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float*
     return CH_OK;
 }
 
+int ch_sean_encode_features(ch_handle* h, const float* img, int B, int S, ch_stream_t stream) {
+    if (!h) return CH_ERR_ARG;
+    if (!h->sean_ready) return fail(h, CH_ERR_STATE, "ch_sean_encode_features: SEAN weights not finalized");
+    if (!img || B < 1) return fail(h, CH_ERR_ARG, "ch_sean_encode_features: bad argument");
+    DeviceGuard guard(h->device);
+    try {
+        std::string e = h->sean.encode(img, nullptr, nullptr, B, S, static_cast<hipStream_t>(stream), 1);
+        if (!e.empty()) return fail(h, CH_ERR_HIP, "ch_sean_encode_features: " + e);
+    } catch (const std::exception& e) {
+        return fail(h, CH_ERR_HIP, std::string("ch_sean_encode_features: ") + e.what());
+    }
+    return CH_OK;
+}
+int ch_sean_encode_regions(ch_handle* h, const uint8_t* labels, float* codes, int B, int S, ch_stream_t stream) {
+    if (!h) return CH_ERR_ARG;
+    if (!h->sean_ready) return fail(h, CH_ERR_STATE, "ch_sean_encode_regions: SEAN weights not finalized");
+    if (!labels || !codes || B < 1) return fail(h, CH_ERR_ARG, "ch_sean_encode_regions: bad argument");
+    DeviceGuard guard(h->device);
+    try {
+        std::string e = h->sean.encode(nullptr, labels, codes, B, S, static_cast<hipStream_t>(stream), 2);
+        if (!e.empty()) return fail(h, CH_ERR_HIP, "ch_sean_encode_regions: " + e);
+    } catch (const std::exception& e) {
+        return fail(h, CH_ERR_HIP, std::string("ch_sean_encode_regions: ") + e.what());
+    }
+    return CH_OK;
+}
+
 #define CH_CALL(name, expr)                                                             \
     if (!h) return CH_ERR_ARG;                                                          \
     DeviceGuard guard(h->device);                                                       \

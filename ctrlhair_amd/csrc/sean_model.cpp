@@ -827,10 +827,17 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
     return "";
 }
 
+// phase: 0 = the whole encoder; 1 = the convolutional part only (feature map stays in the workspace; one chunk: Btot <=
+// max_batch); 2 = the region means over the feature map of the preceding phase-1 call (same Btot, S).  The split lets a caller
+// compute the label map concurrently with the convs: the labels are only needed by the means (architecture.py:185-205).
 std::string SeanModel::encode(const float* img, const uint8_t* labels, float* codes_out, int Btot, int S,
-                              hipStream_t st) {
+                              hipStream_t st, int phase) {
     if (blocks.empty() || !has_zencoder) return "Zencoder weights not loaded/finalized";
     if (S % 32 != 0 || S < 32 || S > max_size) return "S must be a multiple of 32 and <= max_size";
+    if (phase != 0 && Btot > max_batch) return "split encode: B must not exceed max_batch";
+    if (phase == 1) { enc_pending_B = Btot; enc_pending_S = S; }
+    if (phase == 2 && (enc_pending_B != Btot || enc_pending_S != S)) return "split encode: no matching ch_sean_encode_features call";
+    if (phase == 2) enc_pending_B = 0;
     for (int bo = 0; bo < Btot; bo += max_batch) {
         const int B = std::min(max_batch, Btot - bo);
         std::string err;
@@ -846,8 +853,9 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         ConvOpts last = refl;
         last.act = ACT_TANH;
         const int h2 = S / 2, h4 = S / 4;
-        ck(conv3x3_c3_reflect(x, z1_w, z1.bias, hs, B, 32, S, S, st), "zenc conv1");
         const bool f16path = use_sh16 && h4 * h4 >= 4096;
+        if (phase != 2) {
+        ck(conv3x3_c3_reflect(x, z1_w, z1.bias, hs, B, 32, S, S, st), "zenc conv1");
         if (f16path) {
             // every conv after the stem on the f16x3 kernels: InstanceNorm + lrelu -> SH16 -> stride-2 conv (space-to-depth
             // form) -> C4, twice; then the ConvTranspose (f16x3 conv over the zero-inserted view) and the reflection-padded
@@ -931,6 +939,11 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         } else {
             ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
             ck(run_conv(z14, hs, h0, B, h2, h2, last, st), "zenc conv5");
+        }
+        }   // phase != 2
+        if (phase == 1) {
+            if (!err.empty()) return err;
+            continue;
         }
         ck(region_mean(h0, labels + (size_t)bo * S * S, codes_out + (size_t)bo * LABEL_NC * STYLE, B, STYLE, h2, h2, S, st,
                        use_sh16 ? 1 : 0), "region_mean");

@@ -104,7 +104,8 @@ struct SeanModel {
     // the planes generate() draws on device when it is given noise == nullptr, written out explicitly
     std::string draw_noise(uint64_t seed, float* out, int B, int S, hipStream_t stream);
     // Zencoder (style encoder + region average pooling), architecture.py:177-207
-    std::string encode(const float* img, const uint8_t* labels, float* codes_out, int B, int S, hipStream_t stream);
+    std::string encode(const float* img, const uint8_t* labels, float* codes_out, int B, int S, hipStream_t stream, int phase = 0);
+    int enc_pending_B = 0, enc_pending_S = 0;   // split encode: set by phase 1, consumed by phase 2
     void destroy();
 };
 

@@ -26,6 +26,8 @@ SYMBOLS = {
     'ch_sean_generate': (_I, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _I, _I, _VP]),
     'ch_sean_draw_noise': (_I, [_VP, C.c_uint64, _VP, _I, _I, _VP]),
     'ch_sean_encode': (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
+    'ch_sean_encode_features': (_I, [_VP, _VP, _I, _I, _VP]),
+    'ch_sean_encode_regions': (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     'ch_color_generate': (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     'ch_color_encode': (_I, [_VP, _VP, _VP, _I, _VP]),
     'ch_color_predict': (_I, [_VP, _VP, _VP, _I, _VP]),

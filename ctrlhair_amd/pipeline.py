@@ -87,6 +87,8 @@ class EditPipeline:
         self.median = torch.from_numpy(med.astype(np.float32)).to(self.device)
         self.side = torch.cuda.Stream(self.device)      # edit(): the shape branch runs here, underneath the Zencoder
         self.overlap = True
+        self.split_encode = False      # edit(): BiSeNet underneath the Zencoder's convs (ch_sean_encode_features / _regions);
+                                       # measured: no further gain once the shape branch runs aside (tools/edit_modes.py)
         self.mean = torch.tensor(_MEAN, device=self.device).view(1, 3, 1, 1)
         self.std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1)
 
@@ -165,7 +167,19 @@ class EditPipeline:
         parsed label map / the decoded mask (a caller-supplied parsing; the tests use them to step over argmax ties).
         `stages` (optional dict) receives every intermediate tensor."""
         sliders = DEFAULT_SLIDERS if sliders is None else sliders
-        if labels is None:
+        m, S = self.models, img.shape[-1]
+        split_enc = self.overlap and self.split_encode and labels is None and img.shape[0] <= m.generator.max_batch
+        if split_enc:
+            # The Zencoder's convolutions need the image only (the labels enter its region means at the very end): they start
+            # on the main stream while BiSeNet -- ~70 small kernels -- parses the image on the side stream underneath them.
+            main = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(main)
+            m.generator.encode_features(img)
+            with torch.cuda.stream(self.side):
+                labels = self.parse(img)
+                labels_ready = torch.cuda.Event()
+                labels_ready.record(self.side)
+        elif labels is None:
             labels = self.parse(img)
         if not self.overlap:
             lat = self.analyse(img, labels)
@@ -178,16 +192,20 @@ class EditPipeline:
         # (Zencoder -> colour MLPs -> sliders -> colour generator) on image + parsing: they meet at the generator.  The
         # shape branch is a chain of small, latency-bound kernels, so it runs on a side stream underneath the Zencoder's
         # large convs instead of in front of them (same kernels, same results; ~2 ms per 8 edits).
-        m, S = self.models, img.shape[-1]
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)
+        if not split_enc:
+            self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             lab256 = labels if S == 256 else labels[:, ::S // 256, ::S // 256].contiguous()
             shape, face = m.mask_generator.encode_labels(lab256)
             shape_new = self.apply_sliders({'shape': shape}, sliders, only_shape=True)['shape']
             if mask is None:
                 mask = m.mask_generator.decode_labels(shape_new, face)
-        codes = m.generator.encode(img, labels)
+        if split_enc:
+            main.wait_event(labels_ready)
+            codes = m.generator.encode_regions(labels)
+        else:
+            codes = m.generator.encode(img, labels)
         hair = codes[:, HAIR_IDX].contiguous()
         stats = m.solver_feature.rgb_model({'code': hair})
         enc = m.solver_feature.dis({'code': hair})

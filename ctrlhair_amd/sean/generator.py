@@ -96,3 +96,24 @@ class SeanGenerator:
         stream = torch.cuda.current_stream(img.device).cuda_stream
         self.handle.sean_encode(img.data_ptr(), labels.data_ptr(), out.data_ptr(), B, S, stream)
         return out
+
+    def encode_features(self, img: torch.Tensor) -> None:
+        """First half of encode(): the Zencoder's convolutions (B <= max_batch); the feature map stays in the library's
+        workspace until encode_regions().  The label map is not needed yet -- compute it on another stream meanwhile."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3
+        img = img.contiguous()
+        self._enc_shape = (img.shape[0], img.shape[-1], img.device)
+        self.handle.call('ch_sean_encode_features', img.data_ptr(), img.shape[0], img.shape[-1],
+                         torch.cuda.current_stream(img.device).cuda_stream)
+
+    def encode_regions(self, labels: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Second half: region-wise means of the feature map -> codes [B,19,512] (must be ordered after encode_features)."""
+        B, S, dev = self._enc_shape
+        assert labels.is_cuda and labels.dtype == torch.uint8 and tuple(labels.shape) == (B, S, S)
+        labels = labels.contiguous()
+        if out is None:
+            out = torch.empty(B, 19, 512, dtype=torch.float32, device=dev)
+        self.handle.call('ch_sean_encode_regions', labels.data_ptr(), out.data_ptr(), B, S,
+                         torch.cuda.current_stream(dev).cuda_stream)
+        return out
+

@@ -112,6 +112,13 @@ int  ch_sean_draw_noise(ch_handle* h, uint64_t seed, float* noise, int B, int S,
  * Requires the Zencoder.* tensors to have been loaded before ch_finalize. */
 int  ch_sean_encode(ch_handle* h, const float* img, const uint8_t* labels, float* codes, int B, int S,
                     ch_stream_t stream);
+/* The same encoder in two calls, for callers that compute the label map while the convolutions run (the labels only enter
+ * the region means, architecture.py:185-205): ch_sean_encode_features runs the convolutional part and keeps the feature map
+ * in the handle's workspace; ch_sean_encode_regions reduces it to codes.  One chunk (B <= max_batch); the second call must
+ * follow the first with the same B, S (else CH_ERR_HIP), with no other SEAN call on the handle in between, and be ordered
+ * after it (same stream, or an event).  ch_sean_encode(img, labels, codes) == features(img); regions(labels, codes). */
+int  ch_sean_encode_features(ch_handle* h, const float* img, int B, int S, ch_stream_t stream);
+int  ch_sean_encode_regions(ch_handle* h, const uint8_t* labels, float* codes, int B, int S, ch_stream_t stream);
 
 /* ---- colour / texture branch (three MLPs on 512-d hair style codes) -------------------------------------------
  * Tensor names: the reference state-dict keys prefixed "gen." (EigenGenerator, model_eigengan.py:34-84), "dis."

@@ -68,3 +68,23 @@ def test_size_not_a_multiple_of_the_tiles(hip_lib):
     codes = g.encode(torch.from_numpy(img).to(g.device), torch.from_numpy(lab).to(g.device))
     torch.cuda.synchronize()
     assert float(np.abs(codes.cpu().numpy() - ref).max()) <= TOL
+
+
+def test_split_encode_equals_encode(hip_lib):
+    """ch_sean_encode_features + ch_sean_encode_regions == ch_sean_encode (the same kernels; the region means accumulate with
+    float atomics, so equality is up to their summation order), and a regions call without its features call is refused."""
+    from ctrlhair_amd import procedural as P
+    g = gen('f16x3')
+    B, S = 2, 256
+    lab = torch.from_numpy(P.blocky_labels(B, S, grid=8, seed=29)).to(g.device)
+    img = torch.from_numpy(P.synthetic_images(B, S, seed=30)).to(g.device)
+    whole = g.encode(img, lab)
+    g.encode_features(img)
+    parts = g.encode_regions(lab)
+    torch.cuda.synchronize()
+    again = g.encode(img, lab)
+    torch.cuda.synchronize()
+    print('run-to-run', float((whole - again).abs().max()), 'split vs whole', float((whole - parts).abs().max()))
+    assert float((whole - parts).abs().max()) <= 1e-6
+    with pytest.raises(RuntimeError):
+        g.encode_regions(lab)                  # consumed: needs a new encode_features
