@@ -365,7 +365,10 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     // Run-ahead mode of small jobs (Runner::prepare_all_ahead): a side stream, one join event and one set of buffers per ACE.
     // Only when the handle is sized for interactive work -- for large batches the convs own every CU and nothing co-schedules.
     if (ahead_pixels < 0) ahead_pixels = (long long)8 * 512 * 512;        // default; option "sean.ahead" overrides (0 = never)
-    if (ahead_pixels > 0 && (long long)mb * ms * ms <= ahead_pixels) {
+    // Larger jobs keep the (HBM-write-bound) label-table kernels inline and run only the style LUT builds -- small,
+    // latency-bound GEMMs -- ahead (ahead_full = false).
+    if (ahead_pixels > 0) {
+        ahead_full = (long long)mb * ms * ms <= ahead_pixels;
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess)
             return "side stream creation failed";
         ev_join.assign(n_aces, nullptr);
@@ -378,7 +381,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a) continue;
                 const size_t r = (size_t)ms / a->res_div;
-                actv_ahead[a->index] = B.falloc((size_t)mb * r * r * HID);
+                if (ahead_full) actv_ahead[a->index] = B.falloc((size_t)mb * r * r * HID);
                 if (a->styled) lut_ahead[a->index] = B.falloc(npad_b * 18 * a->C);
             }
         splitk_side = B.falloc((size_t)splitk_cap);
@@ -533,8 +536,9 @@ struct Runner {
         const float* lut = nullptr;
         int lut_rs = 1, lut_ns = 0, lut_bs = LABEL_NC;
     };
+    // what: bit 0 = style LUT, bit 1 = SPADE hidden activations
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
-                        float* splitk, bool prof) {
+                        float* splitk, bool prof, int what = 3) {
         const int r = S / a.res_div;
         const uint8_t* lab = labels_at(labfull, a.res_div);
         AcePrep q;
@@ -544,7 +548,7 @@ struct Runner {
             if (prof) timed(2, flops, bytes, launch);
             else launch();
         };
-        if (a.styled) {
+        if (a.styled && (what & 1)) {
             q.lut = lut_buf;
             // f16x3 path: one extra all-zero column per sample (mu = 0 -> LUT = 0) that taps outside the image point at
             const int bs = m.use_sh16 ? LABEL_NC + 1 : LABEL_NC;
@@ -605,6 +609,7 @@ struct Runner {
                 tm(fl, by, [&] { check(conv_nhwc1x1(p, s), "lut gemm"); });
             }
         }
+        if (!(what & 2)) return q;
         if (m.use_sh16)
             check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2), "mlp_shared");
         else
@@ -614,18 +619,20 @@ struct Runner {
 
     // Small jobs (interactive renders: the chip is mostly empty) run every ACE's prepare step AHEAD on the model's side
     // stream, into per-ACE buffers, while the main stream walks the dependent chain of convs; an event per ACE joins them.
-    bool ahead = false;
+    // full = false (large jobs): only the style LUT builds run ahead; the label-table kernels stay inline.
+    bool ahead = false, ahead_luts = false;
     std::vector<AcePrep> prepared;
-    void prepare_all_ahead(const uint8_t* labfull, const float* codes) {
-        ahead = true;
+    void prepare_all_ahead(const uint8_t* labfull, const float* codes, bool full) {
+        ahead = full;
+        ahead_luts = !full;
         prepared.assign(m.n_aces, AcePrep());
         check(hipEventRecord(m.ev_fork, st), "fork");
         check(hipStreamWaitEvent(m.side, m.ev_fork, 0), "fork wait");
         for (const auto& b : m.blocks)
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
-                if (!a) continue;
+                if (!a || (!full && !a->styled)) continue;
                 prepared[a->index] = ace_prepare(*a, labfull, codes, m.side, m.actv_ahead[a->index], m.lut_ahead[a->index],
-                                                 m.splitk_side, false);
+                                                 m.splitk_side, false, full ? 3 : 1);
                 check(hipEventRecord(m.ev_join[a->index], m.side), "join record");
             }
     }
@@ -639,6 +646,11 @@ struct Runner {
         AcePrep q;
         if (ahead) {
             q = prepared[a.index];
+            check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
+        } else if (ahead_luts && a.styled) {
+            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2);     // label table inline
+            q = prepared[a.index];
+            q.actv = m.actv;
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else {
             q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true);
@@ -777,7 +789,10 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
                                       amax_slots, pass, terms == 2, st), "fc_mu (all ACEs)");
         }
         // interactive-size jobs: everything that depends on labels / codes only runs ahead on the side stream
-        if (side && !prof_on && !(dbg & 4096) && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd);
+        if (side && !prof_on && !(dbg & 4096)) {
+            if (ahead_full && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd, true);
+            else if (use_sh16 && fcmu_batched && !(dbg & 8192)) R.prepare_all_ahead(lab, cd, false);
+        }
 
         const int sw = S / 32;
         float* x = xa;

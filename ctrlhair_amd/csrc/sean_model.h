@@ -87,6 +87,7 @@ struct SeanModel {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     std::vector<float*> actv_ahead, lut_ahead;
+    bool ahead_full = false;                   // handle sized for the full run-ahead mode (else: style LUTs only)
     float* splitk_side = nullptr;
     long long ahead_pixels = -1;               // largest B*S*S served in run-ahead mode (-1: default 8 x 512^2)
     int n_aces = 0;

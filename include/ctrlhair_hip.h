@@ -64,7 +64,8 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  * "sean.ahead" (default 8): run-ahead mode -- when a batch chunk holds at most `value` x 512x512 pixels, the kernels of the
  *   18 ACE layers that depend only on the label map and the style codes (label tables, fc_mu, style LUTs) run on an internal
  *   side stream into per-layer buffers, joined to `stream` by events (interactive latency: 3.3 -> 2.65 ms at 256x256; still
- *   1.6 % at 8 x 512x512, nothing at 16 x 512x512, where the convs own every CU); 0 = off.
+ *   1.6 % at 8 x 512x512).  Handles sized for larger chunks run only the style LUT builds (small GEMMs) ahead and keep the
+ *   HBM-write-bound label-table kernels inline (1 % at 16 x 512x512; with the label tables ahead too: no gain).  0 = off.
  * "shape.f16x3" (default 1): the shape VAE's convs run on the same f16x3 split-operand kernels -- encoder layers 0-3 (k4,
  *   stride 2: space-to-depth staging), decoder layers 1-6 and the output convs; LayerNorm outputs and the one-hot / sin-cos
  *   inputs are bounded, so their scales are static; 0 = every conv on the exact-f32 kernels.
