@@ -182,30 +182,28 @@ __global__ __launch_bounds__(1024) void instnorm_c4_sh16_kernel(const float4* __
     const int G = C >> 3, b = blockIdx.x / G, g = blockIdx.x % G;
     const float4* p0 = x + ((long long)b * (C >> 2) + g * 2) * HW;
     const float4* p1 = p0 + HW;
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < HW; i += 1024) {
-        const float4 a = p0[i], c = p1[i];
-        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
-        s[4] += c.x; s[5] += c.y; s[6] += c.z; s[7] += c.w;
-    }
-    float mean[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) mean[c] = block_sum1024(s[c], red) / HW;
-    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // statistics in ONE pass over the plane (it does not fit any cache: a second pass is another HBM read), as shifted sums
+    // s = sum(x - K), q = sum((x - K)^2) with K = the channel's first element: mean = K + s/n, var = q/n - (s/n)^2 -- the
+    // shift keeps |s/n| at the scale of the deviations, so the subtraction does not cancel
+    const float4 ka = p0[0], kc = p1[0];
+    const float K[8] = {ka.x, ka.y, ka.z, ka.w, kc.x, kc.y, kc.z, kc.w};
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < HW; i += 1024) {
         const float4 a = p0[i], c = p1[i];
         const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float d = v[e] - mean[e];
+            const float d = v[e] - K[e];
+            s[e] += d;
             q[e] += d * d;
         }
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const float var = block_sum1024(q[c], red) / HW;
+        const float sm = block_sum1024(s[c], red) / HW;
+        const float var = fmaxf(block_sum1024(q[c], red) / HW - sm * sm, 0.f);
         if (threadIdx.x == 0) {
-            mean_s[c] = mean[c];
+            mean_s[c] = K[c] + sm;
             rstd_s[c] = 1.f / sqrtf(var + eps);
         }
     }
@@ -250,34 +248,28 @@ __global__ __launch_bounds__(1024) void instnorm_slice_stats_kernel(const float*
     __shared__ float red[16];
     const int G = C >> 3, b = blockIdx.x / G, g = blockIdx.x % G, k = blockIdx.y, NS = gridDim.y;
     const int lo = k * per, hi = lo + per < HW ? lo + per : HW;
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
-        float v[8];
-        instnorm_load8<IN_C4>(x, b, g, C, HW, i, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += v[e];
-    }
-    const float cnt = (float)(hi - lo);
-    float mean[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) mean[e] = block_sum1024(s[e], red) / cnt;
-    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one pass: shifted sums around the slice's first pixel (see instnorm_c4_sh16_kernel)
+    float K[8];
+    instnorm_load8<IN_C4>(x, b, g, C, HW, lo, K);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = lo + threadIdx.x; i < hi; i += 1024) {
         float v[8];
         instnorm_load8<IN_C4>(x, b, g, C, HW, i, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float d = v[e] - mean[e];
+            const float d = v[e] - K[e];
+            s[e] += d;
             q[e] += d * d;
         }
     }
+    const float cnt = (float)(hi - lo);
     float* o = stats + ((long long)blockIdx.x * NS + k) * 16;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float m2 = block_sum1024(q[e], red);
+        const float st = block_sum1024(s[e], red), qt = block_sum1024(q[e], red);
         if (threadIdx.x == 0) {
-            o[e * 2] = mean[e];
-            o[e * 2 + 1] = m2;
+            o[e * 2] = K[e] + st / cnt;                          // slice mean
+            o[e * 2 + 1] = fmaxf(qt - st * st / cnt, 0.f);       // slice M2 = sum (x - mean)^2
         }
     }
 }
