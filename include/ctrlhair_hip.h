@@ -66,7 +66,7 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   side stream into per-layer buffers, joined to `stream` by events (interactive latency: 3.3 -> 2.65 ms at 256x256; still
  *   1.6 % at 8 x 512x512).  Handles sized for larger chunks run only the style LUT builds (small GEMMs) ahead and keep the
  *   HBM-write-bound label-table kernels inline (1 % at 16 x 512x512; with the label tables ahead too: no gain).  0 = off.
- * "shape.f16x3" (default 1): the shape VAE's convs run on the same f16x3 split-operand kernels -- encoder layers 0-3 (k4,
+ * "shape.f16x3" (default 1): the shape VAE's convs run on the same f16x3 split-operand kernels -- all encoder layers (k4,
  *   stride 2: space-to-depth staging), decoder layers 1-6 and the output convs; LayerNorm outputs and the one-hot / sin-cos
  *   inputs are bounded, so their scales are static; 0 = every conv on the exact-f32 kernels.
  * "bisenet.f16x3" (default 1): BiSeNet's convs on the f16x3 kernels; its f32 activations stay in the C4 layout and are split
