@@ -1,0 +1,91 @@
+// ace_sparse.h -- the exact SPADE-interior reduction of the ACE layers (hard part (iii)).
+//
+// SPADE.forward (/root/reference/sean_codes/models/networks/normalization.py:249-257) is
+//      actv = relu(conv3x3_{19->128}(onehot));  gamma = conv3x3_{128->C}(actv);  beta = conv3x3_{128->C}(actv)
+// so gamma/beta at pixel p depend on the labels of the 5x5 neighbourhood of p only.  Where that neighbourhood is uniform
+// (one label j, entirely inside the image -- both convs zero-pad) every tap sees the same hidden vector
+//      a_j = relu(b_shared + sum_t' W_shared[:, j, t'])
+// and gamma/beta are per-label constants  G_j = b + (sum_t W[:, :, t]) a_j  (tables built once at ch_finalize, in double).
+// The style term of a styled ACE (normalization.py:117-153,172-173: conv_gamma/conv_beta on the piecewise-constant style map)
+// is likewise sum_t P[(sample, j), t] there.  So:
+//   * INTERIOR pixels (5x5-uniform): no convolution at all -- an elementwise pass (ace_interior) modulates x with the
+//     per-(sample, label) table row;
+//   * BOUNDARY pixels (everything else, including the 2-pixel frame of the image and labels >= 19) are compacted per spatial
+//     tile into 32-pixel MFMA sub-tiles and go through the dense SPADE conv + fused ACE epilogue (conv_ace_sparse.h /
+//     conv_sh16.h), whose B-fragment addresses are per lane anyway.
+// Identities in real arithmetic; in fp32 the interior value is the same sum in another association (1e-6 level).
+//
+// Per resolution level and generate() chunk, ace_classify builds
+//      u5   [B][H][W]  uint8   label if the pixel is interior, else 255
+//      cnt  [ntiles]   int     boundary pixels of the tile (tiles of 32 x TH pixels, one sample each)
+//      list [ntiles][32*TH] uint16  their in-tile offsets ty*32+tx in raster order
+// and ace_worklist turns the counts into the list of block tasks of one conv launch (depends on the row tiles of the layer):
+// a tile's NS = ceil(cnt/32) sub-tiles are split into `ng` groups of at most 4 (one group = the N extent of one wave), each
+// group meets every 64-row wave tile: ng * mtiles wave tasks, 4 per block (group-major, so that the 4 waves of a block share
+// the group when mtiles % 4 == 0 and only the A rows differ).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chk {
+
+// sub-tile groups of a tile with NS sub-tiles for a layer with `mtiles` 64-row wave tiles: `ng` groups of `per` (last: rest)
+__host__ __device__ inline void sparse_groups(int NS, int mtiles, int& ng, int& per) {
+    if (NS <= 0) {
+        ng = 0;
+        per = 0;
+        return;
+    }
+    int g = (NS + 3) >> 2;
+    while (((g * mtiles) & 3) && g < NS) ++g;      // few row tiles: more, smaller groups so that all 4 waves of a block work
+    per = (NS + g - 1) / g;
+    ng = (NS + per - 1) / per;
+}
+
+// block tasks of a tile of 32 x TH pixels in the dense case (every pixel a boundary pixel): sizes work lists and grids
+__host__ __device__ inline int sparse_max_tasks(int TH, int mtiles) {
+    int ng, per;
+    sparse_groups(TH, mtiles, ng, per);
+    return (ng * mtiles + 3) / 4;
+}
+
+struct SparseLevel {            // device buffers of one resolution level (sean_model.cpp allocates them at build())
+    uint8_t* u5 = nullptr;
+    uint16_t* list = nullptr;
+    int* cnt = nullptr;
+    int TH = 8;                 // tile height the level was classified with (tiles are 32 wide)
+    int cap_tiles = 0;
+};
+struct SparseWork {             // block tasks of one (level, mtiles) pair
+    unsigned* work = nullptr;   // tile | (block task within the tile << 20)
+    int* total = nullptr;       // [0] number of block tasks, [1] boundary pixels, [2] sub-tiles (x32 = pixels the MFMAs run over)
+                                // [3] wave tasks x sub-tiles (x 32 x 64 rows = accumulators computed)
+    int mtiles = 0;
+    long long cap = 0;
+};
+
+// lab: [B][H][W] labels of the level.  Tiles of 32 x TH pixels (TH = 8 or 16).
+hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint16_t* list, int* cnt, int B, int H, int W, int TH, hipStream_t s);
+hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s);
+// gtab[b][j][gamma|beta][C] = bias + gconst[j] + sum_t lut[(t, gamma|beta, c)][(b, j)]   (lut may be null: unstyled ACE)
+// lut element (row = (t*2+gb)*C + c, n = b*lut_bs + j) at lut[row*lut_rs + n*lut_ns]; lut_mul undoes a pre-multiplied LUT
+hipError_t ace_gtable(const float* bias_g, const float* bias_b, const float* gconst, const float* lut, int lut_rs, int lut_ns,
+                      int lut_bs, float lut_mul, float* gtab, int B, int C, hipStream_t s);
+
+struct AceInteriorParams {
+    const float* x;             // exact-f32 path: NCHW [B][C][H>>x_up][W>>x_up]; f16x3 path: C4 [B][C/4][h][w][4]
+    void* out;                  // NCHW f32 / SH16
+    const uint8_t* u5;
+    const float* gtab;          // [B][19][2][C]
+    const float *bn_a, *bn_d, *nv;
+    const float* noise;         // plane base of this ACE, sample stride noise_bstride, layout [W][H]
+    long long noise_bstride;
+    int B, C, H, W, x_up, act;
+    // f16x3 path (SH16 output): first-pass scale, the producer's slot, pass (0 record max / 1 rewrite if the max left the window)
+    float out_scale;
+    unsigned* out_amax;
+    int pass, bf16;
+};
+hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s);
+
+}  // namespace chk

@@ -343,6 +343,15 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.ahead_pixels = (long long)value * 512 * 512;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.sparse") == 0) {     // exact SPADE-interior reduction (ace_sparse.h); buffers are sized at ch_finalize
+        h->sean.sparse = value != 0;
+        return CH_OK;
+    }
+    if (std::strcmp(key, "sean.sparse_min") == 0) { // smallest ACE resolution served by the sparse path
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.sparse_min) must precede ch_finalize");
+        h->sean.sparse_min_r = value;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.dbg_sel") == 0) {
         h->sean.dbg_sel = value;
         return CH_OK;
@@ -361,9 +370,15 @@ int ch_profile_enable(ch_handle* h, int on) {
 }
 
 int ch_profile_read(ch_handle* h, int kind, int* launches, double* total_ms, double* flops, double* bytes) {
+    return ch_profile_read_ex(h, kind, launches, total_ms, flops, nullptr, bytes);
+}
+
+int ch_profile_read_ex(ch_handle* h, int kind, int* launches, double* total_ms, double* flops, double* flops_executed,
+                       double* bytes) {
     if (!h) return CH_ERR_ARG;
+    DeviceGuard guard(h->device);
     int n = 0;
-    double ms = 0, fl = 0, by = 0;
+    double ms = 0, fl = 0, fx = 0, by = 0;
     for (auto& r : h->sean.prof) {
         if (hipEventSynchronize(r.e1) != hipSuccess) return fail(h, CH_ERR_HIP, "hipEventSynchronize failed");
         if (kind < 0 || r.kind == kind) {
@@ -371,10 +386,19 @@ int ch_profile_read(ch_handle* h, int kind, int* launches, double* total_ms, dou
             if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return fail(h, CH_ERR_HIP, "hipEventElapsedTime failed");
             ms += t;
             fl += r.flops;
+            if (r.sp_stat) {        // sparse ACE launch: the matrix cores ran over the compacted boundary sub-tiles only
+                int st[4] = {0, 0, 0, 0};
+                if (hipMemcpy(st, r.sp_stat, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
+                    return fail(h, CH_ERR_HIP, "ch_profile_read: work-list statistics read failed");
+                fx += (double)st[3] * r.sp_flops_unit;
+            } else {
+                fx += r.flops;
+            }
             by += r.bytes;
             ++n;
         }
     }
+    if (flops_executed) *flops_executed = fx;
     if (kind < 0 || true) {
         // records are consumed only by a read with kind < 0 (read specific kinds first)
         if (kind < 0) {

@@ -94,6 +94,11 @@ struct ConvParams {
                             // and the first phase (0: 2x2-tap form of a k3 / k4 pad-1 kernel; 3: 1x1 stride-2 conv)
     int mtiles_hint_small;  // set by the caller when the layer has few tiles (prefer the split-K path over the persistent kernel)
     int dbg;                // perf experiments only: 1 = skip staging after chunk 0, 2 = skip the MFMA loop
+    // exact SPADE-interior reduction (ace_sparse.h): boundary pixels of the level's tiles and the block tasks of this launch
+    const uint16_t* sp_list;
+    const int* sp_cnt;
+    const unsigned* sp_work;
+    const int* sp_total;
     // EPI_NHWC
     int npix_valid;         // number of valid linear pixels (y*W+x < npix_valid)
 };

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstring>
 
+#include "ace_sparse.h"
+#include "conv_ace_sparse.h"
 #include "conv_mfma.h"
 #include "conv_sh16.h"
 #include "kernels.h"
@@ -234,6 +236,33 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 const float w = (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t];
                 return w * (beta ? sb : sg);
             };
+            {   // per-label constants of the SPADE gamma/beta for pixels with a uniform 5x5 label neighbourhood (ace_sparse.h):
+                // every tap sees a_j = relu(b_shared + sum_t' W_shared[:, j, t']), so gamma_j = (sum_t W[:, :, t]) a_j.  Double.
+                std::vector<double> aj((size_t)LABEL_NC * HID);
+                for (int j = 0; j < LABEL_NC; ++j)
+                    for (int k = 0; k < HID; ++k) {
+                        double v = bs->f32()[k];
+                        for (int t = 0; t < 9; ++t) v += T[((size_t)j * 9 + t) * HID + k];
+                        aj[(size_t)j * HID + k] = v > 0.0 ? v : 0.0;
+                    }
+                std::vector<float> gc((size_t)LABEL_NC * 2 * C);
+                std::vector<double> wsum(HID);
+                for (int gb = 0; gb < 2; ++gb)
+                    for (int c = 0; c < C; ++c) {
+                        const float* w = (gb ? wbp : wgp) + (size_t)c * HID * 9;
+                        for (int k = 0; k < HID; ++k) {
+                            double acc = 0.0;
+                            for (int t = 0; t < 9; ++t) acc += w[k * 9 + t];
+                            wsum[k] = acc;
+                        }
+                        for (int j = 0; j < LABEL_NC; ++j) {
+                            double acc = 0.0;
+                            for (int k = 0; k < HID; ++k) acc += wsum[k] * aj[(size_t)j * HID + k];
+                            gc[((size_t)j * 2 + gb) * C + c] = (float)(acc * (gb ? sb : sg));
+                        }
+                    }
+                a.gconst = B.upload(gc);
+            }
             if (use_sh16) {
                 auto kexp = sh16_row_exponents(tiles * 64, HID, 3, getsp);
                 for (int t0 = 0; t0 < tiles * 64; t0 += 64) {     // one power of two per 64-row wave tile (a scalar in the ACE epilogue)
@@ -436,6 +465,44 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     xs = static_cast<float*>(B.dalloc(outmax * 4));
     xa = static_cast<float*>(B.dalloc(outmax * 4));
     xb = static_cast<float*>(B.dalloc(outmax * 4));
+    // ---- exact SPADE-interior reduction: classification buffers per level, work lists per (level, row tiles) ------------
+    for (int k = 0; k < 6; ++k) {
+        sp_level[k] = SparseLevel();
+        sp_work[k].clear();
+    }
+    gtab = nullptr;
+    if (sparse && !use_sh16) {
+        int cmax = 0;
+        for (const auto& b : blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
+                if (!a) continue;
+                int k = 0;
+                while ((1 << k) < a->res_div) ++k;
+                const int r = ms >> k;
+                if (r < sparse_min_r || r < 32) continue;
+                SparseLevel& L = sp_level[k];
+                if (!L.u5) {
+                    L.TH = 8;
+                    L.cap_tiles = mb * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
+                    L.u5 = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
+                    L.list = static_cast<uint16_t*>(B.dalloc((size_t)L.cap_tiles * 32 * L.TH * sizeof(uint16_t)));
+                    L.cnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
+                }
+                const int mt = (a->C + 31) / 32;
+                bool have = false;
+                for (const auto& w : sp_work[k]) have = have || w.mtiles == mt;
+                if (!have) {
+                    SparseWork w;
+                    w.mtiles = mt;
+                    w.cap = (long long)L.cap_tiles * sparse_max_tasks(L.TH, mt);
+                    w.work = static_cast<unsigned*>(B.dalloc((size_t)w.cap * sizeof(unsigned)));
+                    w.total = static_cast<int*>(B.dalloc(4 * sizeof(int)));
+                    sp_work[k].push_back(w);
+                }
+                cmax = std::max(cmax, a->C);
+            }
+        if (cmax) gtab = B.falloc((size_t)mb * LABEL_NC * 2 * cmax);
+    }
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "hipDeviceSynchronize failed after weight upload";
     return "";
@@ -487,7 +554,9 @@ struct Runner {
         return e;
     }
     template <class F>
-    void timed(int kind, double flops, double bytes, F launch) {
+    void timed(int kind, double flops, double bytes, F launch) { timed(kind, flops, bytes, nullptr, 0.0, launch); }
+    template <class F>
+    void timed(int kind, double flops, double bytes, const int* sp_stat, double sp_unit, F launch) {
         if (!m.prof_on) {
             launch();
             return;
@@ -496,6 +565,8 @@ struct Runner {
         r.kind = kind;
         r.flops = flops;
         r.bytes = bytes;
+        r.sp_stat = sp_stat;
+        r.sp_flops_unit = sp_unit;
         r.e0 = ev();
         r.e1 = ev();
         check(hipEventRecord(r.e0, st), "hipEventRecord");
@@ -521,6 +592,32 @@ struct Runner {
         auto it = m.taps.find(name);
         if (it != m.taps.end() && it->second)
             check(hipMemcpyAsync(it->second, src, floats * 4, hipMemcpyDeviceToDevice, st), "tap copy");
+    }
+    // exact SPADE-interior reduction: the level's classification and the work list of (level, row tiles), once per chunk
+    bool lvl_done[6] = {false, false, false, false, false, false};
+    std::vector<int> work_done[6];
+    const SparseWork* sparse_prepare(const AceW& a, const uint8_t* lab, int r) {
+        int k = 0;
+        while ((1 << k) < a.res_div) ++k;
+        const SparseLevel& L = m.sp_level[k];
+        if (!m.sparse || !L.u5 || r < m.sparse_min_r || r < 32) return nullptr;
+        const int ntiles = B * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
+        if (!lvl_done[k]) {
+            check(ace_classify(lab, L.u5, L.list, L.cnt, B, r, r, L.TH, st), "ace_classify");
+            lvl_done[k] = true;
+        }
+        const int mt = (a.C + 31) / 32;
+        for (const auto& w : m.sp_work[k])
+            if (w.mtiles == mt) {
+                bool done = false;
+                for (int d : work_done[k]) done = done || d == mt;
+                if (!done) {
+                    check(ace_worklist(L.cnt, ntiles, mt, w.work, w.total, st), "ace_worklist");
+                    work_done[k].push_back(mt);
+                }
+                return &w;
+            }
+        return nullptr;
     }
     const uint8_t* labels_at(const uint8_t* full, int res_div) {
         if (res_div == 1) return full;
@@ -690,7 +787,39 @@ struct Runner {
         p.out_amax = m.amax_slots + 2 * a.index;
         if ((m.dbg & 256) && a.index == m.dbg_sel) p.partial = m.splitk_ws;      // cycle stamps of this launch (profiling)
         else p.dbg &= ~256;
-        timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] {
+        const SparseWork* sw = m.use_sh16 ? nullptr : sparse_prepare(a, lab, r);
+        timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), sw ? sw->total : nullptr,
+              32.0 * 64 * 2.0 * HID * 9, [&] {
+            if (!m.use_sh16 && sw) {
+                // interior pixels: elementwise with the per-(sample, label) gamma/beta rows; boundary pixels: compacted conv
+                int lk = 0;
+                while ((1 << lk) < a.res_div) ++lk;
+                const SparseLevel& L = m.sp_level[lk];
+                check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
+                AceInteriorParams ip{};
+                ip.x = x;
+                ip.out = hout;
+                ip.u5 = L.u5;
+                ip.gtab = m.gtab;
+                ip.bn_a = a.bn_a;
+                ip.bn_d = a.bn_d;
+                ip.nv = a.nv;
+                ip.noise = noise + noff;
+                ip.noise_bstride = (long long)nf;
+                ip.B = B;
+                ip.C = a.C;
+                ip.H = r;
+                ip.W = r;
+                ip.x_up = x_up;
+                ip.act = act;
+                check(ace_interior_f32(ip, st), "ace interior");
+                p.sp_list = L.list;
+                p.sp_cnt = L.cnt;
+                p.sp_work = sw->work;
+                p.sp_total = sw->total;
+                check(conv_ace_sparse(p, L.TH, st), "spade conv (boundary pixels)");
+                return;
+            }
             if (!m.use_sh16) {
                 check(conv_ace(p, st), "spade conv");
                 return;

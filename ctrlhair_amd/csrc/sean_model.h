@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "ace_sparse.h"
 #include "net_common.h"
 
 namespace chk {
@@ -34,6 +35,8 @@ struct AceW {
     float out_scale = 8.f;                      // f16x3 path: first-pass SH16 scale of this ACE's output (SH16_ACT_SCALE; the
                                                 //   shortcut's ace_s carries the 2^D aligning conv_s with conv_1, sean_model.cpp)
     float actv_scale = 1.f;                     // f16x3 path: SH16 scale of the SPADE hidden activations (from a table bound)
+    float* gconst = nullptr;                    // [19][gamma|beta][C]: SPADE gamma/beta of a pixel whose 5x5 label neighbourhood
+                                                //   is uniformly j (blend factor folded in, biases not) -- ace_sparse.h
 };
 
 struct BlockW {
@@ -47,7 +50,9 @@ struct BlockW {
 struct ProfRec {
     hipEvent_t e0, e1;
     int kind;       // 0 plain conv, 1 ACE conv, 2 LUT gemm
-    double flops, bytes;
+    double flops, bytes;            // flops: the dense evaluation of the layer (every pixel through the conv)
+    const int* sp_stat = nullptr;   // sparse ACE launch: SparseWork::total of its work list (read back at ch_profile_read)
+    double sp_flops_unit = 0.0;     //   executed FLOPs = sp_stat[3] * sp_flops_unit
 };
 
 struct SeanModel {
@@ -91,6 +96,13 @@ struct SeanModel {
     float* splitk_side = nullptr;
     long long ahead_pixels = -1;               // largest B*S*S served in run-ahead mode (-1: default 8 x 512^2)
     int n_aces = 0;
+    // exact SPADE-interior reduction (ace_sparse.h): per resolution level (index = log2(res_div)) the classification buffers
+    // and one work list per distinct number of 64-row tiles among the level's ACEs; gtab: [max_batch][19][2][C max]
+    int sparse = 1;                            // option "sean.sparse" (0 = every pixel through the conv)
+    int sparse_min_r = 64;                     // option "sean.sparse_min": smallest resolution served by the sparse path
+    SparseLevel sp_level[6];
+    std::vector<SparseWork> sp_work[6];
+    float* gtab = nullptr;
     std::map<std::string, float*> taps;
     // profiling
     bool prof_on = false;

@@ -42,6 +42,7 @@ SYMBOLS = {
     'ch_sean_debug_read': (_I, [_VP, _VP, C.c_size_t]),
     'ch_profile_enable': (_I, [_VP, _I]),
     'ch_profile_read': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
+    'ch_profile_read_ex': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
 }
 
 _lib = None
@@ -137,10 +138,12 @@ class Handle:
         self._check(self.lib.ch_profile_enable(self._h, int(on)), 'ch_profile_enable')
 
     def profile_read(self, kind: int = -1):
-        n, ms, fl, by = _I(), _D(), _D(), _D()
-        self._check(self.lib.ch_profile_read(self._h, kind, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)),
-                    'ch_profile_read')
-        return {'launches': n.value, 'ms': ms.value, 'flops': fl.value, 'bytes': by.value}
+        """'flops': the dense evaluation of the recorded layers; 'flops_executed': what the matrix cores ran (smaller for
+        ACE launches on the exact SPADE-interior reduction, csrc/ace_sparse.h)."""
+        n, ms, fl, fx, by = _I(), _D(), _D(), _D(), _D()
+        self._check(self.lib.ch_profile_read_ex(self._h, kind, C.byref(n), C.byref(ms), C.byref(fl), C.byref(fx), C.byref(by)),
+                    'ch_profile_read_ex')
+        return {'launches': n.value, 'ms': ms.value, 'flops': fl.value, 'flops_executed': fx.value, 'bytes': by.value}
 
     def close(self):
         if getattr(self, '_h', None):

@@ -198,6 +198,13 @@ int  ch_sean_debug_read(ch_handle* h, void* host_out, size_t bytes);
  * duration (ms) and summed algorithmic flops / bytes.  A read with kind < 0 also clears the records. */
 int  ch_profile_enable(ch_handle* h, int on);
 int  ch_profile_read(ch_handle* h, int kind, int* launches, double* total_ms, double* flops, double* bytes);
+/* As ch_profile_read; additionally `flops_executed`: the FLOPs the matrix cores actually ran.  They differ from `flops`
+ * (the dense evaluation of every layer) for ACE launches served by the exact SPADE-interior reduction (option "sean.sparse",
+ * ctrlhair_amd/csrc/ace_sparse.h): gamma/beta of SPADE.forward (/root/reference/sean_codes/models/networks/
+ * normalization.py:249-257) depend on the 5x5 label neighbourhood only, so pixels whose neighbourhood is uniform take
+ * per-label constants and only the compacted boundary pixels go through the conv. */
+int  ch_profile_read_ex(ch_handle* h, int kind, int* launches, double* total_ms, double* flops, double* flops_executed,
+                        double* bytes);
 
 #ifdef __cplusplus
 }

@@ -22,25 +22,7 @@ import refharness as R                        # noqa: E402
 CROPS = [(0, 0), (37, 101), (128, 64), (-64, -64)]   # top-left corners of 64x64 crops (negative = from end)
 
 
-def face_like_labels(S, seed):
-    """Concentric/elliptic blobs roughly like a parsing map (background, skin, hair cap, eyes, mouth...)."""
-    rng = np.random.Generator(np.random.Philox(key=[seed, 77]))
-    yy, xx = np.mgrid[0:S, 0:S].astype(np.float32) / S
-    lab = np.zeros((S, S), np.uint8)
-    def ell(cx, cy, rx, ry): return ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 < 1
-    lab[ell(.5, .45, .42, .48)] = 13          # hair
-    lab[ell(.5, .55, .27, .35)] = 1           # skin
-    lab[ell(.5, .95, .22, .2)] = 17           # neck
-    lab[ell(.5, 1.1, .5, .2)] = 18            # cloth
-    lab[ell(.38, .48, .06, .03)] = 4; lab[ell(.62, .48, .06, .03)] = 5      # eyes
-    lab[ell(.38, .42, .08, .015)] = 6; lab[ell(.62, .42, .08, .015)] = 7    # brows
-    lab[ell(.5, .6, .05, .08)] = 2            # nose
-    lab[ell(.5, .74, .1, .03)] = 11; lab[ell(.5, .77, .09, .025)] = 12      # lips
-    lab[ell(.22, .55, .03, .08)] = 8; lab[ell(.78, .55, .03, .08)] = 9      # ears
-    j = rng.integers(0, S - 8, size=(6, 2))
-    for (a, b) in j:                           # a few tiny specks that vanish at low resolution
-        lab[a:a + 3, b:b + 3] = 15
-    return lab
+face_like_labels = P.face_like_labels      # (moved to the package: bench.py's face-like workload variant uses it too)
 
 
 def summarize(img):

@@ -1,0 +1,111 @@
+"""GPU tests of the exact SPADE-interior reduction (ctrlhair_amd/csrc/ace_sparse.h): gamma/beta of SPADE.forward
+(/root/reference/sean_codes/models/networks/normalization.py:249-257) depend on the 5x5 label neighbourhood only, so pixels
+with a uniform neighbourhood take per-label constants and only the compacted boundary pixels go through the conv.
+
+The golden / oracle tests of test_hip_sean_generator.py already run with the reduction on (it is the default); here the
+sparse path is compared with the dense evaluation of the SAME library (option sean.sparse = 0) on label maps chosen to hit
+its edge cases, and the executed-FLOP accounting is checked."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MODE = {'f32': 0, 'f16x3': 1}
+
+
+def _gen(sd, mb, ms, path, sparse, extra=None):
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    opts = {'sean.sparse': sparse}
+    opts.update(extra or {})
+    return SeanGenerator(0, f16x3=MODE[path], options=opts).load_state_dict(sd, max_batch=mb, max_size=ms)
+
+
+def _run(gen, labels, codes, noise):
+    dev = gen.device
+    out = gen.generate(torch.from_numpy(labels).to(dev), torch.from_numpy(codes).to(dev), torch.from_numpy(noise).to(dev))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _label_sets(B, S):
+    from ctrlhair_amd import procedural as P
+    sets = {}
+    sets['blocky'] = P.blocky_labels(B, S, grid=8)
+    sets['face'] = np.stack([P.face_like_labels(S, 40 + b) for b in range(B)])
+    sets['one_region'] = np.full((B, S, S), 13, np.uint8)                      # everything interior except the image frame
+    diag = (np.add.outer(np.arange(S), np.arange(S)) % 19).astype(np.uint8)    # no interior pixel at any resolution (a
+    sets['diag'] = np.repeat(diag[None], B, 0)                                 # checkerboard would turn uniform when down-sampled)
+    noclass = P.blocky_labels(B, S, grid=4, seed=77).copy()                    # labels >= 19 ("no class") never count as interior
+    noclass[:, : S // 2, : S // 2] = 255
+    noclass[:, S // 2:, S // 2:] = 19
+    sets['noclass'] = noclass
+    stripes = np.zeros((B, S, S), np.uint8)                                    # 5-pixel stripes: interior = exactly the centre line
+    stripes[:] = ((np.arange(S) // 5) % 19)[None, None, :]
+    sets['stripes5'] = stripes
+    return sets
+
+
+@pytest.mark.parametrize('path', ['f32', 'f16x3'])
+@pytest.mark.parametrize('S', [64, 160])
+def test_sparse_equals_dense_tiny(hip_lib, path, S):
+    """ngf=16 (a single 64-row tile per ACE: partially filled blocks), S=160 -> ACE resolutions 160 / 80 (ragged tiles)."""
+    from ctrlhair_amd import procedural as P
+    ngf, B = 16, 3
+    sd = P.sean_state_dict(0, ngf)
+    dense = _gen(sd, B, S, path, 0)
+    sparse = _gen(sd, B, S, path, 1, {'sean.sparse_min': 32})
+    codes, noise = P.style_codes(B), P.noise_planes(B, S, ngf)
+    for name, lab in _label_sets(B, S).items():
+        a, b = _run(dense, lab, codes, noise), _run(sparse, lab, codes, noise)
+        d = float(np.abs(a - b).max())
+        print(f'{path} S={S} {name}: max |sparse - dense| = {d:.3e}')
+        assert np.isfinite(b).all() and d <= 2e-5, name
+    dense.handle.close()
+    sparse.handle.close()
+
+
+@pytest.mark.parametrize('path', ['f32', 'f16x3'])
+def test_sparse_equals_dense_ngf64(hip_lib, path):
+    """ngf=64 at 256x256 (row tiles 2 ... 32), against the dense evaluation and against the oracle on face-like labels."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    ngf, S, B = 64, 256, 2
+    sd = P.sean_state_dict(0, ngf)
+    dense, sparse = _gen(sd, B, S, path, 0), _gen(sd, B, S, path, 1)
+    codes, noise = P.style_codes(B), P.noise_planes(B, S, ngf)
+    sets = _label_sets(B, S)
+    for name in ('blocky', 'face', 'noclass'):
+        a, b = _run(dense, sets[name], codes, noise), _run(sparse, sets[name], codes, noise)
+        d = float(np.abs(a - b).max())
+        print(f'{path} ngf64 {name}: max |sparse - dense| = {d:.3e}')
+        assert d <= 2e-5, name
+    ref = O.generator_forward(O.to_torch(sd), sets['face'][:1], codes[:1], noise[:1], ngf).numpy()
+    got = _run(sparse, sets['face'][:1], codes[:1], noise[:1])
+    assert np.abs(got - ref).max() <= 1e-3
+    dense.handle.close()
+    sparse.handle.close()
+
+
+@pytest.mark.parametrize('path', ['f32', 'f16x3'])
+def test_executed_flops_accounting(hip_lib, path):
+    """ch_profile_read_ex: executed <= dense FLOPs; equal for a label map without interior pixels; the executed fraction of a
+    single-region map is the 2-pixel image frame (rounded up to 32-pixel sub-tiles)."""
+    from ctrlhair_amd import procedural as P
+    ngf, S, B = 16, 128, 2
+    sd = P.sean_state_dict(0, ngf)
+    gen = _gen(sd, B, S, path, 1, {'sean.sparse_min': 64})
+    codes, noise = P.style_codes(B), P.noise_planes(B, S, ngf)
+    sets = _label_sets(B, S)
+    frac = {}
+    for name in ('diag', 'one_region', 'face'):
+        gen.handle.profile_enable(True)
+        _run(gen, sets[name], codes, noise)
+        gen.handle.profile_enable(False)
+        ace = gen.handle.profile_read(1)
+        gen.handle.profile_read(-1)
+        assert ace['launches'] > 0 and 0 < ace['flops_executed'] <= ace['flops'] * 1.2     # (C = 16 layers run a padded 64-row tile)
+        frac[name] = ace['flops_executed'] / ace['flops']
+    print('executed / dense SPADE-conv FLOPs:', frac)
+    assert 1.0 - 1e-9 <= frac['diag'] <= 1.2
+    assert frac['one_region'] < 0.45 and frac['face'] < 0.9
+    gen.handle.close()
