@@ -1,52 +1,73 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the CtrlHair hot path on MI355X.
 
-Workloads
-  generator (default; BASELINE.json configs[1], SURVEY.md 8d Config 2): SEAN generator forward only, batch 16 per GPU
-      (32 per GPU with --gpus 8 = configs[3], B=256), synthetic 512x512 blocky label maps + tanh(N(0,1)) style codes +
-      explicit N(0,1) noise planes, procedural (random, calibrated) weights of the real ngf=64 architecture.
-  pipeline (BASELINE.json configs[2], SURVEY.md 8d Config 3): the whole edit at batch 8 -- BiSeNet parse @512 -> label remap
-      -> nearest 256 -> shape encoders -> Zencoder @512 -> colour encoder / predictor / generator with slider deltas ->
-      shape decoder -> nearest x2 -> SEAN generator @512.
-One "step" = one pass over one batch already resident in HBM.  With N>1 (one process per GPU, torch.distributed/RCCL)
-every rank runs its own batch (weak scaling) and the output shards are all-gathered over xGMI inside the timed region
-(ctrlhair_amd.parallel.PipelinedGather: side stream, under the next step's pass; --sync-gather serialises it).
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Two arithmetic legs are timed with the same steps / warm-up, each in its own pass WITHOUT per-launch instrumentation:
-  * the headline leg (--path, default f16x3): fp32 storage and accumulation, conv products as a 3-term f16 split on the
-    matrix cores with power-of-two operand scaling (ctrlhair_amd/csrc/sh16.h) -- f32-class by construction;
-  * "strict_fp32": the same job on the exact-f32 matrix-core path (v_mfma_f32_32x32x2_f32), the reference's arithmetic.
-A third, separate pass per leg with hipEvent brackets around every MFMA conv launch gives the roofline figures.
+One "step" = one pass of the hot path over one batch already resident in HBM.  The default run (N = 1) answers, in ONE JSON
+line, every configuration of BASELINE.json that fits one GPU:
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size 512] [--workload generator|pipeline]
-                    [--path f16x3|f32|f16|bf16] [--no-strict-fp32] [--no-cpu-baseline]
+  top level   configs[1]: SEAN generator forward only, batch 16, synthetic 512x512 blocky label maps + tanh(N(0,1)) style
+              codes + explicit N(0,1) noise planes, procedural (random, calibrated) weights of the real ngf=64 architecture,
+              on the EXACT-f32 matrix-core path (v_mfma_f32_32x32x2_f32) -- the reference's arithmetic.  `value`, `dtype`,
+              `roofline`, the per-step percentiles and `cpu_baseline` all belong to this leg.
+  f32_class_f16x3        the same job with the conv products evaluated as a 3-term f16 split on the f16 matrix cores (f32
+                         storage and accumulation, power-of-two operand scaling: ctrlhair_amd/csrc/sh16.h).  Narrower than
+                         fp32 per product (2^-22), so it is NOT the fp32 number of record; tested to 1e-3 like the exact path.
+  face_like_labels       both legs again on face-like label maps (large regions, curved boundaries) instead of the blocky
+                         maps of SURVEY.md 8(d) Config 2.
+  pipeline               configs[2]: the whole edit at batch 8 (BiSeNet parse @512 -> label remap -> nearest 256 -> shape
+                         encoders -> Zencoder @512 -> colour encoder / predictor / generator with slider deltas -> shape
+                         decoder -> nearest x2 -> SEAN generator @512), f16x3 and exact-f32 legs, with per-stage times.
 
-Prints ONE JSON line (rank 0).
+With --gpus N > 1 the script starts N ranks itself when it was not launched by torch.distributed.run (it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`), one process per GPU over RCCL:
+every rank runs its own batch (weak scaling; 32 per GPU with --gpus 8 = configs[3], B=256) and the output shards are
+all-gathered over xGMI inside the timed region (ctrlhair_amd.parallel.PipelinedGather: side stream, under the next step's
+pass; --sync-gather serialises it).  `n_gpus` is the world size RCCL reports.
+
+Timing: W untimed warm-up steps, then K steps bracketed by barrier + torch.cuda.synchronize() on both sides (max over ranks)
+-> `value` / `ms_per_step`; an event is recorded on the launch stream at every step boundary (no synchronisation inside the
+region) -> `step_ms` median / p10 / p90.  Per-kernel figures come from a separate instrumented pass (hipEvents around every
+MFMA conv launch on the launch stream), never from the timed region.
+
+Other flags: --workload generator|pipeline (only that workload), --path f32|f16x3|f16|bf16 (only that arithmetic as the top
+level; f16 / bf16 = single-term reduced-precision operands of configs[4], tolerance 5e-2), --labels blocky|face,
+--only-headline (skip the extra blocks), --batch, --size, --no-cpu-baseline.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32 (at the 2.4 GHz boost clock)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16/bf16 MFMA dense peak (spec; the 2:1-sparse figure is not used)
 PEAK_HBM_GBS = 8000.0
 CONTRACT_BYTES_PER_IMAGE = 5.805e9        # conv-layer accounting, activations in + out, S=512, fp32
 CONTRACT_WEIGHT_BYTES = 1.061e9           # ... + weights once per batch
+DENSE_REFERENCE_FLOP_PER_IMAGE = 2.5696e12    # the reference's dense graph at S=512
 PATH_OPTION = {'f32': 0, 'f16x3': 1, 'f16': 2, 'bf16': 3}
+
+DTYPE = {
+    'f32': 'f32 (exact-f32 MFMA, v_mfma_f32_32x32x2_f32)',
+    'f16x3': 'f32 storage + f32 accumulate; conv products as 3-term f16 split on MFMA with power-of-two operand scaling '
+             '(2^-22 per product: f32-class, not the fp32 number of record; csrc/sh16.h)',
+    'f16': 'f16 operands on MFMA, f32 accumulate, f32 normalisation/modulation (reduced precision: tolerance 5e-2)',
+    'bf16': 'bf16 operands on MFMA, f32 accumulate, f32 normalisation/modulation (reduced precision: tolerance 5e-2)',
+}
 
 
 def csrc_sha():
-    """Hash of the sources of the dominant kernels (the MFMA conv headers): profiles/latest_traffic.json records the one its
-    PMC passes were taken at; a mismatch means the committed traffic figure is stale and is not reported."""
+    """Hash of the sources of the dominant kernels: profiles/latest_traffic.json records the one its PMC passes were taken at;
+    a mismatch means the committed traffic figure is stale and is not reported."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'ctrlhair_amd', 'csrc')
-    for f in ('conv_mfma.h', 'conv_sh16.h', 'conv_sh16_ws2.h', 'sh16.h'):
+    for f in ('conv_mfma.h', 'conv_ace_sparse.h', 'ace_sparse.h', 'conv_sh16.h', 'conv_sh16_ws2.h', 'sh16.h'):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
@@ -74,29 +95,47 @@ def cpu_baseline(ngf, S, sd_np, budget_s=40.0):
             break
     med = float(np.median(times))
     return {'value': round(1.0 / med, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{len(times)} single-image {S}x{S} generator forwards (median; batch 16 would take minutes), torch '
-                      f'{torch.__version__} CPU, after a 128x128 warm-up'}
+            'sample': f'{len(times)} single-image {S}x{S} generator forwards (median; the dense reference graph, batch 16 would '
+                      f'take minutes), torch {torch.__version__} CPU, after a 128x128 warm-up'}
+
+
+def make_labels(kind, B, S, first):
+    import numpy as np
+    from ctrlhair_amd import procedural as P
+    if kind == 'face':
+        return np.stack([P.face_like_labels(S, 500 + first + b) for b in range(B)])
+    return P.blocky_labels(B, S, first=first)
 
 
 class GeneratorJob:
     """configs[1]: one SEAN generator pass over this rank's batch."""
 
-    def __init__(self, args, path, dev, rank, sd):
+    def __init__(self, args, path, dev, rank, sd, labels='blocky'):
         import torch
         from ctrlhair_amd import procedural as P
         from ctrlhair_amd.sean.generator import SeanGenerator
         B, S, ngf = args.batch, args.size, args.ngf
-        opts = {'sean.ahead': args.ahead} if args.ahead >= 0 else None
+        opts = {'sean.sparse': args.sparse}
+        if args.ahead >= 0:
+            opts['sean.ahead'] = args.ahead
+        if args.sparse_th:
+            opts['sean.sparse_th'] = args.sparse_th
         self.gen = SeanGenerator(dev.index, f16x3=PATH_OPTION[path], options=opts).load_state_dict(sd, max_batch=B, max_size=S)
         if args.dbg:
             self.gen.handle.set_option('sean.dbg', args.dbg)
+        self.dev, self.rank, self.args = dev, rank, args
         first = rank * B     # global sample index offset (SURVEY.md 8d Config 4)
-        self.labels = torch.from_numpy(P.blocky_labels(B, S, first=first)).to(dev)
         self.codes = torch.from_numpy(P.style_codes(B, first=first)).to(dev)
         self.noise = torch.from_numpy(P.noise_planes(B, S, ngf, first=first)).to(dev)
+        self.set_labels(labels)
         self.handle = self.gen.handle
         self.images = B
         self.out_shape = (B, 3, S, S)
+
+    def set_labels(self, kind):
+        import torch
+        a = self.args
+        self.labels = torch.from_numpy(make_labels(kind, a.batch, a.size, self.rank * a.batch)).to(self.dev)
 
     def step(self, out):
         self.gen.generate(self.labels, self.codes, self.noise, out=out)
@@ -108,11 +147,11 @@ class GeneratorJob:
 class PipelineJob:
     """configs[2]: the whole edit (ctrlhair_amd.pipeline.EditPipeline) over this rank's batch of portraits."""
 
-    def __init__(self, args, path, dev, rank, weights):
+    def __init__(self, args, path, dev, rank, weights, B):
         import torch
         from ctrlhair_amd import procedural as P
         from ctrlhair_amd.pipeline import EditPipeline
-        B, S = args.batch, args.size
+        S = args.size
         self.pipe = EditPipeline(weights, device=dev.index, img_size=S, max_batch=B, f16x3=PATH_OPTION[path])
         self.img = torch.from_numpy(P.synthetic_images(B, S, seed=11 + rank * B)).to(dev)
         self.handle = self.pipe.models.generator.handle
@@ -122,7 +161,7 @@ class PipelineJob:
     def step(self, out):
         self.pipe.edit(self.img, out=out)
 
-    # algorithmic GFLOP per image of each stage (generator: FLOPs executed after the exact reformulations)
+    # algorithmic GFLOP per image of each stage (generator: the dense evaluation after the LUT reformulations)
     STAGE_GFLOP = {'parse': 27.5, 'shape_encode': 4.9, 'zencoder': 169.6, 'shape_decode': 32.2, 'generator': 1083.8}
 
     def stages(self, path):
@@ -133,12 +172,9 @@ class PipelineJob:
             row = {'ms': round(t, 3)}
             if k in self.STAGE_GFLOP:
                 tf = self.STAGE_GFLOP[k] * self.images / t            # GFLOP per ms = TFLOP/s
-                # matrix-core path of the stage's dominant convs: exact-f32 MFMA, or 3 executed f16 products per f32 product
                 f16 = path != 'f32'          # every stage's convs run on the f16 matrix cores unless the strict-f32 path is on
-                terms = 3.0 if (f16 and (path == 'f16x3' or k != 'generator')) else 1.0     # (aux networks: always the 3-term split)
-                peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-                row.update({'algorithmic_tflops': round(tf, 1), 'bound': 'mfma', 'peak_tflops': peak,
-                            'frac': round(terms * tf / peak, 4)})
+                row.update({'algorithmic_tflops': round(tf, 1), 'bound': 'mfma',
+                            'peak_tflops': PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS})
             else:
                 row['bound'] = 'launch latency (three small MLPs + slider arithmetic)'
             out[k] = row
@@ -148,11 +184,22 @@ class PipelineJob:
         self.pipe.close()
 
 
-def run_leg(job, args, dist, dev, world):
+def percentiles(ms):
+    import numpy as np
+    if not ms:
+        return None
+    a = np.asarray(ms, dtype=np.float64)
+    return {'median': round(float(np.median(a)), 3), 'p10': round(float(np.percentile(a, 10)), 3),
+            'p90': round(float(np.percentile(a, 90)), 3), 'n': int(a.size)}
+
+
+def run_leg(job, args, dist, dev, world, steps=None, warmup=None, profile=True):
     """warm-up, then the timed region (barrier + synchronize on both sides, MAX over ranks), then a separate
     instrumented pass for the per-kernel figures."""
     import torch
     from ctrlhair_amd.parallel import PipelinedGather
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     pg = PipelinedGather(job.out_shape, torch.float32, dev, overlap=not args.sync_gather)
 
     def step():
@@ -165,48 +212,60 @@ def run_leg(job, args, dist, dev, world):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(steps):
+        marks[i].record()            # on the launch stream; nothing waits on it inside the region
         step()
+    marks[steps].record()
     sync()
     dt = time.perf_counter() - t0
-    if args.steps > 0:
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    if steps > 0:
         assert pg.check_slot(), 'all-gather result does not contain this rank\'s shard at its slot'
     out = pg.last_local()
-    assert args.dbg or args.steps == 0 or bool(torch.isfinite(out).all())
+    assert args.dbg or steps == 0 or bool(torch.isfinite(out).all())
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # instrumented pass (not timed as a whole): hipEvent brackets around every MFMA conv launch, on the launch stream
-    nprof = max(1, min(args.steps, 5))
-    job.handle.profile_enable(True)
-    scratch = pg.outs[0]
-    for _ in range(nprof):
-        job.step(scratch)
-    torch.cuda.synchronize()
-    job.handle.profile_enable(False)
-    prof = {'ace': job.handle.profile_read(1), 'plain': job.handle.profile_read(0)}
-    prof['all'] = job.handle.profile_read(-1)
-    prof['steps'] = nprof
-    return dt, prof
+    prof = None
+    if profile:
+        # instrumented pass (not timed as a whole): hipEvent brackets around every MFMA conv launch, on the launch stream
+        nprof = max(1, min(steps, 3))
+        job.handle.profile_enable(True)
+        scratch = pg.outs[0]
+        for _ in range(nprof):
+            job.step(scratch)
+        torch.cuda.synchronize()
+        job.handle.profile_enable(False)
+        prof = {'ace': job.handle.profile_read(1), 'plain': job.handle.profile_read(0), 'interior': job.handle.profile_read(3)}
+        prof['all'] = job.handle.profile_read(-1)
+        prof['steps'] = nprof
+    value = world * job.images * steps / dt if steps else 0.0
+    return {'value': round(value, 3), 'ms_per_step': round(dt / max(steps, 1) * 1e3, 3), 'step_ms': percentiles(step_ms),
+            'steps': steps, 'warmup': warmup}, prof
 
 
-def roofline_block(path, prof, value, B):
-    ace, plain, allk = prof['ace'], prof['plain'], prof['all']
-    alg = ace['flops'] / (ace['ms'] * 1e-3) / 1e12 if ace['ms'] > 0 else 0.0     # algorithmic (f32-equivalent) TFLOP/s
+def roofline_block(path, prof, value, B, sustained):
+    ace, plain, allk, inter = prof['ace'], prof['plain'], prof['all'], prof['interior']
+    n = max(ace['launches'], 1)
+    t_ace = ace['ms'] * 1e-3
+    dense = ace['flops'] / t_ace / 1e12 if t_ace > 0 else 0.0            # dense-equivalent f32 TFLOP/s of the SPADE convs
+    useful = ace['flops_executed'] / t_ace / 1e12 if t_ace > 0 else 0.0  # f32 FLOPs the matrix cores were asked for
     if path in ('f16', 'bf16'):
-        executed, peak = alg, PEAK_F16_MFMA_TFLOPS
+        executed, peak, pk = useful, PEAK_F16_MFMA_TFLOPS, 'f16'
         kname = f'conv_sh16_ws_kernel / conv_sh16_kernel <KS=3,...,EPI_ACE,TERMS=1> (SPADE gamma/beta conv, {path} operands, fused ACE epilogue)'
     elif path == 'f16x3':
-        executed, peak = 3.0 * alg, PEAK_F16_MFMA_TFLOPS      # every f32 product is executed as 3 f16 MFMA products
+        executed, peak, pk = 3.0 * useful, PEAK_F16_MFMA_TFLOPS, 'f16'      # every f32 product is executed as 3 f16 MFMA products
         kname = 'conv_sh16_ws_kernel / conv_sh16_kernel <KS=3,...,EPI_ACE> (SPADE gamma/beta conv, f16x3 split operands, fused ACE epilogue)'
     else:
-        executed, peak = alg, PEAK_F32_MFMA_TFLOPS
-        kname = 'conv_mfma_kernel<KS=3,...,EPI_ACE> (SPADE gamma/beta conv, exact-f32 MFMA, fused ACE epilogue)'
+        executed, peak, pk = useful, PEAK_F32_MFMA_TFLOPS, 'f32'
+        kname = ('conv_ace_sparse_kernel<TH> (SPADE gamma/beta conv over the compacted boundary pixels, exact-f32 MFMA, fused ACE '
+                 'epilogue) + conv_mfma_kernel<KS=3,...,EPI_ACE> for the low-resolution ACEs')
     traffic = detail = note = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
@@ -219,65 +278,105 @@ def roofline_block(path, prof, value, B):
                 detail = None
         except Exception:
             traffic = detail = None
+    alg_bytes = ace['bytes'] / n
     contract = CONTRACT_BYTES_PER_IMAGE + CONTRACT_WEIGHT_BYTES / B
-    return {
+    steps = prof['steps']
+    sus = (sustained or {}).get(pk)
+    blk = {
         'bound': 'mfma', 'kernel': kname, 'achieved': round(executed, 2), 'peak': peak, 'unit': 'TFLOP/s',
-        'frac': round(executed / peak, 4), 'traffic': traffic,
-        'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_detail': detail, 'traffic_note': note,
-        'algorithmic_f32_tflops': round(alg, 2), 'launches': ace['launches'],
-        'avg_launch_ms': round(ace['ms'] / max(ace['launches'], 1), 4),
-        'flops_per_launch_avg': ace['flops'] / max(ace['launches'], 1),
-        'all_mfma_convs': {'algorithmic_tflops': round(allk['flops'] / max(allk['ms'], 1e-9) / 1e9, 2),
-                           'ms_per_step': round(allk['ms'] / prof['steps'], 3),
-                           'plain_algorithmic_tflops': round(plain['flops'] / max(plain['ms'], 1e-9) / 1e9, 2)},
+        'frac': round(executed / peak, 4),
+        'peak_sustained': sus, 'frac_of_sustained': round(executed / sus, 4) if sus else None,
+        'peak_note': 'peak = spec at the 2.4 GHz boost clock; peak_sustained = MFMA-only loop measured on this device in this run '
+                     '(ch_mfma_peak)',
+        'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)',
+        'algorithmic_bytes_per_launch': round(alg_bytes),
+        'traffic_ratio': round(traffic / alg_bytes, 3) if (traffic and alg_bytes > 0) else None,
+        'traffic_detail': detail, 'traffic_note': note,
+        'launches': ace['launches'], 'avg_launch_ms': round(ace['ms'] / n, 4),
+        'flops_executed_per_launch_avg': ace['flops_executed'] / n, 'flops_dense_per_launch_avg': ace['flops'] / n,
+        'executed_over_dense': round(ace['flops_executed'] / max(ace['flops'], 1.0), 4),
+        'dense_equivalent_f32_tflops': round(dense, 2),
+        'note': 'executed = FLOPs the matrix cores ran (exact SPADE-interior reduction: pixels with a uniform 5x5 label '
+                'neighbourhood take per-label constants, csrc/ace_sparse.h); utilisation is priced on executed FLOPs only',
+        'all_mfma_convs': {
+            'executed_tflops': round(allk['flops_executed'] / max(allk['ms'], 1e-9) / 1e9, 2),
+            'ms_per_step': round(allk['ms'] / steps, 3),
+            'plain_tflops': round(plain['flops_executed'] / max(plain['ms'], 1e-9) / 1e9, 2),
+            'flops_executed_per_image': allk['flops_executed'] / steps / B,
+            'flops_dense_per_image_after_lut': allk['flops'] / steps / B,
+            'flops_dense_reference_per_image': DENSE_REFERENCE_FLOP_PER_IMAGE},
+        'interior_pass': None if not inter['launches'] else {
+            'bound': 'hbm', 'kernel': 'ace_gtable_kernel + ace_interior_*_kernel (elementwise modulation of the interior pixels)',
+            'ms_per_step': round(inter['ms'] / steps, 3), 'algorithmic_gb_per_step': round(inter['bytes'] / steps / 1e9, 3),
+            'achieved_gbs': round(inter['bytes'] / max(inter['ms'], 1e-9) / 1e6, 1), 'peak_gbs': PEAK_HBM_GBS,
+            'frac': round(inter['bytes'] / max(inter['ms'], 1e-9) / 1e6 / PEAK_HBM_GBS, 4)},
         'timing': 'hipEvents around each launch in a separate instrumented pass (not the timed region)',
         # north_star's other yardstick: conv-layer contract bytes (each conv reads its input and writes its output once,
         # fp32) against HBM peak.  The path is matrix-core bound (AI ~ 440 FLOP/B): this fraction cannot reach 55 %.
         'hbm_contract': {'bytes_per_image': contract, 'achieved_gbs': round(value * contract / 1e9, 1),
                          'peak_gbs': PEAK_HBM_GBS, 'frac': round(value * contract / 1e9 / PEAK_HBM_GBS, 4)},
     }
+    return blk
 
 
-DTYPE = {
-    'f16x3': 'f32 storage + f32 accumulate; conv products as 3-term f16 split on MFMA with power-of-two operand scaling '
-             '(f32-class by construction: csrc/sh16.h)',
-    'f32': 'f32 (exact-f32 MFMA)',
-    'f16': 'f16 operands on MFMA, f32 accumulate, f32 normalisation/modulation (reduced precision: tolerance 5e-2)',
-    'bf16': 'bf16 operands on MFMA, f32 accumulate, f32 normalisation/modulation (reduced precision: tolerance 5e-2)',
-}
+def respawn_under_torchrun(n):
+    """--gpus N without a launcher: start N ranks ourselves (one per GPU) and let rank 0 print the JSON line."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f'bench.py --gpus {n}: only {have} GPU(s) visible on this node -- refusing to run a smaller job '
+                         f'under the label n_gpus={n}')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=0, help='per GPU; default 16 (generator; 32 with --gpus 8 = configs[3]) / 8 (pipeline)')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ngf', type=int, default=64)
-    ap.add_argument('--workload', choices=('generator', 'pipeline'), default='generator')
+    ap.add_argument('--workload', choices=('all', 'generator', 'pipeline'), default='all')
+    ap.add_argument('--labels', choices=('blocky', 'face'), default='blocky', help='label maps of the top-level generator legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-strict-fp32', action='store_true', help='skip the exact-f32 leg')
-    ap.add_argument('--path', choices=tuple(PATH_OPTION), default='f16x3',
-                    help='arithmetic of the headline leg: f16x3 = 3-term split-operand f16 MFMA, f32 accumulate, f32-class '
-                         '(default); f32 = exact-f32 MFMA; f16 / bf16 = single-term reduced-precision operands (configs[4])')
+    ap.add_argument('--only-headline', action='store_true', help='top-level leg only (no f16x3 / face-like / pipeline blocks)')
+    ap.add_argument('--no-strict-fp32', action='store_true', help=argparse.SUPPRESS)      # (older tools: implies --only-headline)
+    ap.add_argument('--path', choices=tuple(PATH_OPTION), default='f32',
+                    help='arithmetic of the top-level leg: f32 = exact-f32 MFMA (default, the reference\'s arithmetic); f16x3 = 3-term '
+                         'split-operand f16 MFMA, f32 accumulate; f16 / bf16 = single-term reduced-precision operands (configs[4])')
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--ahead', type=int, default=-1, help=argparse.SUPPRESS)       # option sean.ahead (experiments)
+    ap.add_argument('--sparse', type=int, default=1, help='0: every pixel through the SPADE convs (no interior reduction)')
+    ap.add_argument('--sparse-th', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--sync-gather', action='store_true',
                     help='N > 1: all-gather each step on the compute stream instead of overlapping it with the next step')
-    ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)   # 1-rank process group: exercises the N > 1 code
+    ap.add_argument('--force-dist', action='store_true', help='1-rank process group: exercises the RCCL code path on one GPU')
     args = ap.parse_args()
-    if args.batch <= 0:
-        args.batch = 8 if args.workload == 'pipeline' else (32 if args.gpus == 8 else 16)
+    if args.no_strict_fp32:
+        args.only_headline = True
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        respawn_under_torchrun(args.gpus)
+    gen_batch = args.batch if args.batch > 0 else (32 if args.gpus == 8 else 16)
+    pipe_batch = args.batch if args.batch > 0 else 8
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f'rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -286,65 +385,114 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()            # what RCCL actually sees
 
-    B, S, ngf = args.batch, args.size, args.ngf
-    if args.workload == 'pipeline':
-        from ctrlhair_amd.hair_editor import procedural_weights
-        weights = procedural_weights(0, ngf)
-        sd = weights['sean']
-        make = lambda path: PipelineJob(args, path, dev, rank, weights)
-        wl = (f'full CtrlHair edit (BiSeNet parse -> shape + colour/texture branches -> Zencoder -> SEAN generator), '
-              f'batch {B}/GPU, {S}x{S}, ngf={ngf} (BASELINE.json configs[2])')
-        metric = '512x512 edited images/sec (full pipeline), whole job'
-    else:
+    S, ngf = args.size, args.ngf
+    do_gen = args.workload in ('all', 'generator')
+    do_pipe = args.workload == 'pipeline' or (args.workload == 'all' and world == 1 and not args.only_headline)
+    extras = world == 1 and not args.only_headline
+    res = {}
+    sustained = None
+    sd = None
+
+    if do_gen:
         from ctrlhair_amd import procedural as P
+        args.batch = gen_batch
         sd = P.sean_state_dict(0, ngf)
-        make = lambda path: GeneratorJob(args, path, dev, rank, sd)
-        cfgn = 'configs[3]: B=256 on 8 GPUs' if (world == 8 and B == 32) else 'configs[1]'
-        wl = f'SEAN generator forward only, batch {B}/GPU, {S}x{S}, ngf={ngf} (BASELINE.json {cfgn})'
-        metric = '512x512 edited images/sec (SEAN generator forward), whole job'
-
-    legs = [args.path] + ([] if (args.no_strict_fp32 or args.path == 'f32') else ['f32'])
-    results = {}
-    for path in legs:
-        job = make(path)
-        dt, prof = run_leg(job, args, dist, dev, world)
-        value = world * job.images * args.steps / dt if args.steps else 0.0
-        results[path] = {'value': round(value, 3), 'ms_per_step': round(dt / max(args.steps, 1) * 1e3, 3),
-                         'roofline': roofline_block(path, prof, value / world, B)}
-        if hasattr(job, 'stages') and rank == 0:
-            results[path]['stages'] = job.stages(path)
-        job.close()
-        del job
-        torch.cuda.empty_cache()
-
-    res = None
-    if rank == 0:
-        head = results[args.path]
+        legs = [args.path] + (['f16x3'] if (extras and args.path == 'f32') else [])
+        blocks = {}
+        for path in legs:
+            job = GeneratorJob(args, path, dev, rank, sd, labels=args.labels)
+            if sustained is None and rank == 0:
+                try:
+                    sustained = {'f32': round(job.handle.mfma_peak(0, 30), 1), 'f16': round(job.handle.mfma_peak(1, 30), 1),
+                                 'unit': 'TFLOP/s', 'how': 'MFMA-only loop, 2 waves per SIMD, random operands, ~30 ms (ch_mfma_peak)'}
+                except Exception as e:         # never lose the run over the helper
+                    sustained = {'error': str(e)}
+            r, prof = run_leg(job, args, dist, dev, world)
+            r['roofline'] = roofline_block(path, prof, r['value'] / world, gen_batch, sustained)
+            r['dtype'] = DTYPE[path]
+            if extras and args.labels == 'blocky':      # the same handle on face-like label maps (shorter run)
+                job.set_labels('face')
+                rf, pf = run_leg(job, args, dist, dev, world, steps=max(5, args.steps // 3), warmup=max(2, args.warmup // 3))
+                rb = roofline_block(path, pf, rf['value'], gen_batch, sustained)
+                rf.update({'executed_over_dense_spade': rb['executed_over_dense'],
+                           'flops_executed_per_image': rb['all_mfma_convs']['flops_executed_per_image'],
+                           'dominant_kernel_tflops': rb['achieved'], 'dominant_kernel_frac': rb['frac']})
+                r['face'] = rf
+            blocks[path] = r
+            job.close()
+            del job
+            torch.cuda.empty_cache()
+        head = blocks[args.path]
         par = f'batch-sharded x{world}'
         if dist is not None:
             par += ' + RCCL all-gather of outputs' + ('' if args.sync_gather else ' overlapped with the next step')
+        cfgn = 'configs[3]: B=256 on 8 GPUs' if (world == 8 and gen_batch == 32) else 'configs[1]'
         res = {
-            'metric': metric, 'value': head['value'], 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': DTYPE[args.path],
-            'data': 'synthetic (blocky labels, tanh-normal codes, explicit noise planes; procedural calibrated weights, '
+            'metric': '512x512 edited images/sec (SEAN generator forward), whole job', 'value': head['value'], 'unit': 'images/s',
+            'n_gpus': world, 'steps': head['steps'], 'warmup': head['warmup'], 'ms_per_step': head['ms_per_step'],
+            'step_ms': head['step_ms'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[args.path],
+            'data': f'synthetic ({args.labels} labels, tanh-normal codes, explicit noise planes; procedural calibrated weights, '
                     'no checkpoint ships with the reference)',
-            'config': {'workload': wl, 'global_batch': world * B, 'conv_path': args.path, 'parallelism': par},
-            'roofline': head['roofline'],
+            'config': {'workload': f'SEAN generator forward only, batch {gen_batch}/GPU, {S}x{S}, ngf={ngf} (BASELINE.json {cfgn})',
+                       'global_batch': world * gen_batch, 'conv_path': args.path, 'parallelism': par, 'labels': args.labels,
+                       'spade_interior_reduction': bool(args.sparse)},
+            'roofline': head['roofline'], 'sustained_peaks': sustained,
         }
-        if 'stages' in head:
-            res['stages'] = head['stages']
-        if 'f32' in results and args.path != 'f32':
-            s = results['f32']
-            res['strict_fp32'] = {'value': s['value'], 'unit': 'images/s', 'ms_per_step': s['ms_per_step'],
-                                  'dtype': DTYPE['f32'], 'steps': args.steps, 'warmup': args.warmup,
-                                  'note': 'same job, same timed protocol, exact-f32 matrix-core path (the reference\'s arithmetic)',
-                                  'roofline': s['roofline']}
-            if 'stages' in s:
-                res['strict_fp32']['stages'] = s['stages']
-        if not args.no_cpu_baseline and world == 1:
-            res['cpu_baseline'] = cpu_baseline(ngf, S, sd)
+        if 'f16x3' in blocks and args.path != 'f16x3':
+            b = blocks['f16x3']
+            res['f32_class_f16x3'] = {k: b[k] for k in ('value', 'ms_per_step', 'step_ms', 'steps', 'warmup', 'dtype', 'roofline')}
+            res['f32_class_f16x3']['unit'] = 'images/s'
+            res['f32_class_f16x3']['note'] = 'same job, same timed protocol; narrower than fp32 per product, reported beside the fp32 number'
+        if any('face' in b for b in blocks.values()):
+            res['face_like_labels'] = {'labels': 'ctrlhair_amd.procedural.face_like_labels (large regions, curved boundaries), same '
+                                                 'batch / size / weights / codes / noise', 'unit': 'images/s'}
+            for path, b in blocks.items():
+                if 'face' in b:
+                    res['face_like_labels'][path] = b['face']
+
+    if do_pipe:
+        from ctrlhair_amd.hair_editor import procedural_weights
+        args.batch = pipe_batch
+        weights = procedural_weights(0, ngf)
+        if sd is None:
+            sd = weights['sean']
+        if args.workload == 'all':
+            plegs = ['f16x3', 'f32']
+        else:           # --workload pipeline: the top level follows --path; the other f32-class arithmetic rides along as a block
+            other = 'f16x3' if args.path == 'f32' else 'f32'
+            plegs = [args.path] + ([] if args.only_headline else [other])
+        pb = {}
+        for path in plegs:
+            job = PipelineJob(args, path, dev, rank, weights, pipe_batch)
+            r, _ = run_leg(job, args, dist, dev, world, profile=False)
+            if rank == 0:
+                r['stages'] = job.stages(path)
+            r['dtype'] = DTYPE[path]
+            pb[path] = r
+            job.close()
+            del job
+            torch.cuda.empty_cache()
+        wl = (f'full CtrlHair edit (BiSeNet parse -> shape + colour/texture branches -> Zencoder -> SEAN generator), '
+              f'batch {pipe_batch}/GPU, {S}x{S}, ngf={ngf} (BASELINE.json configs[2])')
+        if args.workload == 'pipeline':
+            head = pb[plegs[0]]
+            res = {'metric': '512x512 edited images/sec (full pipeline), whole job', 'value': head['value'], 'unit': 'images/s',
+                   'n_gpus': world, 'steps': head['steps'], 'warmup': head['warmup'], 'ms_per_step': head['ms_per_step'],
+                   'step_ms': head['step_ms'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                   'dtype': DTYPE[plegs[0]], 'data': 'synthetic portraits; procedural calibrated weights',
+                   'config': {'workload': wl, 'global_batch': world * pipe_batch, 'conv_path': plegs[0]},
+                   'stages': head.get('stages')}
+            if len(plegs) > 1:
+                res['f32_class_f16x3' if plegs[1] == 'f16x3' else 'strict_fp32'] = pb[plegs[1]]
+        else:
+            res['pipeline'] = {'workload': wl, 'unit': 'images/s', 'metric': '512x512 edited images/sec (full pipeline)'}
+            for path, r in pb.items():
+                res['pipeline'][path] = r
+
+    if rank == 0 and do_gen and not args.no_cpu_baseline and world == 1:
+        res['cpu_baseline'] = cpu_baseline(ngf, S, sd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -61,6 +61,7 @@ struct SparseWork {             // block tasks of one (level, mtiles) pair
     int* total = nullptr;       // [0] number of block tasks, [1] boundary pixels, [2] sub-tiles (x32 = pixels the MFMAs run over)
                                 // [3] wave tasks x sub-tiles (x 32 x 64 rows = accumulators computed)
     int mtiles = 0;
+    int TH = 8;                 // tile height of the classification this list was built from
     long long cap = 0;
 };
 

@@ -347,6 +347,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.sparse = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.sparse_th") == 0) {  // tile height of the compaction: 8 / 16, 0 = chosen per layer
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.sparse_th) must precede ch_finalize");
+        h->sean.sparse_th = value;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.sparse_min") == 0) { // smallest ACE resolution served by the sparse path
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.sparse_min) must precede ch_finalize");
         h->sean.sparse_min_r = value;
@@ -361,6 +366,13 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         return CH_OK;
     }
     return fail(h, CH_ERR_ARG, std::string("unknown option '") + key + "'");
+}
+
+int ch_mfma_peak(ch_handle* h, int kind, int ms_target, double* tflops) {
+    if (!h || !tflops || kind < 0 || kind > 1 || ms_target < 1 || ms_target > 2000) return fail(h, CH_ERR_ARG, "ch_mfma_peak: bad argument");
+    DeviceGuard guard(h->device);
+    hipError_t e = chk::mfma_peak(kind, ms_target, tflops, nullptr);
+    return e == hipSuccess ? CH_OK : fail(h, CH_ERR_HIP, std::string("ch_mfma_peak: ") + hipGetErrorString(e));
 }
 
 int ch_profile_enable(ch_handle* h, int on) {
@@ -391,10 +403,11 @@ int ch_profile_read_ex(ch_handle* h, int kind, int* launches, double* total_ms, 
                 if (hipMemcpy(st, r.sp_stat, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
                     return fail(h, CH_ERR_HIP, "ch_profile_read: work-list statistics read failed");
                 fx += (double)st[3] * r.sp_flops_unit;
+                by += r.sp_bytes_fixed + r.sp_bytes_px * (r.kind == 3 ? r.sp_npix - (double)st[1] : (double)st[1]);
             } else {
                 fx += r.flops;
+                by += r.bytes;
             }
-            by += r.bytes;
             ++n;
         }
     }

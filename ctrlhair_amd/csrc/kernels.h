@@ -24,6 +24,8 @@ hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, floa
                          hipStream_t s, int c4 = 0, const float* w4 = nullptr);
 hipError_t c4_decode(const float* in, float* out, int B, int C, long long HW, hipStream_t s);
 hipError_t gen_noise(float* out, long long n, uint64_t seed, hipStream_t s);
+// mfma_peak.hip: sustained MFMA-only rate of the device (kind 0: f32 32x32x2, 1: f16 32x32x16), ~ms_target ms, synchronises
+hipError_t mfma_peak(int kind, int ms_target, double* tflops, hipStream_t s);
 // misc_kernels.hip
 // instance-norm outputs are bounded by sqrt(HW): their SH16 scale is instnorm_sh16_scale(HW), no saturation possible
 float instnorm_sh16_scale(int HW);

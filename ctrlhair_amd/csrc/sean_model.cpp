@@ -467,7 +467,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     xb = static_cast<float*>(B.dalloc(outmax * 4));
     // ---- exact SPADE-interior reduction: classification buffers per level, work lists per (level, row tiles) ------------
     for (int k = 0; k < 6; ++k) {
-        sp_level[k] = SparseLevel();
+        sp_level[k][0] = sp_level[k][1] = SparseLevel();
         sp_work[k].clear();
     }
     gtab = nullptr;
@@ -480,20 +480,21 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 while ((1 << k) < a->res_div) ++k;
                 const int r = ms >> k;
                 if (r < sparse_min_r || r < 32) continue;
-                SparseLevel& L = sp_level[k];
+                const int mt = (a->C + 31) / 32;
+                SparseLevel& L = sp_level[k][sparse_tile_h(mt) == 16 ? 1 : 0];
                 if (!L.u5) {
-                    L.TH = 8;
+                    L.TH = sparse_tile_h(mt);
                     L.cap_tiles = mb * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
                     L.u5 = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
                     L.list = static_cast<uint16_t*>(B.dalloc((size_t)L.cap_tiles * 32 * L.TH * sizeof(uint16_t)));
                     L.cnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
                 }
-                const int mt = (a->C + 31) / 32;
                 bool have = false;
                 for (const auto& w : sp_work[k]) have = have || w.mtiles == mt;
                 if (!have) {
                     SparseWork w;
                     w.mtiles = mt;
+                    w.TH = L.TH;
                     w.cap = (long long)L.cap_tiles * sparse_max_tasks(L.TH, mt);
                     w.work = static_cast<unsigned*>(B.dalloc((size_t)w.cap * sizeof(unsigned)));
                     w.total = static_cast<int*>(B.dalloc(4 * sizeof(int)));
@@ -554,9 +555,10 @@ struct Runner {
         return e;
     }
     template <class F>
-    void timed(int kind, double flops, double bytes, F launch) { timed(kind, flops, bytes, nullptr, 0.0, launch); }
+    void timed(int kind, double flops, double bytes, F launch) { timed(kind, flops, bytes, nullptr, 0.0, 0.0, 0.0, 0.0, launch); }
     template <class F>
-    void timed(int kind, double flops, double bytes, const int* sp_stat, double sp_unit, F launch) {
+    void timed(int kind, double flops, double bytes, const int* sp_stat, double sp_unit, double sp_bytes_px, double sp_bytes_fixed,
+               double sp_npix, F launch) {
         if (!m.prof_on) {
             launch();
             return;
@@ -567,6 +569,9 @@ struct Runner {
         r.bytes = bytes;
         r.sp_stat = sp_stat;
         r.sp_flops_unit = sp_unit;
+        r.sp_bytes_px = sp_bytes_px;
+        r.sp_bytes_fixed = sp_bytes_fixed;
+        r.sp_npix = sp_npix;
         r.e0 = ev();
         r.e1 = ev();
         check(hipEventRecord(r.e0, st), "hipEventRecord");
@@ -594,21 +599,23 @@ struct Runner {
             check(hipMemcpyAsync(it->second, src, floats * 4, hipMemcpyDeviceToDevice, st), "tap copy");
     }
     // exact SPADE-interior reduction: the level's classification and the work list of (level, row tiles), once per chunk
-    bool lvl_done[6] = {false, false, false, false, false, false};
+    bool lvl_done[6][2] = {};
     std::vector<int> work_done[6];
     const SparseWork* sparse_prepare(const AceW& a, const uint8_t* lab, int r) {
         int k = 0;
         while ((1 << k) < a.res_div) ++k;
-        const SparseLevel& L = m.sp_level[k];
-        if (!m.sparse || !L.u5 || r < m.sparse_min_r || r < 32) return nullptr;
-        const int ntiles = B * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
-        if (!lvl_done[k]) {
-            check(ace_classify(lab, L.u5, L.list, L.cnt, B, r, r, L.TH, st), "ace_classify");
-            lvl_done[k] = true;
-        }
         const int mt = (a.C + 31) / 32;
+        if (!m.sparse || r < m.sparse_min_r || r < 32) return nullptr;
         for (const auto& w : m.sp_work[k])
             if (w.mtiles == mt) {
+                const int ti = w.TH == 16 ? 1 : 0;
+                const SparseLevel& L = m.sp_level[k][ti];
+                if (!L.u5) return nullptr;
+                const int ntiles = B * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
+                if (!lvl_done[k][ti]) {
+                    check(ace_classify(lab, L.u5, L.list, L.cnt, B, r, r, L.TH, st), "ace_classify");
+                    lvl_done[k][ti] = true;
+                }
                 bool done = false;
                 for (int d : work_done[k]) done = done || d == mt;
                 if (!done) {
@@ -788,13 +795,13 @@ struct Runner {
         if ((m.dbg & 256) && a.index == m.dbg_sel) p.partial = m.splitk_ws;      // cycle stamps of this launch (profiling)
         else p.dbg &= ~256;
         const SparseWork* sw = m.use_sh16 ? nullptr : sparse_prepare(a, lab, r);
-        timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), sw ? sw->total : nullptr,
-              32.0 * 64 * 2.0 * HID * 9, [&] {
-            if (!m.use_sh16 && sw) {
-                // interior pixels: elementwise with the per-(sample, label) gamma/beta rows; boundary pixels: compacted conv
-                int lk = 0;
-                while ((1 << lk) < a.res_div) ++lk;
-                const SparseLevel& L = m.sp_level[lk];
+        if (sw) {
+            // interior pixels: elementwise with the per-(sample, label) gamma/beta rows; boundary pixels: compacted conv
+            int lk = 0;
+            while ((1 << lk) < a.res_div) ++lk;
+            const SparseLevel& L = m.sp_level[lk][sw->TH == 16 ? 1 : 0];
+            const double xpp = 4.0 * a.C / (x_up ? 4.0 : 1.0), opp = 4.0 * a.C;
+            timed(3, 0.0, 0.0, sw->total, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
                 check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
                 AceInteriorParams ip{};
                 ip.x = x;
@@ -813,13 +820,16 @@ struct Runner {
                 ip.x_up = x_up;
                 ip.act = act;
                 check(ace_interior_f32(ip, st), "ace interior");
-                p.sp_list = L.list;
-                p.sp_cnt = L.cnt;
-                p.sp_work = sw->work;
-                p.sp_total = sw->total;
-                check(conv_ace_sparse(p, L.TH, st), "spade conv (boundary pixels)");
-                return;
-            }
+            });
+            p.sp_list = L.list;
+            p.sp_cnt = L.cnt;
+            p.sp_work = sw->work;
+            p.sp_total = sw->total;
+            timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 0.0, sw->total, 32.0 * 64 * 2.0 * HID * 9, 4.0 * HID + xpp + opp,
+                  4.0 * 2.0 * a.C * HID * 9, npix, [&] { check(conv_ace_sparse(p, L.TH, st), "spade conv (boundary pixels)"); });
+            return;
+        }
+        timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] {
             if (!m.use_sh16) {
                 check(conv_ace(p, st), "spade conv");
                 return;

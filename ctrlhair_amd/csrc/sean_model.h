@@ -49,10 +49,12 @@ struct BlockW {
 
 struct ProfRec {
     hipEvent_t e0, e1;
-    int kind;       // 0 plain conv, 1 ACE conv, 2 LUT gemm
+    int kind;       // 0 plain conv, 1 ACE conv, 2 LUT gemm, 3 interior pass of a sparse ACE (table build + elementwise kernel)
     double flops, bytes;            // flops: the dense evaluation of the layer (every pixel through the conv)
     const int* sp_stat = nullptr;   // sparse ACE launch: SparseWork::total of its work list (read back at ch_profile_read)
     double sp_flops_unit = 0.0;     //   executed FLOPs = sp_stat[3] * sp_flops_unit
+    double sp_bytes_px = 0.0, sp_bytes_fixed = 0.0, sp_npix = 0.0;   // algorithmic bytes = fixed + per-pixel x (boundary pixels
+                                    //   sp_stat[1] for kind 1, interior pixels sp_npix - sp_stat[1] for kind 3)
 };
 
 struct SeanModel {
@@ -100,8 +102,11 @@ struct SeanModel {
     // and one work list per distinct number of 64-row tiles among the level's ACEs; gtab: [max_batch][19][2][C max]
     int sparse = 1;                            // option "sean.sparse" (0 = every pixel through the conv)
     int sparse_min_r = 64;                     // option "sean.sparse_min": smallest resolution served by the sparse path
-    SparseLevel sp_level[6];
+    int sparse_th = 0;                         // option "sean.sparse_th": tile height 8 / 16 (0 = by the layer's row tiles)
+    SparseLevel sp_level[6][2];                // [level][0: tiles of 32 x 8 | 1: tiles of 32 x 16]
     std::vector<SparseWork> sp_work[6];
+    // few row tiles (C <= 64): taller tiles, so that a tile's sub-tiles still fill the four waves of a block
+    int sparse_tile_h(int mtiles) const { return sparse_th == 8 || sparse_th == 16 ? sparse_th : (mtiles <= 2 ? 16 : 8); }
     float* gtab = nullptr;
     std::map<std::string, float*> taps;
     // profiling

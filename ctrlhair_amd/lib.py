@@ -40,6 +40,7 @@ SYMBOLS = {
     'ch_sean_set_tap': (_I, [_VP, C.c_char_p, _VP]),
     'ch_sean_scale_report': (_I, [_VP, C.POINTER(C.c_float), _I]),
     'ch_sean_debug_read': (_I, [_VP, _VP, C.c_size_t]),
+    'ch_mfma_peak': (_I, [_VP, _I, _I, C.POINTER(_D)]),
     'ch_profile_enable': (_I, [_VP, _I]),
     'ch_profile_read': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
     'ch_profile_read_ex': (_I, [_VP, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
@@ -133,6 +134,12 @@ class Handle:
         self._check(self.lib.ch_sean_scale_report(self._h, buf, 36), 'ch_sean_scale_report')
         a = np.array(buf[:], dtype=np.float32)
         return {'ace': a[0::2].copy(), 'style': a[1::2].copy()}
+
+    def mfma_peak(self, kind: int, ms_target: int = 30) -> float:
+        """TFLOP/s this device sustains on an MFMA-only loop (kind 0: f32 32x32x2, 1: f16 32x32x16).  Synchronises."""
+        t = _D()
+        self._check(self.lib.ch_mfma_peak(self._h, kind, ms_target, C.byref(t)), 'ch_mfma_peak')
+        return t.value
 
     def profile_enable(self, on: bool):
         self._check(self.lib.ch_profile_enable(self._h, int(on)), 'ch_profile_enable')

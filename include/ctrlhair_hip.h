@@ -192,9 +192,14 @@ int  ch_sean_scale_report(ch_handle* h, float* host_out, int n);
  * "sean.dbg" bit 256 the wave-specialised conv kernel leaves per-tile cycle stamps there.  Synchronises the device. */
 int  ch_sean_debug_read(ch_handle* h, void* host_out, size_t bytes);
 
+/* Roofline helper: the matrix-core issue rate this device sustains on an MFMA-only loop with non-trivial operands (no memory
+ * traffic; ~ms_target ms; synchronises the device).  kind 0 = v_mfma_f32_32x32x2_f32, 1 = v_mfma_f32_32x32x16_f16.  Reported by
+ * bench.py next to the spec peak (the spec figure assumes the 2.4 GHz boost clock). */
+int  ch_mfma_peak(ch_handle* h, int kind, int ms_target, double* tflops);
+
 /* Kernel-level timing hook for bench.py / roofline: when enabled, ch_sean_generate brackets every MFMA conv launch
  * with hipEvents on `stream`.  ch_profile_read synchronises those events and returns, for launches of `kind`
- * (0 = plain conv, 1 = SPADE conv with fused ACE epilogue, 2 = style-LUT GEMM, <0 = all), their count, summed
+ * (0 = plain conv, 1 = SPADE conv with fused ACE epilogue, 2 = style-LUT GEMM, 3 = interior pass of a sparse ACE, <0 = all), their count, summed
  * duration (ms) and summed algorithmic flops / bytes.  A read with kind < 0 also clears the records. */
 int  ch_profile_enable(ch_handle* h, int on);
 int  ch_profile_read(ch_handle* h, int kind, int* launches, double* total_ms, double* flops, double* bytes);

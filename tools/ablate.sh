@@ -1,7 +1,7 @@
 #!/bin/bash
 # perf ablations of the f16x3 conv kernels via the library's sean.dbg switches
 for d in ${@:-0 64 68}; do
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline --path f16x3 --dbg $d 2>/dev/null | tail -1 > /tmp/ab.json
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-headline --path f16x3 --dbg $d 2>/dev/null | tail -1 > /tmp/ab.json
 python - <<PY
 import json
 d=json.load(open('/tmp/ab.json'))

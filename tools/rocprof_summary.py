@@ -29,7 +29,7 @@ def main(path):
     print('| kernel | grid | lds | vgpr | calls | avg us |')
     print('|---|---|---|---|---|---|')
     for n, g, l, v, k, a in c.execute("select name, grid_x/workgroup_x, lds_size, vgpr_count, count(*), avg(duration) from kernels "
-                                      "where name like '%conv_mfma%' group by name, grid_x, lds_size order by avg(duration)*count(*) desc limit 40"):
+                                      "where (name like '%conv_mfma%' or name like '%conv_ace_sparse%') group by name, grid_x, lds_size order by avg(duration)*count(*) desc limit 40"):
         print(f'| `{short(n)}` | {g} | {l} | {v} | {k} | {a / 1e3:.1f} |')
 
 
