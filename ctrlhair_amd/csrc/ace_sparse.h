@@ -17,6 +17,7 @@
 //
 // Per resolution level and generate() chunk, ace_classify builds
 //      u5   [B][H][W]  uint8   label if the pixel is interior, else 255
+//      need [B][H][W]  uint8   1 where the boundary conv reads the SPADE hidden activations (the label-table kernel skips the rest)
 //      cnt  [ntiles]   int     boundary pixels of the tile (tiles of 32 x TH pixels, one sample each)
 //      list [ntiles][32*TH] uint16  their in-tile offsets ty*32+tx in raster order
 // and ace_worklist turns the counts into the list of block tasks of one conv launch (depends on the row tiles of the layer):
@@ -51,6 +52,7 @@ __host__ __device__ inline int sparse_max_tasks(int TH, int mtiles) {
 
 struct SparseLevel {            // device buffers of one resolution level (sean_model.cpp allocates them at build())
     uint8_t* u5 = nullptr;
+    uint8_t* need = nullptr;    // [B][H][W] 1 where the boundary conv reads the SPADE hidden activations (3x3 around a boundary pixel)
     uint16_t* list = nullptr;
     int* cnt = nullptr;
     int TH = 8;                 // tile height the level was classified with (tiles are 32 wide)
@@ -62,12 +64,16 @@ struct SparseWork {             // block tasks of one (level, mtiles) pair
                                 // [3] wave tasks x sub-tiles (x 32 x 64 rows = accumulators computed)
     int mtiles = 0;
     int TH = 8;                 // tile height of the classification this list was built from
+    int mode = 0;               // ace_worklist mode: 0 = block tasks of conv_ace_sparse_kernel, 1 = f16x3 tile-skip entries
     long long cap = 0;
 };
 
 // lab: [B][H][W] labels of the level.  Tiles of 32 x TH pixels (TH = 8 or 16).
-hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint16_t* list, int* cnt, int B, int H, int W, int TH, hipStream_t s);
-hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s);
+hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t* list, int* cnt, int B, int H, int W, int TH,
+                        hipStream_t s);
+// mode 0: block tasks of conv_ace_sparse_kernel; mode 1: (tile, row tile) pairs of the tiles with a boundary pixel (f16x3 tile-skip)
+hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s, int mode = 0,
+                        int tile_px = 512);
 // gtab[b][j][gamma|beta][C] = bias + gconst[j] + sum_t lut[(t, gamma|beta, c)][(b, j)]   (lut may be null: unstyled ACE)
 // lut element (row = (t*2+gb)*C + c, n = b*lut_bs + j) at lut[row*lut_rs + n*lut_ns]; lut_mul undoes a pre-multiplied LUT
 hipError_t ace_gtable(const float* bias_g, const float* bias_b, const float* gconst, const float* lut, int lut_rs, int lut_ns,
@@ -86,7 +92,13 @@ struct AceInteriorParams {
     float out_scale;
     unsigned* out_amax;
     int pass, bf16;
+    const int* cnt;             // f16x3 path: boundary-pixel count per tile of 32 x 16 (tiles_x = ceil(W / 32))
+    int variant;                // 0 = four pixels per thread (16-byte accesses), 1 = one pixel per thread
 };
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s);
+// f16x3 path (tile-skip mode): the pixels of the tiles of 32 x 16 WITHOUT a boundary pixel (q.cnt[tile] == 0); x in the C4
+// layout, out in the SH16 layout, scale protocol of sh16.h (q.pass 0: write at out_scale and record the maximum in q.out_amax;
+// pass 1: return at once unless the recorded maximum left the f16 window, else rewrite at the corrected scale)
+hipError_t ace_interior_sh16(const AceInteriorParams& q, hipStream_t s);
 
 }  // namespace chk

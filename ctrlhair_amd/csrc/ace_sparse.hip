@@ -9,32 +9,51 @@ namespace chk {
 
 // ---- classification: one block = one tile of 32 x TH pixels of one sample (TH * 32 threads) -------------------------------
 // A pixel is INTERIOR iff its label is < 19 and all 25 labels of its 5x5 neighbourhood exist (inside the image) and equal it.
+// need[p] = 1 iff some pixel of the 3x3 neighbourhood of p is a boundary pixel: only there does the boundary conv read the
+// SPADE hidden activations, so the label-table kernel may skip every other pixel.
 template <int TH>
 __global__ __launch_bounds__(32 * TH) void ace_classify_kernel(const uint8_t* __restrict__ lab, uint8_t* __restrict__ u5,
-                                                             uint16_t* __restrict__ list, int* __restrict__ cnt, int H, int W,
-                                                             int tiles_x, int tiles_y) {
-    constexpr int NT = 32 * TH, PW = 36, PH = TH + 4, NW = NT / 64;
-    __shared__ uint8_t patch[PH * PW];
+                                                             uint8_t* __restrict__ need, uint16_t* __restrict__ list,
+                                                             int* __restrict__ cnt, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int NT = 32 * TH, PW = 38, PH = TH + 6, BW = 34, BH = TH + 2, NW = NT / 64;
+    __shared__ uint8_t patch[PH * PW];       // labels of the tile + 3 pixels around it (255 outside the image)
+    __shared__ uint8_t bflag[BH * BW];       // boundary flags of the tile + 1 pixel around it
     __shared__ int wcnt[NW];
     const int tile = blockIdx.x, tid = threadIdx.x;
     const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
     const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * 32;
     const uint8_t* lb = lab + (long long)b * H * W;
     for (int i = tid; i < PH * PW; i += NT) {
-        const int y = y0 - 2 + i / PW, x = x0 - 2 + i % PW;
+        const int y = y0 - 3 + i / PW, x = x0 - 3 + i % PW;
         patch[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? lb[(long long)y * W + x] : (uint8_t)255;
+    }
+    __syncthreads();
+    for (int i = tid; i < BH * BW; i += NT) {
+        const int by = i / BW, bx = i % BW;                       // pixel (y0 - 1 + by, x0 - 1 + bx)
+        const int y = y0 - 1 + by, x = x0 - 1 + bx;
+        const uint8_t c = patch[(by + 2) * PW + bx + 2];
+        bool uni = c < 19;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) uni = uni && patch[(by + dy) * PW + bx + dx] == c;
+        const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        bflag[i] = inside ? (uni ? c : (uint8_t)255) : (uint8_t)254;       // 254: outside the image (neither kind)
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31, y = y0 + ty, x = x0 + tx;
     const bool inside = y < H && x < W;
-    const uint8_t c = patch[(ty + 2) * PW + tx + 2];
-    bool uni = c < 19;
+    const uint8_t me = bflag[(ty + 1) * BW + tx + 1];
+    bool nd = false;
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy)
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) uni = uni && patch[(ty + dy) * PW + tx + dx] == c;
-    if (inside) u5[(long long)b * H * W + (long long)y * W + x] = uni ? c : (uint8_t)255;
-    const bool bnd = inside && !uni;
+        for (int dx = 0; dx < 3; ++dx) nd = nd || bflag[(ty + dy) * BW + tx + dx] == 255;
+    if (inside) {
+        u5[(long long)b * H * W + (long long)y * W + x] = me;
+        need[(long long)b * H * W + (long long)y * W + x] = nd ? 1 : 0;
+    }
+    const bool bnd = inside && me == 255;
     // ordered compaction: raster order inside the tile (wave w = rows 2w, 2w+1)
     const unsigned long long m = __ballot(bnd);
     const int lane = tid & 63, wave = tid >> 6;
@@ -50,16 +69,20 @@ __global__ __launch_bounds__(32 * TH) void ace_classify_kernel(const uint8_t* __
     if (tid == 0) cnt[tile] = tot;
 }
 
-hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint16_t* list, int* cnt, int B, int H, int W, int TH, hipStream_t s) {
+hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t* list, int* cnt, int B, int H, int W, int TH,
+                        hipStream_t s) {
     const int tx = (W + 31) / 32, ty = (H + TH - 1) / TH;
-    if (TH == 8) hipLaunchKernelGGL(ace_classify_kernel<8>, dim3(B * tx * ty), dim3(256), 0, s, lab, u5, list, cnt, H, W, tx, ty);
-    else if (TH == 16) hipLaunchKernelGGL(ace_classify_kernel<16>, dim3(B * tx * ty), dim3(512), 0, s, lab, u5, list, cnt, H, W, tx, ty);
+    if (TH == 8) hipLaunchKernelGGL(ace_classify_kernel<8>, dim3(B * tx * ty), dim3(256), 0, s, lab, u5, need, list, cnt, H, W, tx, ty);
+    else if (TH == 16) hipLaunchKernelGGL(ace_classify_kernel<16>, dim3(B * tx * ty), dim3(512), 0, s, lab, u5, need, list, cnt, H, W, tx, ty);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 // ---- work list: exclusive scan of the block tasks per tile, one block of 1024 threads ------------------------------------
-__global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restrict__ cnt, int ntiles, int mtiles,
+// mode 0: block tasks of conv_ace_sparse_kernel (entry = tile | block task << 20); mode 1: tile-skip mode of the f16x3
+// wave-specialised kernel -- one entry (tile | row tile << 20) per row tile of every spatial tile with a boundary pixel, the
+// tile's 512 pixels all go through the conv (statistics count them as such)
+__global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restrict__ cnt, int ntiles, int mtiles, int mode, int tile_px,
                                                             unsigned* __restrict__ work, int* __restrict__ total) {
     __shared__ int wsum[16];
     __shared__ int carry;
@@ -73,10 +96,16 @@ __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restric
         const int tile = t0 + tid;
         int nbt = 0;
         if (tile < ntiles) {
-            const int c = cnt[tile], NS = (c + 31) >> 5;
-            int ng, per;
-            sparse_groups(NS, mtiles, ng, per);
-            nbt = (ng * mtiles + 3) >> 2;
+            int c = cnt[tile];
+            if (mode == 1 && c > 0) c = tile_px;
+            const int NS = (c + 31) >> 5;
+            if (mode == 1) {
+                nbt = c > 0 ? mtiles : 0;
+            } else {
+                int ng, per;
+                sparse_groups(NS, mtiles, ng, per);
+                nbt = (ng * mtiles + 3) >> 2;
+            }
             s_px += c;
             s_sub += NS;
             s_ws += NS * mtiles;
@@ -109,9 +138,9 @@ __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restric
     }
 }
 
-hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s) {
-    if (ntiles >= (1 << 20)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ace_worklist_kernel, dim3(1), dim3(1024), 0, s, cnt, ntiles, mtiles, work, total);
+hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s, int mode, int tile_px) {
+    if (ntiles >= (1 << 20) || mtiles >= (1 << 12)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ace_worklist_kernel, dim3(1), dim3(1024), 0, s, cnt, ntiles, mtiles, mode, tile_px, work, total);
     return hipGetLastError();
 }
 
@@ -129,7 +158,11 @@ __global__ __launch_bounds__(256) void ace_gtable_kernel(const float* __restrict
         float sacc = 0.f;
         const long long col = (long long)(b * lut_bs + j) * lut_ns;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) sacc += lut[(long long)((t * 2 + gb) * C + c) * lut_rs + col];
+        for (int t = 0; t < 9; ++t) {
+            const long long row = (long long)(t * 2 + gb) * C + c;
+            // lut_rs == 1: rows contiguous per column; else the C4 layout [row / 4][column][4] written by the f16x3 LUT GEMM
+            sacc += lut_rs == 1 ? lut[row + col] : lut[(row >> 2) * 4 * lut_rs + col + (row & 3)];
+        }
         v += sacc * lut_mul;
     }
     gtab[i] = v;
@@ -144,11 +177,76 @@ hipError_t ace_gtable(const float* bias_g, const float* bias_b, const float* gco
 }
 
 // ---- interior pass, exact-f32 path (NCHW in, NCHW out): HBM-bound streaming ----------------------------------------------
-// One block = 256 consecutive pixels of one sample x CG channels; the sample's table slice [19][2][CG] sits in LDS (row
-// pitch padded by one float: lanes that hold different labels hit different banks).
+// One thread = 4 consecutive pixels of a row (16-byte loads / stores when all four are interior), one block = 1024 pixels of
+// one sample x CG channels; the sample's table slice [19][2][CG] sits in LDS (row pitch padded by one float: lanes that hold
+// different labels hit different banks).
 //      out = act((bn_a x + nv nz + bn_d) (1 + gamma) + beta)          (normalization.py:111-112,182; architecture.py:95)
 constexpr int IN_CG = 32;
 __global__ __launch_bounds__(256) void ace_interior_f32_kernel(const AceInteriorParams q) {
+    constexpr int RS = 2 * IN_CG + 1;
+    __shared__ float gt[19 * RS];
+    __shared__ float pa[IN_CG], pd[IN_CG], pn[IN_CG];
+    const int HW = q.H * q.W, ppb = (HW + 1023) / 1024;
+    const int b = blockIdx.x / ppb, c0 = blockIdx.y * IN_CG;
+    const int pix = (blockIdx.x % ppb) * 1024 + threadIdx.x * 4;          // W % 4 == 0: the four pixels share a row
+    uchar4 j4 = make_uchar4(255, 255, 255, 255);
+    if (pix < HW) j4 = *reinterpret_cast<const uchar4*>(q.u5 + (long long)b * HW + pix);
+    const bool i0 = j4.x < 19, i1 = j4.y < 19, i2 = j4.z < 19, i3 = j4.w < 19;
+    if (__syncthreads_or(i0 || i1 || i2 || i3) == 0) return;             // no interior pixel in this block
+    for (int i = threadIdx.x; i < 19 * 2 * IN_CG; i += 256) {
+        const int jj = i / (2 * IN_CG), r = i % (2 * IN_CG), gb = r / IN_CG, c = c0 + r % IN_CG;
+        gt[jj * RS + r] = c < q.C ? q.gtab[(((long long)b * 19 + jj) * 2 + gb) * q.C + c] : 0.f;
+    }
+    if (threadIdx.x < IN_CG) {
+        const int c = c0 + threadIdx.x;
+        pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
+        pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
+        pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
+    }
+    __syncthreads();
+    if (!(i0 || i1 || i2 || i3)) return;
+    const int y = pix / q.W, x = pix - y * q.W;
+    const float* np = q.noise + (long long)b * q.noise_bstride + (long long)x * q.H + y;      // plane layout [W][H]
+    const float nz0 = np[0], nz1 = np[q.H], nz2 = np[2 * q.H], nz3 = np[3 * q.H];
+    const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up);
+    const float* xp = q.x + ((long long)b * q.C + c0) * xHW + (y >> q.x_up) * xW + (x >> q.x_up);
+    float* op = reinterpret_cast<float*>(q.out) + ((long long)b * q.C + c0) * HW + pix;
+    const float *g0 = gt + (i0 ? j4.x : 0) * RS, *g1 = gt + (i1 ? j4.y : 0) * RS, *g2 = gt + (i2 ? j4.z : 0) * RS,
+                *g3 = gt + (i3 ? j4.w : 0) * RS;
+    const int cmax = q.C - c0 < IN_CG ? q.C - c0 : IN_CG;
+    const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
+    const bool all4 = i0 && i1 && i2 && i3;
+#pragma unroll 4
+    for (int c = 0; c < cmax; ++c) {
+        float4 xv;
+        if (q.x_up) {
+            const float2 t = *reinterpret_cast<const float2*>(xp + (long long)c * xHW);
+            xv = make_float4(t.x, t.x, t.y, t.y);
+        } else {
+            xv = *reinterpret_cast<const float4*>(xp + (long long)c * xHW);
+        }
+        const float a = pa[c], n = pn[c], d = pd[c];
+        float4 o;
+        o.x = (a * xv.x + n * nz0 + d) * (1.f + g0[c]) + g0[IN_CG + c];
+        o.y = (a * xv.y + n * nz1 + d) * (1.f + g1[c]) + g1[IN_CG + c];
+        o.z = (a * xv.z + n * nz2 + d) * (1.f + g2[c]) + g2[IN_CG + c];
+        o.w = (a * xv.w + n * nz3 + d) * (1.f + g3[c]) + g3[IN_CG + c];
+        o.x = fmaxf(o.x, slope * o.x); o.y = fmaxf(o.y, slope * o.y);
+        o.z = fmaxf(o.z, slope * o.z); o.w = fmaxf(o.w, slope * o.w);
+        float* oc = op + (long long)c * HW;
+        if (all4) {
+            *reinterpret_cast<float4*>(oc) = o;
+        } else {
+            if (i0) oc[0] = o.x;
+            if (i1) oc[1] = o.y;
+            if (i2) oc[2] = o.z;
+            if (i3) oc[3] = o.w;
+        }
+    }
+}
+
+// one pixel per thread (4-byte accesses): kept selectable for A/B measurements (AceInteriorParams::variant = 1)
+__global__ __launch_bounds__(256) void ace_interior_f32_scalar_kernel(const AceInteriorParams q) {
     constexpr int RS = 2 * IN_CG + 1;
     __shared__ float gt[19 * RS];
     __shared__ float pa[IN_CG], pd[IN_CG], pn[IN_CG];
@@ -189,9 +287,120 @@ __global__ __launch_bounds__(256) void ace_interior_f32_kernel(const AceInterior
 
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU) return hipErrorInvalidValue;
+    if (q.W % 4 != 0) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
-    dim3 grid((unsigned)(q.B * ((HW + 255) / 256)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
+    if (q.variant == 1) {
+        dim3 grid1((unsigned)(q.B * ((HW + 255) / 256)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
+        hipLaunchKernelGGL(ace_interior_f32_scalar_kernel, grid1, dim3(256), 0, s, q);
+        return hipGetLastError();
+    }
+    dim3 grid((unsigned)(q.B * ((HW + 1023) / 1024)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
     hipLaunchKernelGGL(ace_interior_f32_kernel, grid, dim3(256), 0, s, q);
+    return hipGetLastError();
+}
+
+// ---- interior pass, f16x3 path (tile-skip mode): C4 in, SH16 out --------------------------------------------------------
+// One thread = one pixel x 8 channels (one SH16 unit pair); one block = 256 consecutive pixels x IS_GPB channel groups.
+// Only pixels of tiles of 32 x 16 without a boundary pixel are written (the conv kernel writes every pixel of the others).
+//      o = act((bn_a x + nv nz + bn_d) (1 + gamma) + beta) * out_scale [* extra];  hi = f16(o), lo = f16(o - hi)
+constexpr int IS_GPB = 4;
+typedef _Float16 is_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 is_b8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInteriorParams q) {
+    constexpr int CB = IS_GPB * 8, RS = 2 * CB + 4;          // row pitch: 16-byte aligned, labels spread over the banks
+    __shared__ __attribute__((aligned(16))) float gt[19 * RS];
+    __shared__ __attribute__((aligned(16))) float pa[CB], pd[CB], pn[CB];
+    sh16_mode_on();
+    float extra = 1.f;
+    if (q.pass == 1) {
+        extra = sh16_dyn_extra(*q.out_amax);
+        if (extra == 1.f) return;                             // nothing to repair (the normal case)
+    }
+    const int HW = q.H * q.W, ppb = (HW + 255) / 256;
+    const int b = blockIdx.x / ppb, c0 = blockIdx.y * CB;
+    const int pix = (blockIdx.x % ppb) * 256 + threadIdx.x;
+    const int y = pix / q.W, x = pix - y * q.W;
+    const int tiles_x = (q.W + 31) >> 5, tiles_y = (q.H + 15) >> 4;
+    bool mine = false;
+    int j = 255;
+    if (pix < HW) {
+        mine = q.cnt[(b * tiles_y + (y >> 4)) * tiles_x + (x >> 5)] == 0;
+        j = q.u5[(long long)b * HW + pix];
+        mine = mine && j < 19;                                // (always true in such a tile)
+    }
+    const int any = __syncthreads_or(mine);
+    float amax = 0.f;
+    if (any) {
+        for (int i = threadIdx.x; i < 19 * 2 * CB; i += 256) {
+            const int jj = i / (2 * CB), r = i % (2 * CB), gb = r / CB, c = c0 + r % CB;
+            gt[jj * RS + r] = c < q.C ? q.gtab[(((long long)b * 19 + jj) * 2 + gb) * q.C + c] : 0.f;
+        }
+        if (threadIdx.x < CB) {
+            const int c = c0 + threadIdx.x;
+            pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
+            pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
+            pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
+        }
+        __syncthreads();
+        if (mine) {
+            const float nz = q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y];
+            const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up);
+            const long long xpix = (long long)(y >> q.x_up) * xW + (x >> q.x_up);
+            const float4* xp = reinterpret_cast<const float4*>(q.x) + (long long)b * (q.C >> 2) * xHW + xpix;
+            const int Go = (q.C + 7) >> 3;
+            uint4* op = reinterpret_cast<uint4*>(q.out) + (long long)b * Go * 2 * HW + pix;
+            const float* g = gt + j * RS;
+            const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
+            const float osc = q.out_scale * extra;
+#pragma unroll
+            for (int gq = 0; gq < IS_GPB; ++gq) {
+                const int c = c0 + gq * 8;
+                if (c >= q.C) break;
+                float xv[8];
+                {
+                    const float4 a = xp[(long long)(c >> 2) * xHW];
+                    xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+                    if (c + 4 < q.C) {
+                        const float4 d = xp[(long long)((c >> 2) + 1) * xHW];
+                        xv[4] = d.x; xv[5] = d.y; xv[6] = d.z; xv[7] = d.w;
+                    } else {
+                        xv[4] = xv[5] = xv[6] = xv[7] = 0.f;
+                    }
+                }
+                is_h8 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int cc = gq * 8 + e;
+                    const float nrm = pa[cc] * xv[e] + pn[cc] * nz + pd[cc];
+                    float o = nrm * (1.f + g[cc]) + g[CB + cc];
+                    o = fmaxf(o, slope * o) * osc;
+                    if (c + e >= q.C) o = 0.f;                 // padding channels of the last group hold zeros
+                    amax = fmaxf(amax, fabsf(o));
+                    if (q.bf16) {
+                        const __bf16 t = (__bf16)o;
+                        vh[e] = __builtin_bit_cast(_Float16, t);
+                        vl[e] = (_Float16)0.f;
+                    } else {
+                        const _Float16 h = (_Float16)o;
+                        vh[e] = h;
+                        vl[e] = (_Float16)(o - (float)h);
+                    }
+                }
+                const long long u = (long long)(c >> 3) * 2 * HW;
+                op[u] = __builtin_bit_cast(uint4, vh);
+                op[u + HW] = __builtin_bit_cast(uint4, vl);
+            }
+        }
+    }
+    // pass 0: the tensor's maximum at the first-pass scale (uniform: every thread of every block gets here)
+    if (q.pass == 0 && q.out_amax) sh16_block_slot_max(q.out_amax, amax);
+}
+
+hipError_t ace_interior_sh16(const AceInteriorParams& q, hipStream_t s) {
+    if (q.act > ACT_RELU || !q.cnt || (q.C & 3)) return hipErrorInvalidValue;
+    const int HW = q.H * q.W;
+    dim3 grid((unsigned)(q.B * ((HW + 255) / 256)), (unsigned)((q.C + IS_GPB * 8 - 1) / (IS_GPB * 8)));
+    hipLaunchKernelGGL(ace_interior_sh16_kernel, grid, dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

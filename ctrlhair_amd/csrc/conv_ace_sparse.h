@@ -25,7 +25,7 @@ template <int TH, int NSUB>
 __device__ __forceinline__ void ace_sparse_body(const ConvParams& p, float* smem, int b0, int y0, int x0, int mtile64, int s0,
                                                 int cnt, const uint16_t* __restrict__ lst) {
     using Cfg = SpCfg<TH>;
-    constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, NG = Cfg::NG, NLOAD = Cfg::NLOAD, SE = Cfg::SE, CK = Cfg::CK;
+    constexpr int PW = Cfg::PW, PLANE = Cfg::PLANE, NG = Cfg::NG, NLOAD = Cfg::NLOAD, SE = Cfg::SE, CK = Cfg::CK;
     constexpr int NA = NSUB > 0 ? NSUB : 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int HW = p.H * p.W;

@@ -5,8 +5,14 @@ template <int TH>
 static hipError_t launch_ace_sparse(ConvParams p, hipStream_t s) {
     using Cfg = SpCfg<TH>;
     auto kern = conv_ace_sparse_kernel<TH>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    if (e != hipSuccess) return e;
+    static bool attr_set[64] = {};                           // per device (a process may own handles on several GPUs)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
     p.nchunks = (p.Cin + Cfg::CK - 1) / Cfg::CK;
     p.mtiles = (p.C + 31) / 32;                    // 64-row wave tiles of 32 channels (gamma | beta)
     p.tiles_x = (p.W + 31) / 32;

@@ -397,12 +397,14 @@ template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
 hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ConvCfg<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
     auto kern = conv_mfma_kernel<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                           // per device (a process may own handles on several GPUs)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     p.nchunks = (p.Cin + CK - 1) / CK;
     if (p.Hin == 0) { p.Hin = p.H; p.Win = p.W; }

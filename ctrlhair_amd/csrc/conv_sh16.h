@@ -733,7 +733,11 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     const int wn = wave & 3, ltid = tid & 255;
     const int HW = p.H * p.W;
     const int G = p.Cin >> 3;
-    const int ntiles = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    // Tile-skip mode of the exact SPADE-interior reduction (ace_sparse.h; EPI_ACE only): p.sp_work lists the (spatial tile, row
+    // tile) pairs whose spatial tile holds at least one boundary pixel -- tiles made of interior pixels only are served by
+    // ace_interior_sh16 and never reach this kernel.  Same static stride, over the list instead of the full tile grid.
+    const bool sp = EPI == EPI_ACE && p.sp_work != nullptr;
+    const int ntiles = sp ? p.sp_total[0] : p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
     const int first = xcd_remap(blockIdx.x, gridDim.x);      // logical slot of this block inside one round of tiles
     const int my_tiles = first < ntiles ? (ntiles - 1 - first) / (int)gridDim.x + 1 : 0;
     const int Q = my_tiles * p.nchunks;                       // chunks this block will process
@@ -741,8 +745,15 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
 
     auto tile_coords = [&](int k, int& mtile64, int& x0, int& y0, int& b0) {
         const int L = first + k * (int)gridDim.x;
-        mtile64 = L % p.mtiles;
-        int nt = L / p.mtiles;
+        int nt;
+        if (sp) {
+            const unsigned wk = p.sp_work[L];
+            mtile64 = (int)(wk >> 20);
+            nt = (int)(wk & 0xFFFFFu);
+        } else {
+            mtile64 = L % p.mtiles;
+            nt = L / p.mtiles;
+        }
         const int txi = nt % p.tiles_x; nt /= p.tiles_x;
         const int tyi = nt % p.tiles_y; nt /= p.tiles_y;
         x0 = txi * TW; y0 = tyi * TH; b0 = nt * TB;
@@ -789,9 +800,15 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             }
         };
         const uint4* gA = reinterpret_cast<const uint4*>(p.wpk);
+        int dma_k = -1, dma_mt = 0;
         auto dma_A = [&](int q) {                                     // A fragments of global chunk q -> its LDS stage
-            int mt, x0, y0, b0;
-            tile_coords(q / p.nchunks, mt, x0, y0, b0);
+            const int kq = q / p.nchunks;
+            if (kq != dma_k) {                                        // (tile-skip mode: tile_coords reads the work list)
+                int x0, y0, b0;
+                tile_coords(kq, dma_mt, x0, y0, b0);
+                dma_k = kq;
+            }
+            const int mt = dma_mt;
             const uint4* src = gA + ((long long)mt * p.nchunks + q % p.nchunks) * AUNITS + ltid;
             uint4* dst = smem_u + (q & 1) * STAGE + UNITS + wn * 64;
 #pragma unroll
@@ -1076,17 +1093,20 @@ hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
     constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
                                           : 2 * V3_STAGE * 16;
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
+    // per device: a process may own handles on several GPUs (ch_api.cpp DeviceGuard)
+    static bool attr_set[64] = {};
+    static int ncus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            V3_LDS);
         if (e != hipSuccess) return e;
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        attr_set = true;
+        ncus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        attr_set[dev] = true;
     }
+    const int ncu = ncus[dev];
     p.nchunks = (p.Cin + 15) / 16;
     p.mtiles = (rows + 63) / 64;
     p.tiles_x = (p.W + TW - 1) / TW;
@@ -1152,12 +1172,14 @@ template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool FUSE = fa
 hipError_t launch_sh16(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     auto kern = conv_sh16_kernel<KS, TW, TH, TB, EPI, TERMS, FUSE, INC4, S2D, D2S>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                           // per device (a process may own handles on several GPUs)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     p.nchunks = (p.Cin + 15) / 16;
     p.mtiles = (rows + 63) / 64;
@@ -1196,6 +1218,16 @@ hipError_t launch_sh16_ws2(ConvParams p, int rows, hipStream_t stream);     // c
 
 // implemented in conv_inst_sh16*.hip
 // ---- layer -> kernel selection, shared by the 3-term (f32-class) and 1-term (plain f16 operands) instantiation files
+// true when dispatch_sh16_ace serves this layer with the wave-specialised persistent kernel -- the only ACE kernel that
+// honours p.sp_work (tile-skip mode of the exact SPADE-interior reduction); sean_model.cpp asks before it sets the list
+inline bool sh16_ace_uses_ws(const ConvParams& p) {
+    const int rows = ((p.C + 31) / 32) * 64;
+    const long long ntiles = (long long)(rows / 64) * ((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+    if ((p.dbg & 2048) && p.Cin == 128 && p.W >= 32) return false;
+    const bool ws_ok = p.W >= 32 && p.Cin >= 48;
+    return ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512));
+}
+
 template <int TERMS>
 hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
     if (p.act > ACT_RELU) return hipErrorInvalidValue;   // the ACE epilogue implements none / leaky / relu only

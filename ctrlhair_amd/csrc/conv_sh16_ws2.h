@@ -454,20 +454,22 @@ hipError_t launch_sh16_ws2(ConvParams p, int rows, hipStream_t stream) {
     if (p.Cin != 128 || p.in_mode != IN_DIRECT) return hipErrorInvalidValue;
     constexpr int UNITS = 4 * 34 * 10, STAGE = UNITS + 9 * 4 * 64, SMALL = 40 + 64 + (10 * 34 + 15) / 16;
     constexpr int LDS = (2 * STAGE + 2 * SMALL) * 16;
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                           // per device (a process may own handles on several GPUs)
+    static int ncus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sh16_ws2_kernel<TERMS, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sh16_ws2_kernel<TERMS, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        attr_set = true;
+        ncus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        attr_set[dev] = true;
     }
+    const int ncu = ncus[dev];
     p.nchunks = 8;
     p.mtiles = (rows + 63) / 64;
     p.tiles_x = (p.W + 31) / 32;

@@ -5,11 +5,13 @@
 
 namespace chk {
 hipError_t label_downsample(const uint8_t* in, uint8_t* out, int B, int S, int r, hipStream_t s);
+// need (optional, [B][H][W]): pixels with need == 0 are not written (ace_sparse.h: nothing reads them)
 hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* bias, float* out, int B, int H, int W,
-                          int K, int relu, hipStream_t s, int c4 = 0);
+                          int K, int relu, hipStream_t s, int c4 = 0, const uint8_t* need = nullptr);
 // `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
-                               int K, int relu, float scale, hipStream_t s, int bf16 = 0);
+                               int K, int relu, float scale, hipStream_t s, int bf16 = 0, const uint8_t* need = nullptr,
+                               const int* tile_cnt = nullptr);   // tile_cnt: boundary pixels per tile of 32 x 16 (tile-skip mode)
 // amax: device slot of a dynamically scaled tensor (sh16.h), null = static scale
 hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, const unsigned* amax,
                        hipStream_t s, int bf16 = 0);

@@ -35,10 +35,17 @@ constexpr int OH_KC = 32;
 __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __restrict__ lab,
                                                              const float* __restrict__ table,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int B, int H, int W, int K, int relu, int c4) {
+                                                             int B, int H, int W, int K, int relu, int c4,
+                                                             const uint8_t* __restrict__ need) {
     __shared__ float T[19 * 9 * OH_KC];
     __shared__ float bs[OH_KC];
     const int k0 = blockIdx.y * OH_KC;
+    bool wanted = true;
+    if (need) {       // exact SPADE-interior reduction: only pixels next to a boundary pixel are ever read (ace_sparse.h)
+        const long long pq = blockIdx.x * 256LL + threadIdx.x;
+        wanted = pq < (long long)B * H * W && need[pq];
+        if (__syncthreads_or(wanted) == 0) return;
+    }
     for (int i = threadIdx.x; i < 19 * 9 * OH_KC; i += 256) {
         const int jt = i / OH_KC, kk = i % OH_KC;
         T[i] = (k0 + kk < K) ? table[(long long)jt * K + k0 + kk] : 0.f;
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
     __syncthreads();
     const long long HW = (long long)H * W;
     const long long pix = blockIdx.x * 256LL + threadIdx.x;
-    if (pix >= B * HW) return;
+    if (pix >= B * HW || !wanted) return;
     const int b = (int)(pix / HW);
     const int y = (int)((pix % HW) / W), x = (int)(pix % W);
     int jt[9];
@@ -74,10 +81,10 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
 }
 
 hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* bias, float* out, int B, int H, int W,
-                          int K, int relu, hipStream_t s, int c4) {
+                          int K, int relu, hipStream_t s, int c4, const uint8_t* need) {
     const long long npix = (long long)B * H * W;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
-    hipLaunchKernelGGL(onehot_conv3x3_kernel, grid, dim3(256), 0, s, lab, table, bias, out, B, H, W, K, relu, c4);
+    hipLaunchKernelGGL(onehot_conv3x3_kernel, grid, dim3(256), 0, s, lab, table, bias, out, B, H, W, K, relu, c4, need);
     return hipGetLastError();
 }
 
@@ -88,11 +95,33 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t* __restrict__ lab,
                                                                   const float* __restrict__ table,
                                                                   const float* __restrict__ bias, uint4* __restrict__ out,
-                                                                  int B, int H, int W, int K, int relu, float scale, int bf16) {
+                                                                  int B, int H, int W, int K, int relu, float scale, int bf16,
+                                                                  const uint8_t* __restrict__ need, const int* __restrict__ tcnt) {
     // Table slice in LDS with a padded row pitch (36 floats: consecutive (label, tap) rows start 4 banks apart, so lanes
     // that hold different labels do not collide on the same banks) and one extra all-zero row that taps outside the image
     // point at -- every lane then issues the same 9 x 2 ds_read_b128 per 8 channels, no predication.
     constexpr int RS = OH_KC + 4, ZROW = 19 * 9;
+    bool wanted = true;
+    if (need) {       // exact SPADE-interior reduction: only pixels next to a boundary pixel are ever read (ace_sparse.h)
+        const long long pq = blockIdx.x * 256LL + threadIdx.x;
+        wanted = pq < (long long)B * H * W && need[pq];
+        if (__syncthreads_or(wanted) == 0) return;
+    }
+    if (tcnt) {       // tile-skip mode (f16x3 path): the conv only stages the tiles of 32 x 16 that hold a boundary pixel, plus a
+                      // one-pixel ring around them -- pixels further inside skipped tiles are never read
+        const long long pq = blockIdx.x * 256LL + threadIdx.x;
+        wanted = false;
+        if (pq < (long long)B * H * W) {
+            const long long hw = (long long)H * W;
+            const int bq = (int)(pq / hw), yq = (int)((pq % hw) / W), xq = (int)(pq % W);
+            const int ttx = (W + 31) >> 5, tty = (H + 15) >> 4;
+            const int ya = (yq > 0 ? yq - 1 : 0) >> 4, yb = (yq + 1 < H ? yq + 1 : H - 1) >> 4;
+            const int xa = (xq > 0 ? xq - 1 : 0) >> 5, xb = (xq + 1 < W ? xq + 1 : W - 1) >> 5;
+            const int* tc = tcnt + (long long)bq * tty * ttx;
+            wanted = (tc[ya * ttx + xa] | tc[ya * ttx + xb] | tc[yb * ttx + xa] | tc[yb * ttx + xb]) != 0;
+        }
+        if (__syncthreads_or(wanted) == 0) return;
+    }
     sh16_mode_on();       // (the scale comes from a bound of the table sums: nothing can saturate; kept for uniformity)
     __shared__ __attribute__((aligned(16))) float T[(ZROW + 1) * RS];
     __shared__ __attribute__((aligned(16))) float bs[OH_KC];
@@ -105,7 +134,7 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
     __syncthreads();
     const long long HW = (long long)H * W;
     const long long pix = blockIdx.x * 256LL + threadIdx.x;
-    if (pix >= B * HW) return;
+    if (pix >= B * HW || !wanted) return;
     const int b = (int)(pix / HW);
     const int y = (int)((pix % HW) / W), x = (int)(pix % W);
     int jt[9];
@@ -150,11 +179,11 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
 }
 
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
-                               int K, int relu, float scale, hipStream_t s, int bf16) {
+                               int K, int relu, float scale, hipStream_t s, int bf16, const uint8_t* need, const int* tile_cnt) {
     const long long npix = (long long)B * H * W;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
     hipLaunchKernelGGL(onehot_conv3x3_sh16_kernel, grid, dim3(256), 0, s, lab, table, bias, static_cast<uint4*>(out), B, H,
-                       W, K, relu, scale, bf16);
+                       W, K, relu, scale, bf16, need, tile_cnt);
     return hipGetLastError();
 }
 
@@ -324,7 +353,6 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
                                                        int Cin, int H, int W, int c4) {
     __shared__ float patch[CI_CK][CI_TH + 2][CI_TW + 2];
-    __shared__ float ws[3][CI_CK][9];
     const int tx = threadIdx.x % CI_TW, ty = threadIdx.x / CI_TW;
     const int x0 = blockIdx.x * CI_TW, y0 = blockIdx.y * CI_TH, b = blockIdx.z;
     const long long HW = (long long)H * W;
@@ -344,20 +372,21 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
             }
             patch[c][py][px] = v;
         }
-        for (int e = threadIdx.x; e < 3 * CI_CK * 9; e += 256) {
-            const int co = e / (CI_CK * 9), c = (e / 9) % CI_CK, t = e % 9;
-            ws[co][c][t] = (c0 + c < Cin) ? w[((long long)co * Cin + c0 + c) * 9 + t] : 0.f;
-        }
         __syncthreads();
+        // weights: wave-uniform addresses -> scalar loads, SGPR operands of the FMAs (as LDS broadcasts they were 3 of the 4
+        // LDS reads per tap and made the kernel LDS-issue bound); Cin % CI_CK == 0 or the tail channels hold zeros in `patch`
+        const float* w0 = w + (long long)c0 * 9;
 #pragma unroll
-        for (int c = 0; c < CI_CK; ++c)
+        for (int c = 0; c < CI_CK; ++c) {
+            if (c0 + c >= Cin) break;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float v = patch[c][ty + t / 3][tx + t % 3];
-                a0 += ws[0][c][t] * v;
-                a1 += ws[1][c][t] * v;
-                a2 += ws[2][c][t] * v;
+                a0 += w0[c * 9 + t] * v;
+                a1 += w0[(long long)Cin * 9 + c * 9 + t] * v;
+                a2 += w0[(long long)Cin * 18 + c * 9 + t] * v;
             }
+        }
     }
     const int xx = x0 + tx, yy = y0 + ty;
     if (xx < W && yy < H) {

@@ -471,7 +471,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         sp_work[k].clear();
     }
     gtab = nullptr;
-    if (sparse && !use_sh16) {
+    if (sparse) {
         int cmax = 0;
         for (const auto& b : blocks)
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
@@ -481,11 +481,14 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 const int r = ms >> k;
                 if (r < sparse_min_r || r < 32) continue;
                 const int mt = (a->C + 31) / 32;
-                SparseLevel& L = sp_level[k][sparse_tile_h(mt) == 16 ? 1 : 0];
+                // f16x3 path: tile-skip mode of the wave-specialised kernel, whose tiles are 32 x 16
+                const int th = use_sh16 ? 16 : sparse_tile_h(mt, r);
+                SparseLevel& L = sp_level[k][th == 16 ? 1 : 0];
                 if (!L.u5) {
-                    L.TH = sparse_tile_h(mt);
+                    L.TH = th;
                     L.cap_tiles = mb * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
                     L.u5 = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
+                    L.need = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
                     L.list = static_cast<uint16_t*>(B.dalloc((size_t)L.cap_tiles * 32 * L.TH * sizeof(uint16_t)));
                     L.cnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
                 }
@@ -495,7 +498,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     SparseWork w;
                     w.mtiles = mt;
                     w.TH = L.TH;
-                    w.cap = (long long)L.cap_tiles * sparse_max_tasks(L.TH, mt);
+                    w.mode = use_sh16 ? 1 : 0;
+                    w.cap = (long long)L.cap_tiles * (use_sh16 ? mt : sparse_max_tasks(L.TH, mt));
                     w.work = static_cast<unsigned*>(B.dalloc((size_t)w.cap * sizeof(unsigned)));
                     w.total = static_cast<int*>(B.dalloc(4 * sizeof(int)));
                     sp_work[k].push_back(w);
@@ -613,13 +617,13 @@ struct Runner {
                 if (!L.u5) return nullptr;
                 const int ntiles = B * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
                 if (!lvl_done[k][ti]) {
-                    check(ace_classify(lab, L.u5, L.list, L.cnt, B, r, r, L.TH, st), "ace_classify");
+                    check(ace_classify(lab, L.u5, L.need, L.list, L.cnt, B, r, r, L.TH, st), "ace_classify");
                     lvl_done[k][ti] = true;
                 }
                 bool done = false;
                 for (int d : work_done[k]) done = done || d == mt;
                 if (!done) {
-                    check(ace_worklist(L.cnt, ntiles, mt, w.work, w.total, st), "ace_worklist");
+                    check(ace_worklist(L.cnt, ntiles, mt, w.work, w.total, st, w.mode, 32 * L.TH), "ace_worklist");
                     work_done[k].push_back(mt);
                 }
                 return &w;
@@ -642,7 +646,7 @@ struct Runner {
     };
     // what: bit 0 = style LUT, bit 1 = SPADE hidden activations
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
-                        float* splitk, bool prof, int what = 3) {
+                        float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr) {
         const int r = S / a.res_div;
         const uint8_t* lab = labels_at(labfull, a.res_div);
         AcePrep q;
@@ -715,9 +719,9 @@ struct Runner {
         }
         if (!(what & 2)) return q;
         if (m.use_sh16)
-            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2), "mlp_shared");
+            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2, need, tile_cnt), "mlp_shared");
         else
-            check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s), "mlp_shared");
+            check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, need), "mlp_shared");
         return q;
     }
 
@@ -747,17 +751,38 @@ struct Runner {
         const int r = S / a.res_div;
         const uint8_t* lab = labels_at(labfull, a.res_div);
         const double npix = (double)B * r * r;
+        // exact SPADE-interior reduction (ace_sparse.h): classification of the level + work list of this layer's row tiles.
+        // f16x3 path: tile-skip mode, honoured by the wave-specialised kernel only (conv_sh16.h)
+        const SparseWork* sw = sparse_prepare(a, lab, r);
+        if (sw && m.use_sh16) {
+            ConvParams t{};
+            t.C = a.C;
+            t.W = t.H = r;
+            t.B = B;
+            t.Cin = HID;
+            t.dbg = m.dbg;
+            if (!sh16_ace_uses_ws(t)) sw = nullptr;
+        }
+        const SparseLevel* SL = nullptr;
+        if (sw) {
+            int lk = 0;
+            while ((1 << lk) < a.res_div) ++lk;
+            SL = &m.sp_level[lk][sw->TH == 16 ? 1 : 0];
+        }
+        // the label-table kernel only writes the hidden activations the conv will read
+        const uint8_t* need = (SL && !m.use_sh16 && (m.dbg & 131072)) ? SL->need : nullptr;
+        const int* tile_cnt = (SL && m.use_sh16) ? SL->cnt : nullptr;
         AcePrep q;
         if (ahead) {
             q = prepared[a.index];
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else if (ahead_luts && a.styled) {
-            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2);     // label table inline
+            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt);     // label table inline
             q = prepared[a.index];
             q.actv = m.actv;
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else {
-            q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true);
+            q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true, 3, need, tile_cnt);
         }
         ConvParams p{};
         p.in = q.actv;
@@ -794,39 +819,53 @@ struct Runner {
         p.out_amax = m.amax_slots + 2 * a.index;
         if ((m.dbg & 256) && a.index == m.dbg_sel) p.partial = m.splitk_ws;      // cycle stamps of this launch (profiling)
         else p.dbg &= ~256;
-        const SparseWork* sw = m.use_sh16 ? nullptr : sparse_prepare(a, lab, r);
         if (sw) {
-            // interior pixels: elementwise with the per-(sample, label) gamma/beta rows; boundary pixels: compacted conv
-            int lk = 0;
-            while ((1 << lk) < a.res_div) ++lk;
-            const SparseLevel& L = m.sp_level[lk][sw->TH == 16 ? 1 : 0];
+            // interior pixels: elementwise with the per-(sample, label) gamma/beta rows; the others: conv over the compacted
+            // boundary pixels (exact-f32 path) / over the tiles that hold a boundary pixel (f16x3 path)
+            const SparseLevel& L = *SL;
             const double xpp = 4.0 * a.C / (x_up ? 4.0 : 1.0), opp = 4.0 * a.C;
-            timed(3, 0.0, 0.0, sw->total, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
-                check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
-                AceInteriorParams ip{};
-                ip.x = x;
-                ip.out = hout;
-                ip.u5 = L.u5;
-                ip.gtab = m.gtab;
-                ip.bn_a = a.bn_a;
-                ip.bn_d = a.bn_d;
-                ip.nv = a.nv;
-                ip.noise = noise + noff;
-                ip.noise_bstride = (long long)nf;
-                ip.B = B;
-                ip.C = a.C;
-                ip.H = r;
-                ip.W = r;
-                ip.x_up = x_up;
-                ip.act = act;
-                check(ace_interior_f32(ip, st), "ace interior");
-            });
+            AceInteriorParams ip{};
+            ip.x = x;
+            ip.out = hout;
+            ip.u5 = L.u5;
+            ip.cnt = L.cnt;
+            ip.gtab = m.gtab;
+            ip.bn_a = a.bn_a;
+            ip.bn_d = a.bn_d;
+            ip.nv = a.nv;
+            ip.noise = noise + noff;
+            ip.noise_bstride = (long long)nf;
+            ip.B = B;
+            ip.C = a.C;
+            ip.H = r;
+            ip.W = r;
+            ip.x_up = x_up;
+            ip.act = act;
+            ip.out_scale = a.out_scale;
+            ip.out_amax = m.amax_slots + 2 * a.index;
+            ip.bf16 = m.terms == 2;
+            ip.variant = (m.dbg & 65536) ? 1 : 0;
             p.sp_list = L.list;
             p.sp_cnt = L.cnt;
             p.sp_work = sw->work;
             p.sp_total = sw->total;
+            timed(3, 0.0, 0.0, sw->total, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
+                // (the f16x3 LUT is stored pre-multiplied by the ACE output scale)
+                check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, m.use_sh16 ? 1.f / a.out_scale : 1.f,
+                                 m.gtab, B, a.C, st), "ace_gtable");
+                check(m.use_sh16 ? ace_interior_sh16(ip, st) : ace_interior_f32(ip, st), "ace interior");
+            });
             timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 0.0, sw->total, 32.0 * 64 * 2.0 * HID * 9, 4.0 * HID + xpp + opp,
-                  4.0 * 2.0 * a.C * HID * 9, npix, [&] { check(conv_ace_sparse(p, L.TH, st), "spade conv (boundary pixels)"); });
+                  4.0 * 2.0 * a.C * HID * 9, npix, [&] {
+                      if (m.use_sh16) check(conv_sh16_ace(p, st), "spade conv (tiles with boundary pixels)");
+                      else check(conv_ace_sparse(p, L.TH, st), "spade conv (boundary pixels)");
+                  });
+            if (m.use_sh16) {      // second passes: return at once unless the recorded maximum left the f16 window (sh16.h)
+                ip.pass = 1;
+                check(ace_interior_sh16(ip, st), "ace interior (second pass)");
+                p.pass = 1;
+                check(conv_sh16_ace(p, st), "spade conv (second pass)");
+            }
             return;
         }
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] {

@@ -105,8 +105,12 @@ struct SeanModel {
     int sparse_th = 0;                         // option "sean.sparse_th": tile height 8 / 16 (0 = by the layer's row tiles)
     SparseLevel sp_level[6][2];                // [level][0: tiles of 32 x 8 | 1: tiles of 32 x 16]
     std::vector<SparseWork> sp_work[6];
-    // few row tiles (C <= 64): taller tiles, so that a tile's sub-tiles still fill the four waves of a block
-    int sparse_tile_h(int mtiles) const { return sparse_th == 8 || sparse_th == 16 ? sparse_th : (mtiles <= 2 ? 16 : 8); }
+    // Taller tiles where a tile of 32 x 8 carries few sub-tiles: few row tiles (C <= 64: the four waves of a block split the
+    // sub-tiles), and the full-resolution level of large images (measured at 512^2, B = 16: 5.26 vs 5.64 ms per C = 128 ACE;
+    // at 256^2 and below the 32 x 8 tiles are faster: 5.44 vs 5.62, 4.13 vs 4.27, 2.69 vs 2.80 ms)
+    int sparse_tile_h(int mtiles, int r) const {
+        return sparse_th == 8 || sparse_th == 16 ? sparse_th : ((mtiles <= 2 || r >= 512) ? 16 : 8);
+    }
     float* gtab = nullptr;
     std::map<std::string, float*> taps;
     // profiling

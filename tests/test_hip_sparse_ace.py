@@ -17,7 +17,12 @@ def _gen(sd, mb, ms, path, sparse, extra=None):
     from ctrlhair_amd.sean.generator import SeanGenerator
     opts = {'sean.sparse': sparse}
     opts.update(extra or {})
-    return SeanGenerator(0, f16x3=MODE[path], options=opts).load_state_dict(sd, max_batch=mb, max_size=ms)
+    g = SeanGenerator(0, f16x3=MODE[path], options=opts).load_state_dict(sd, max_batch=mb, max_size=ms)
+    if path == 'f16x3':
+        # the f16x3 path serves the reduction in tile-skip mode of its wave-specialised kernel, which small jobs do not select
+        # by themselves: force it (sean.dbg bit 64) so that these small cases exercise the mode
+        g.handle.set_option('sean.dbg', 64)
+    return g
 
 
 def _run(gen, labels, codes, noise):
@@ -107,5 +112,8 @@ def test_executed_flops_accounting(hip_lib, path):
         frac[name] = ace['flops_executed'] / ace['flops']
     print('executed / dense SPADE-conv FLOPs:', frac)
     assert 1.0 - 1e-9 <= frac['diag'] <= 1.2
-    assert frac['one_region'] < 0.45 and frac['face'] < 0.9
+    if path == 'f32':       # pixel granularity (32-pixel sub-tiles)
+        assert frac['one_region'] < 0.45 and frac['face'] < 0.9
+    else:                   # tile granularity (tiles of 32 x 16 without any boundary pixel are skipped)
+        assert frac['one_region'] < 0.95 and frac['face'] <= frac['diag'] + 1e-9      # (a 128-pixel face has no boundary-free tile)
     gen.handle.close()
