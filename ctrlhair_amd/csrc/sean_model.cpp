@@ -393,7 +393,10 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     n_aces = ace_index;
     // Run-ahead mode of small jobs (Runner::prepare_all_ahead): a side stream, one join event and one set of buffers per ACE.
     // Only when the handle is sized for interactive work -- for large batches the convs own every CU and nothing co-schedules.
-    if (ahead_pixels < 0) ahead_pixels = (long long)8 * 512 * 512;        // default; option "sean.ahead" overrides (0 = never)
+    // Default: interactive sizes only (up to 2 x 512^2 per chunk, where the win was measured: 3.3 -> 2.65 ms per render at
+    // 256^2).  The per-ACE buffers of the full mode cost mb * r^2 * 128 * 4 bytes each -- 4.3 GB for an 8 x 512^2 handle, for
+    // 1.6 % at that size -- so larger handles opt in explicitly: option "sean.ahead" = images of 512^2 per chunk (0 = never).
+    if (ahead_pixels < 0) ahead_pixels = (long long)2 * 512 * 512;
     // Larger jobs keep the (HBM-write-bound) label-table kernels inline and run only the style LUT builds -- small,
     // latency-bound GEMMs -- ahead (ahead_full = false).
     if (ahead_pixels > 0) {

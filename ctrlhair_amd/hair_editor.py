@@ -41,13 +41,16 @@ from .checkpoints import reference_checkpoints      # noqa: E402,F401  (referenc
 class HipModels:
     """Builds every network of the path on one ch_handle (one GPU)."""
 
-    def __init__(self, weights: Dict[str, dict], device: int = 0, img_size: int = 256, max_batch: int = 1, f16x3=True):
+    def __init__(self, weights: Dict[str, dict], device: int = 0, img_size: int = 256, max_batch: int = 1, f16x3=True,
+                 options: Optional[Dict[str, int]] = None):
         """f16x3: arithmetic of the SEAN generator / Zencoder convs (see SeanGenerator): True = split-operand f16 MFMA,
-        f32-class results (default); False = exact-f32 MFMA; 2 = single-term f16 (reduced precision)."""
+        f32-class results (default); False = exact-f32 MFMA; 2 = single-term f16 (reduced precision).
+        options: extra ch_set_option pairs applied before the generator is finalised (e.g. {'sean.ahead': 8})."""
         from .models import ColorTextureModels, FaceParsing, ShapeGenerator
         from .sean.generator import SeanGenerator
         from .sean.pix2pix_model import Pix2PixModel
-        self.generator = SeanGenerator(device, f16x3=f16x3).load_state_dict(weights['sean'], max_batch=max_batch, max_size=img_size)
+        self.generator = SeanGenerator(device, f16x3=f16x3, options=options).load_state_dict(weights['sean'], max_batch=max_batch,
+                                                                                           max_size=img_size)
         h, dev = self.generator.handle, self.generator.device
         self.device = dev
         self.sean_model = Pix2PixModel(self.generator)
@@ -65,7 +68,14 @@ class HairEditor:
     """This is the basic module (hair_editor.py:40-43); ctrlhair_amd.ui.backend.Backend succeeds this class."""
 
     def __init__(self, load_feature_model=True, load_mask_model=True, *, weights='procedural', device: int = 0,
-                 img_size: int = 256, models=None, texture_dirs=None, shape_dirs=None, max_batch: int = 1, f16x3=True):
+                 img_size: int = 256, models=None, texture_dirs=None, shape_dirs=None, max_batch: int = 1, f16x3=None):
+        """f16x3: None = by the weights: True (split-operand f16 MFMA, f32-class, ~3x faster) for procedural weights, on which
+        every parity test runs; False (exact-f32 MFMA, the reference's arithmetic) for a released checkpoint tree
+        (weights='reference' or a directory) -- the split-operand path is tested on heavy-tailed synthetic weights
+        (tests/test_hip_robust_weights.py) but has never seen the real checkpoints, which cannot be fetched here.  Pass
+        True / False to choose explicitly."""
+        if f16x3 is None:
+            f16x3 = not (weights == 'reference' or (isinstance(weights, str) and weights != 'procedural'))
         if models is None:
             if weights == 'procedural':
                 weights = procedural_weights()

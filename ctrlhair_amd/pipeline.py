@@ -69,11 +69,11 @@ def hsv_to_rgb_u8(hsv: torch.Tensor) -> torch.Tensor:
 
 class EditPipeline:
     def __init__(self, weights: Optional[Dict[str, dict]] = None, device: int = 0, img_size: int = 512, max_batch: int = 8,
-                 f16x3=1, models=None, texture_dirs=None, shape_dirs=None, hsv_table=None):
+                 f16x3=1, models=None, texture_dirs=None, shape_dirs=None, hsv_table=None, options=None):
         from .hair_editor import HipModels, procedural_weights
         if models is None:
             models = HipModels(weights if weights is not None else procedural_weights(), device=device, img_size=img_size,
-                               max_batch=max_batch, f16x3=f16x3)
+                               max_batch=max_batch, f16x3=f16x3, options=options)
         self.models = models
         self.device = models.device
         self.img_size = img_size
@@ -97,9 +97,24 @@ class EditPipeline:
 
     # ---- stages (each returns device tensors; citations: module docstring) -----------------------------------------------
     def parse(self, img: torch.Tensor) -> torch.Tensor:
-        """img [B,3,H,W] in [-1,1] -> CelebAMask-HQ label map uint8 [B,H,W] (ToTensor + Normalize, net, argmax, remap)."""
-        x = ((img * 0.5 + 0.5) - self.mean) / self.std
-        return self.models.face_parsing.parse_tensor(x)[0]
+        """img [B,3,S,S] in [-1,1] -> CelebAMask-HQ label map uint8 [B,S,S].  As the reference does for every img_size
+        (my_parsing_util.py:34-35, hair_editor.py:331-335): the parser always sees a 512x512 bilinear resize of the portrait
+        (8-bit, like the PIL image it resizes), and the label map is nearest-resized back to S (cv2 INTER_NEAREST:
+        src = floor(dst * 512 / S)); ToTensor + Normalize, net, argmax, remap in between."""
+        S = img.shape[-1]
+        x01 = img * 0.5 + 0.5
+        if S != 512:
+            # PIL resamples in two passes, horizontal then vertical, each stored as 8-bit (ImagingResample)
+            u8 = torch.round(x01 * 255.0).clamp(0, 255)
+            for size in ((S, 512), (512, 512)):
+                u8 = torch.nn.functional.interpolate(u8, size=size, mode='bilinear', align_corners=False, antialias=S > 512)
+                u8 = torch.round(u8).clamp(0, 255)
+            x01 = u8 / 255.0
+        lab = self.models.face_parsing.parse_tensor((x01 - self.mean) / self.std)[0]
+        if S != 512:
+            idx = (torch.arange(S, device=lab.device) * 512) // S
+            lab = lab[:, idx][:, :, idx].contiguous()
+        return lab
 
     def analyse(self, img: torch.Tensor, labels: torch.Tensor):
         """-> dict(shape [B,16], face [B,1024], codes [B,19,512], rgb_mean [B,3], pca_std [B,1], texture [B,8],

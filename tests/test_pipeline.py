@@ -146,3 +146,26 @@ def test_backend_512_matches_pipeline(hip_lib):
     print('Backend vs pipeline: max level difference', int(d.max()), 'pixels differing', int((d > 0).sum()))
     assert d.max() <= 1
     be.models.generator.handle.close()
+
+
+def test_parse_at_256_goes_through_the_512_resize(hip_lib):
+    """img_size = 256 (the reference's own default): EditPipeline.parse must see what HairEditor.get_mask sees -- a 512x512
+    bilinear resize through BiSeNet, labels nearest-resized back (my_parsing_util.py:34-35, hair_editor.py:331-335) -- and
+    not a 256x256 parse, whose labels differ."""
+    from ctrlhair_amd import procedural as P
+    from ctrlhair_amd.hair_editor import HairEditor, procedural_weights
+    from ctrlhair_amd.pipeline import EditPipeline
+    w = procedural_weights(0, 16)
+    he = HairEditor(weights=w, device=0, img_size=256, max_batch=2)
+    pipe = EditPipeline(models=he.models, img_size=256)
+    img = P.synthetic_images(1, 256, seed=77)                       # [-1, 1], NCHW
+    u8 = np.clip(np.round((img[0].transpose(1, 2, 0) * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+    ref = he.get_mask(u8)                                             # PIL bilinear -> 512 -> parse -> cv2-style nearest -> 256
+    t = torch.from_numpy(u8.transpose(2, 0, 1)[None].astype(np.float32) / 127.5 - 1.0).to(pipe.device)
+    got = pipe.parse(t)[0].cpu().numpy()
+    direct = he.models.face_parsing.parse_tensor(((t * 0.5 + 0.5) - pipe.mean) / pipe.std)[0][0].cpu().numpy()
+    mism = float((got != ref).mean())
+    print(f'pipeline.parse vs get_mask at 256: {100 * mism:.3f} % of the labels differ; a direct 256x256 parse: '
+          f'{100 * float((direct != ref).mean()):.2f} %')
+    dm = float((direct != ref).mean())
+    assert mism <= 0.01 and dm >= 10 * mism                    # PIL and torch bilinear agree up to 8-bit rounding ties
