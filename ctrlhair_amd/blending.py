@@ -46,7 +46,9 @@ class PoissonBlender:
         self.handle.call('ch_poisson_blend', s.data_ptr(), t.data_ptr(), m.data_ptr(), out.data_ptr(), H, W,
                          1 if with_gamma else 0, self.max_iters, float(self.rel_tol), C.byref(iters),
                          torch.cuda.current_stream(self.device).cuda_stream)
-        self.last_iters, self.last_converged = abs(iters.value), iters.value >= 0
+        # negated count (INT_MIN for zero iterations) = rel_tol not reached (include/ctrlhair_hip.h)
+        self.last_iters = 0 if iters.value == -2 ** 31 else abs(iters.value)
+        self.last_converged = iters.value >= 0
         if not self.last_converged:
             # the reference solves the system directly (poisson_blending.py:80-85): a partially converged image is not its result
             import warnings

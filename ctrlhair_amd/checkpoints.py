@@ -140,7 +140,18 @@ def expected(ngf: int = 64) -> Dict[str, Dict[str, Tuple[int, ...]]]:
     state-dict keys; values are irrelevant here)."""
     from . import procedural as P
     from .hair_editor import procedural_weights
-    w = procedural_weights(0, ngf)
+    # Only the shapes are wanted: the random-tensor makers of ctrlhair_amd.procedural are swapped for zero-stride views for
+    # the duration of the call (no hundreds of MB of Gaussians, no power iterations); calibration tables are not applied.
+    saved = (P._normal, P._xavier, P.power_iterate, P.load_calibration)
+    view = lambda shape: np.broadcast_to(np.float32(0), tuple(int(d) for d in shape))
+    try:
+        P._normal = lambda seed, name, shape, std: view(shape)
+        P._xavier = lambda seed, name, shape: view(shape)
+        P.power_iterate = lambda w, seed, name, iters=60: (view((w.shape[0],)), view((int(np.prod(w.shape[1:])),)))
+        P.load_calibration = lambda seed, ngf: {}              # (an empty table: nothing to apply, shapes unchanged)
+        w = procedural_weights(0, ngf)
+    finally:
+        P._normal, P._xavier, P.power_iterate, P.load_calibration = saved
     return {m: {k: _shape(v) for k, v in w[m].items()} for m in MODELS}
 
 
@@ -164,6 +175,13 @@ def validate(weights: Dict[str, dict], ngf: int = 64, optional=('num_batches_tra
             if k not in exp[m] and not any(k.endswith(o) for o in optional):
                 problems.append(f'{m}: unexpected key {k} {have[k]}')
     return problems
+
+
+def split_problems(problems: List[str]) -> Tuple[List[str], List[str]]:
+    """(fatal, benign): missing keys and shape mismatches stop a load; keys the implemented architectures do not use (an extra
+    buffer in a newer checkpoint) are only reported -- the reference would have needed strict loading per module for them."""
+    benign = [p for p in problems if ': unexpected key ' in p]
+    return [p for p in problems if p not in benign], benign
 
 
 def save_npz(path: str, weights: Dict[str, object]) -> None:

@@ -305,7 +305,6 @@ hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
 //      o = act((bn_a x + nv nz + bn_d) (1 + gamma) + beta) * out_scale [* extra];  hi = f16(o), lo = f16(o - hi)
 constexpr int IS_GPB = 4;
 typedef _Float16 is_h8 __attribute__((ext_vector_type(8)));
-typedef __bf16 is_b8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInteriorParams q) {
     constexpr int CB = IS_GPB * 8, RS = 2 * CB + 4;          // row pitch: 16-byte aligned, labels spread over the banks
     __shared__ __attribute__((aligned(16))) float gt[19 * RS];
@@ -316,42 +315,44 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInterio
         extra = sh16_dyn_extra(*q.out_amax);
         if (extra == 1.f) return;                             // nothing to repair (the normal case)
     }
-    const int HW = q.H * q.W, ppb = (HW + 255) / 256;
-    const int b = blockIdx.x / ppb, c0 = blockIdx.y * CB;
-    const int pix = (blockIdx.x % ppb) * 256 + threadIdx.x;
-    const int y = pix / q.W, x = pix - y * q.W;
+    const int HW = q.H * q.W, ppb = (HW + 255) / 256, nblk = q.B * ppb;
     const int tiles_x = (q.W + 31) >> 5, tiles_y = (q.H + 15) >> 4;
-    bool mine = false;
-    int j = 255;
-    if (pix < HW) {
-        mine = q.cnt[(b * tiles_y + (y >> 4)) * tiles_x + (x >> 5)] == 0;
-        j = q.u5[(long long)b * HW + pix];
-        mine = mine && j < 19;                                // (always true in such a tile)
-    }
-    const int any = __syncthreads_or(mine);
+    const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up), Go = (q.C + 7) >> 3;
+    const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
+    const float osc = q.out_scale * extra;
     float amax = 0.f;
-    if (any) {
-        for (int i = threadIdx.x; i < 19 * 2 * CB; i += 256) {
-            const int jj = i / (2 * CB), r = i % (2 * CB), gb = r / CB, c = c0 + r % CB;
-            gt[jj * RS + r] = c < q.C ? q.gtab[(((long long)b * 19 + jj) * 2 + gb) * q.C + c] : 0.f;
+    // persistent blocks, grid-stride over blocks of 256 consecutive pixels: on label maps without a boundary-free tile (every
+    // block leaves after one byte per thread) the launch costs a few microseconds instead of one dispatch per pixel block
+    for (int pbk = blockIdx.x; pbk < nblk; pbk += gridDim.x) {
+        const int b = pbk / ppb, pix = (pbk - b * ppb) * 256 + threadIdx.x;
+        const int y = pix / q.W, x = pix - y * q.W;
+        bool mine = false;
+        int j = 255;
+        if (pix < HW) {
+            mine = q.cnt[(b * tiles_y + (y >> 4)) * tiles_x + (x >> 5)] == 0;
+            if (mine) j = q.u5[(long long)b * HW + pix];
+            mine = mine && j < 19;                            // (always true in such a tile)
         }
-        if (threadIdx.x < CB) {
-            const int c = c0 + threadIdx.x;
-            pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
-            pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
-            pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
-        }
-        __syncthreads();
-        if (mine) {
-            const float nz = q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y];
-            const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up);
-            const long long xpix = (long long)(y >> q.x_up) * xW + (x >> q.x_up);
-            const float4* xp = reinterpret_cast<const float4*>(q.x) + (long long)b * (q.C >> 2) * xHW + xpix;
-            const int Go = (q.C + 7) >> 3;
-            uint4* op = reinterpret_cast<uint4*>(q.out) + (long long)b * Go * 2 * HW + pix;
+        if (__syncthreads_or(mine) == 0) continue;
+        const float nz = mine ? q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y] : 0.f;
+        const long long xpix = (long long)(y >> q.x_up) * xW + (x >> q.x_up);
+        const float4* xp = reinterpret_cast<const float4*>(q.x) + (long long)b * (q.C >> 2) * xHW + xpix;
+        uint4* op = reinterpret_cast<uint4*>(q.out) + (long long)b * Go * 2 * HW + pix;
+        for (int c0 = 0; c0 < q.C; c0 += CB) {
+            __syncthreads();                                  // the previous slice is no longer read
+            for (int i = threadIdx.x; i < 19 * 2 * CB; i += 256) {
+                const int jj = i / (2 * CB), r = i % (2 * CB), gb = r / CB, c = c0 + r % CB;
+                gt[jj * RS + r] = c < q.C ? q.gtab[(((long long)b * 19 + jj) * 2 + gb) * q.C + c] : 0.f;
+            }
+            if (threadIdx.x < CB) {
+                const int c = c0 + threadIdx.x;
+                pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
+                pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
+                pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
+            }
+            __syncthreads();
+            if (!mine) continue;
             const float* g = gt + j * RS;
-            const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
-            const float osc = q.out_scale * extra;
 #pragma unroll
             for (int gq = 0; gq < IS_GPB; ++gq) {
                 const int c = c0 + gq * 8;
@@ -399,8 +400,8 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInterio
 hipError_t ace_interior_sh16(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU || !q.cnt || (q.C & 3)) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
-    dim3 grid((unsigned)(q.B * ((HW + 255) / 256)), (unsigned)((q.C + IS_GPB * 8 - 1) / (IS_GPB * 8)));
-    hipLaunchKernelGGL(ace_interior_sh16_kernel, grid, dim3(256), 0, s, q);
+    const int nblk = q.B * ((HW + 255) / 256);
+    hipLaunchKernelGGL(ace_interior_sh16_kernel, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

@@ -136,13 +136,30 @@ __device__ __forceinline__ uint4 sh16_pair_swap(const uint4& w) {
     return make_uint4(r0[0], r1[0], r0[1], r1[1]);
 }
 
+// Pixel of slot `idx` of a block tile (idx = wave * 128 + sub-tile * 32 + lane % 32).  TW == 16: a 32-pixel sub-tile is two rows
+// of 16 pixels whose patch rows start PW units apart in LDS.  ds_read_b128 serves a wave in the lane groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS): with PW = 18 and the plain mapping, lanes 12,13 (row 0, units 12,13) and
+// lanes 26,27 (row 1, units 18+10, 18+11 = 12, 13 mod 16) of one group fall on the same 16-byte bank slots -- a 2-way conflict
+// in every group, the 44-53 % of the LDS-conflict column these tile variants showed (profiles/r02_pipeline_pmc.md).  Rotating
+// the odd row by `rot` = (16 - PW % 16) % 16 pixels makes the 16 units of every group distinct mod 16; the epilogue uses the
+// same mapping, so a lane still owns the pixel whose B fragment it fed (stores stay inside the same 64-byte row segment).
+template <int TW, int TH>
+__device__ __forceinline__ void sh16_slot_px(int idx, int rot, int& tx, int& ty, int& tb) {
+    tx = idx % TW;
+    ty = (idx / TW) % TH;
+    tb = idx / (TW * TH);
+    if constexpr (TW == 16) {
+        if (ty & 1) tx = (tx + rot) & 15;
+    }
+}
+
 // D2S (EPI_PLAIN): depth-to-space store.  GEMM row = phase * C + channel (C = Mrows / 4, phase = (py, px)); pixel (y, x) of the
 // conv grid lands at (2y + py, 2x + px) of the C-channel, 2H x 2W output: ConvTranspose2d(k3, s2, p1, op1) as ONE 2x2-tap
 // conv at the input resolution (each output phase only sees the taps that reach it: 9 of the 16 (tap, phase) weights are
 // non-zero, against 9 of 36 positions for a 3x3 conv over the zero-inserted x2 view).  bias is indexed by channel.
 template <int TW, int TH, int TB, int EPI, bool BF = false, bool D2S = false>
 __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)[2][4], int mtile64, int wn, int lane,
-                                              int x0, int y0, int b0, int ks = 0) {
+                                              int x0, int y0, int b0, int ks = 0, int rot = 0) {
     const int HW = p.H * p.W;
     // ---- epilogue ------------------------------------------------------------------------------------------
     // Per-channel parameters are loaded ONCE per wave as float4 (a lane's 16 rows are 4 runs of 4 consecutive
@@ -161,7 +178,8 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
-            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+            int tx, ty, tb;
+            sh16_slot_px<TW, TH>(idx, rot, tx, ty, tb);
             const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
             pb_[n] = (b < p.B && y < p.H && x < p.W) ? b : -1;
             pix_[n] = D2S ? 4 * y * p.W + 2 * x : y * p.W + x;
@@ -260,7 +278,8 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
-            const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+            int tx, ty, tb;
+            sh16_slot_px<TW, TH>(idx, rot, tx, ty, tb);
             const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
             const bool ok = b < p.B && y < p.H && x < p.W;
             pb_[n] = ok ? b : -1;
@@ -404,11 +423,13 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     const int HW = p.H * p.W;
     const int G = p.Cin >> 3;                            // input channel groups
 
+    constexpr int ROT = TW == 16 ? (16 - PW % 16) % 16 : 0;     // bank-conflict-free lane -> pixel mapping (sh16_slot_px)
     int ub[4];   // per-lane LDS unit offset of the window origin (hi plane of this lane's k-half) per N-subtile
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int idx = wn * 128 + n * 32 + (lane & 31);
-        const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
+        int tx, ty, tb;
+        sh16_slot_px<TW, TH>(idx, ROT, tx, ty, tb);
         ub[n] = (lane >> 5) * 2 * PLANE + tb * (PH * PW) + ty * PW + tx;
     }
 
@@ -692,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
     }
 
     if (p.dbg & 4) return;
-    sh16_epilogue<TW, TH, TB, EPI, TERMS == 2, D2S>(p, acc, mtile64, wn, lane, x0, y0, b0, ks);
+    sh16_epilogue<TW, TH, TB, EPI, TERMS == 2, D2S>(p, acc, mtile64, wn, lane, x0, y0, b0, ks, ROT);
 }
 
 // -----------------------------------------------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 // (Chronopoulos-Gear CG), scalars (alpha, beta, convergence) stay on the device.  Dot products are two-level and
 // deterministic: per-block partial sums, re-reduced in a fixed order by every block that needs the scalar (no atomics).
 #include <hip/hip_runtime.h>
+
+#include <climits>
 #include <stdint.h>
 
 #include "kernels.h"
@@ -192,6 +194,22 @@ __global__ __launch_bounds__(256) void pb_update_kernel(double* __restrict__ X, 
     }
 }
 
+// Residual check after the LAST allowed update (the update kernel only learns at the top of the following iteration that the
+// previous one met the tolerance): sums the partials of a final mat-vec and sets the flag.  One block.  nparts = blocks of
+// that mat-vec.  With no iteration done (max_iters = 0) there is no ||r0|| on file: only an exactly solved system counts.
+__global__ __launch_bounds__(256) void pb_final_check_kernel(PoissonCG* __restrict__ cg, const double* __restrict__ partG, int nparts,
+                                                             double rel_tol2) {
+    __shared__ double sh[4];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double gam = pb_total(partG + c * nparts, nparts, sh);
+        const double g0 = cg->gamma0[c];
+        any = any || (gam > rel_tol2 * g0 && gam > 1e-24);
+    }
+    if (threadIdx.x == 0 && !any) cg->done = 1;
+}
+
 // out = clamp(x^gamma) truncated to uint8 (poisson_blending.py:81-86); NaN (negative base) -> 0
 __global__ void pb_finish_kernel(const double* __restrict__ X, uint8_t* __restrict__ out, int HW, float gamma) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,14 +252,19 @@ hipError_t poisson_blend(const uint8_t* src, const uint8_t* tgt, const uint8_t* 
             if (e != hipSuccess) return e;
         }
     }
+    if (!done) {           // did the last allowed update reach the tolerance?  (mat-vec + reduction only, no update)
+        hipLaunchKernelGGL(pb_matvec_kernel, gc, b, 0, s, R, Wv, U, cg, partG, partD, H, W);
+        hipLaunchKernelGGL(pb_final_check_kernel, dim3(1), b, 0, s, cg, partG, ncg, rel_tol * rel_tol);
+    }
     hipLaunchKernelGGL(pb_finish_kernel, g, b, 0, s, X, out, HW, gamma);
-    if (iters_out) {       // iteration count; NEGATIVE when the solve stopped at max_iters without reaching rel_tol
-        int st[2] = {0, 0};                                   // PoissonCG {done, iters}
-        hipError_t e = hipMemcpyAsync(st, &cg->done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+    if (iters_out) {       // iteration count; negated (INT_MIN for zero iterations) when rel_tol was not reached
+        int dn = 0, its = 0;
+        hipError_t e = hipMemcpyAsync(&dn, &cg->done, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&its, &cg->iters, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return e;
-        *iters_out = st[0] ? st[1] : -st[1];
+        *iters_out = dn ? its : (its > 0 ? -its : INT_MIN);
     }
     return hipGetLastError();
 }

@@ -82,10 +82,17 @@ class HairEditor:
             elif weights == 'reference' or (isinstance(weights, str) and os.path.isdir(weights)):
                 # the reference's checkpoint tree ('reference' = the current directory, like the reference itself)
                 weights = reference_checkpoints('.' if weights == 'reference' else weights)
-                from .checkpoints import validate
+                from .checkpoints import split_problems, validate
                 fcw = weights['sean'].get('fc.weight') if isinstance(weights.get('sean'), dict) else None
                 ngf = int(fcw.shape[0]) // 16 if fcw is not None else 64      # generator width as the C library infers it
-                problems = validate(weights, ngf=ngf)   # strict=True semantics before anything is uploaded
+                # strict=True semantics before anything is uploaded; keys the architectures do not use are reported, not fatal
+                problems, extras = split_problems(validate(weights, ngf=ngf))
+                if extras:
+                    import warnings
+                    warnings.warn('checkpoint tree has keys the implemented architectures do not use (ignored):\n  ' + '\n  '.join(extras[:20]))
+                    for msg in extras:
+                        mname, key = msg.split(': unexpected key ')[0], msg.split(': unexpected key ')[1].split(' ')[0]
+                        weights[mname].pop(key, None)
                 if problems:
                     raise RuntimeError('checkpoint tree does not match the implemented architectures:\n  ' + '\n  '.join(problems[:20]))
                 if texture_dirs is None and weights.get('texture_dirs'):

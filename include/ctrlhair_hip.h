@@ -167,8 +167,9 @@ int  ch_bisenet_parse(ch_handle* h, const float* img, uint8_t* labels, float* lo
  *   trip and uint8 truncation, solved matrix-free by conjugate gradients (Chronopoulos-Gear form, f64) instead of three sparse direct solves.
  *   source, target, out: uint8 [H,W,3] (cv2 layout); mask uint8 [H,W], non-zero = keep the SOURCE gradients (solve), zero =
  *   keep the target pixel; H, W >= 3.  Stops when ||r|| <= rel_tol * ||r0|| per channel or after max_iters iterations
- *   (recommended 1e-7 / 4000); *iters (host pointer, optional) receives the iteration count, NEGATED when the solve stopped
- *   at max_iters without reaching rel_tol (the reference uses a direct solve: an unconverged image is not its output).  Output agrees with the
+ *   (recommended 1e-7 / 4000); *iters (host pointer, optional) receives the iteration count, NEGATED (INT_MIN for zero
+ *   iterations) when the solve stopped at max_iters without reaching rel_tol -- checked once more after the last update
+ *   (the reference uses a direct solve: an unconverged image is not its output).  Output agrees with the
  *   reference to +-1 grey level (the floor() after the gamma power amplifies last-bit differences of pow() and of the
  *   solve wherever the result sits on an integer boundary, e.g. every kept target pixel).  Run-to-run deterministic. */
 int  ch_blend_mask(ch_handle* h, const uint8_t* target_parsing, const uint8_t* face_parsing, uint8_t* out, int H, int W,

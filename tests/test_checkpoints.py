@@ -80,8 +80,11 @@ def test_editor_from_checkpoint_tree_equals_in_memory_weights(hip_lib, tree):
     import torch
     from ctrlhair_amd.hair_editor import HairEditor
     root, w, tdirs, sdirs, _ = tree
-    a = HairEditor(True, True, weights=root, device=0)
-    b = HairEditor(True, True, weights=w, device=0, texture_dirs=tdirs, shape_dirs=sdirs)
+    a = HairEditor(True, True, weights=root, device=0, f16x3=True)
+    b = HairEditor(True, True, weights=w, device=0, texture_dirs=tdirs, shape_dirs=sdirs, f16x3=True)
+    # (a released checkpoint tree defaults to the exact-f32 path, in-memory / procedural weights to the split-operand path)
+    d = HairEditor(True, True, weights=root, device=0)
+    assert d.models.generator.f16x3 is False and b.models.generator.f16x3 is True
     assert all(torch.equal(x, y) for x, y in zip(a.texture_dirs, b.texture_dirs))
     assert all(torch.equal(x, y) for x, y in zip(a.shape_dirs, b.shape_dirs))
     labels, codes = P.blocky_labels(1, 256, seed=3), P.style_codes(1, seed=4)

@@ -167,3 +167,14 @@ def test_unconverged_solve_is_reported(hip_lib):
     ok = _blender(max_iters=4000, rel_tol=1e-7)
     ok(src, tgt, mask)
     assert ok.last_converged and 0 < ok.last_iters < 4000
+    # the edges of the report: a solve that meets the tolerance with its LAST allowed update is converged (the flag used to be
+    # set only at the top of the following iteration), and zero iterations on an unsolved system is not
+    n = ok.last_iters
+    exact = _blender(max_iters=n, rel_tol=1e-7)
+    a = exact(src, tgt, mask)
+    assert exact.last_converged and exact.last_iters == n and np.array_equal(a, ok(src, tgt, mask))
+    with warnings.catch_warnings(record=True) as w0:
+        warnings.simplefilter('always')
+        none = _blender(max_iters=0, rel_tol=1e-7)
+        none(src, tgt, mask)
+    assert not none.last_converged and none.last_iters == 0 and any(issubclass(x.category, RuntimeWarning) for x in w0)

@@ -14,8 +14,11 @@ import sys
 def avg_kib(db, counter, sub):
     c = sqlite3.connect(db)
     # launches shorter than 20 us are the second ("repair") passes of the ACE kernels, which return at once (csrc/sh16.h)
-    rows = list(c.execute("select count(*), avg(value) from counters_collection where counter_name=? and kernel_name like ? "
-                          "and duration > 20000", (counter, f'%{sub}%')))
+    # `sub`: one or more kernel-name substrings separated by '|' (the launches bench.py's roofline averages over)
+    subs = [t for t in sub.split('|') if t]
+    cond = ' or '.join('kernel_name like ?' for _ in subs)
+    rows = list(c.execute(f"select count(*), avg(value) from counters_collection where counter_name=? and ({cond}) "
+                          "and duration > 20000", (counter, *[f'%{t}%' for t in subs])))
     return rows[0]
 
 
