@@ -120,6 +120,8 @@ class GeneratorJob:
             opts['sean.ahead'] = args.ahead
         if args.sparse_th:
             opts['sean.sparse_th'] = args.sparse_th
+        if args.dbg:
+            opts['sean.dbg'] = args.dbg          # (some experiment bits act at ch_finalize)
         self.gen = SeanGenerator(dev.index, f16x3=PATH_OPTION[path], options=opts).load_state_dict(sd, max_batch=B, max_size=S)
         if args.dbg:
             self.gen.handle.set_option('sean.dbg', args.dbg)

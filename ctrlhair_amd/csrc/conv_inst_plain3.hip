@@ -3,6 +3,11 @@
 namespace chk {
 hipError_t conv_plain3(const ConvParams& p, hipStream_t s) {
     const int rows = p.Mrows;
+    if (p.in2) {          // 3x3 conv with a fused 1x1 second operand (ResBlock shortcut conv_s folded into conv_1)
+        if (p.W < 32 || p.in_mode != IN_DIRECT || p.pad_mode != PAD_ZERO) return hipErrorInvalidValue;
+        if (rows <= 64) return launch_conv<3, 1, 1, 32, 16, 1, CK_KS3, EPI_PLAIN, true>(p, rows, s);
+        return launch_conv<3, 1, 2, 32, 8, 1, CK_KS3, EPI_PLAIN, true>(p, rows, s);
+    }
     if (p.W >= 32) {
         if (rows <= 64) return launch_conv<3, 1, 1, 32, 16, 1, CK_KS3, EPI_PLAIN>(p, rows, s);
         return launch_conv<3, 1, 2, 32, 8, 1, CK_KS3, EPI_PLAIN>(p, rows, s);

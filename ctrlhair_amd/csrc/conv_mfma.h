@@ -137,8 +137,13 @@ struct ConvCfg {
     static_assert(KSTEPS % 4 == 0, "k-steps per chunk must be a multiple of 4");
 };
 
-template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
+// FUSE (EPI_PLAIN, KS = 3, stride 1): a second input `in2` (Cin2 channels, same spatial size, NCHW) whose 1x1 conv with `wpk2`
+// (pack_A with KS = 1, CK = 16) is accumulated into the same tile after the 3x3 chunks -- the ResBlock's learned shortcut
+// conv_s folded into conv_1 (architecture.py:69-96: out = conv_1(h1) + conv_s(hs)): no shortcut kernel, no write + residual
+// read of its output.  Same patch geometry (the centre tap only is read), first fused chunk staged during the last 3x3 chunk.
+template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
+    static_assert(!FUSE || (KS == 3 && STRIDE == 1 && EPI == EPI_PLAIN && CK == 16), "FUSE: plain 3x3 stride-1 convs only");
     using Cfg = ConvCfg<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
     constexpr int WN = Cfg::WN, PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE;
     constexpr int NG = Cfg::NGROUPS, NLOAD = Cfg::NLOAD, SE = Cfg::STAGE_ELEMS;
@@ -221,11 +226,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const float4* Ap = reinterpret_cast<const float4*>(p.wpk) +
                        ((long long)mtile64 * p.nchunks) * (NG * 2 * 64) + lane;
 
+    // FUSE: the second operand's chunk c2 -> LDS buffer `buf` (centre region of the patch only: its 1x1 conv reads no halo)
+    const int nch2 = FUSE ? (p.Cin2 + CK - 1) / CK : 0;
+    auto stage2 = [&](int c2, int buf) {
+        float stg[NLOAD];
+        const float* src = static_cast<const float*>(p.in2) + ((long long)b0 * p.Cin2 + (long long)c2 * CK) * HWin;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            int e = tid + i * 256;
+            asm volatile("" : "+v"(e));
+            float v = 0.f;
+            if (e < SE) {
+                const int c = e / PLANE, rem = e % PLANE;
+                const int tb = rem / (PH * PW), py = (rem / PW) % PH, px = rem % PW;
+                const int y = y0 - 1 + py, x = x0 - 1 + px;
+                const bool ok = b0 + tb < p.B && c2 * CK + c < p.Cin2 && py >= 1 && py < PH - 1 && px >= 1 && px < PW - 1 &&
+                                y < p.H && x < p.W;
+                if (ok) v = src[(tb * p.Cin2 + c) * HWin + y * p.W + x];
+            }
+            stg[i] = v;
+        }
+        float* dst = smem + buf * SE;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int e = tid + i * 256;
+            if (e < SE) dst[e] = stg[i];
+        }
+    };
+
     stage(c_lo, 0);
     __syncthreads();
 
     for (int ch = c_lo; ch < c_hi; ++ch) {
         if (ch + 1 < c_hi) stage(ch + 1, (ch + 1 - c_lo) & 1);
+        if constexpr (FUSE) {
+            if (ch + 1 == c_hi && nch2 > 0) stage2(0, (ch + 1 - c_lo) & 1);
+        }
         const float* sb = smem + ((ch - c_lo) & 1) * SE;
         const float4* Ac = Ap + (long long)ch * (NG * 2 * 64);
         float4 a0 = Ac[0], a1 = Ac[64];
@@ -269,6 +305,37 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             a1 = a1n;
         }
         __syncthreads();
+    }
+
+    if constexpr (FUSE) {
+        // fused 1x1 operand: 16 channels per chunk = 8 k-steps at the centre tap, into the same accumulators
+        const float4* Ap2 = reinterpret_cast<const float4*>(p.wpk2) + ((long long)mtile64 * nch2) * (2 * 2 * 64) + lane;
+        for (int c2 = 0; c2 < nch2; ++c2) {
+            const int v = (c_hi - c_lo) + c2;                  // virtual chunk index: the LDS buffer parity continues
+            if (c2 + 1 < nch2) stage2(c2 + 1, (v + 1) & 1);
+            const float* sb = smem + (v & 1) * SE;
+            const float4* Ac = Ap2 + (long long)c2 * (2 * 2 * 64);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 a0 = Ac[g * 128], a1 = Ac[g * 128 + 64];
+                const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+                const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cp = g * 4 + q;                  // channel pair of this k-step
+                    const int koff = 2 * cp * PLANE + PW + 1;  // centre tap
+                    float bv[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bv[n] = sb[koff + loff[n]];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[q], bv[n], acc[0][n], 0, 0, 0);
+                        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[q], bv[n], acc[1][n], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------
@@ -393,10 +460,10 @@ __global__ void splitk_reduce_kernel(const ConvParams p) {
 }
 
 // host-side launcher for one instantiation
-template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
+template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI, bool FUSE = false>
 hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ConvCfg<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
-    auto kern = conv_mfma_kernel<KS, STRIDE, WM, TW, TH, TB, CK, EPI>;
+    auto kern = conv_mfma_kernel<KS, STRIDE, WM, TW, TH, TB, CK, EPI, FUSE>;
     static bool attr_set[64] = {};                           // per device (a process may own handles on several GPUs)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -416,7 +483,7 @@ hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
     int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
     p.splitk = 1;
     p.cps = p.nchunks;
-    if (EPI == EPI_PLAIN && p.partial && grid < 192 && p.nchunks >= 8) {
+    if (EPI == EPI_PLAIN && p.partial && grid < 192 && p.nchunks >= 8 && !FUSE) {
         // few tiles but a long reduction (low-resolution, wide layers: shape VAE, BiSeNet tail): split K so that
         // ~2 blocks per CU stream the weights concurrently; partial sums go to slabs and are reduced deterministically.
         const long long slab = (long long)p.B * p.Mrows * p.H * p.W;

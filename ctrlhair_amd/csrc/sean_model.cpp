@@ -884,7 +884,7 @@ struct Runner {
 
     // fuse: optional (weights, input) of a 1x1 conv added into this 3x3 conv's accumulators (f16x3 path, W >= 32, no split-K)
     bool can_fuse_1x1(const ConvW& w, int r) const {
-        return m.use_sh16 && !(m.dbg & 32) && w.KS == 3 && r >= 32 &&
+        return !(m.dbg & 32) && w.KS == 3 && r >= 32 &&
                !(((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192);
     }
     // `prod` / `prod2`: the ACEs that wrote `in` / `in2` (their slots hold the scale in effect)
