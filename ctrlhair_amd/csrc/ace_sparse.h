@@ -93,7 +93,8 @@ struct AceInteriorParams {
     unsigned* out_amax;
     int pass, bf16;
     const int* cnt;             // f16x3 path: boundary-pixel count per tile of 32 x 16 (tiles_x = ceil(W / 32))
-    int variant;                // 0 = four pixels per thread (16-byte accesses), 1 = one pixel per thread
+    int variant;                // exact-f32 kernel: 0 = one pixel per thread (default), 1 = four pixels per thread (16-byte
+                                // accesses), 2 = one pixel per thread writing whole 32-byte sectors (A/B measurements)
 };
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s);
 // f16x3 path (tile-skip mode): the pixels of the tiles of 32 x 16 WITHOUT a boundary pixel (q.cnt[tile] == 0); x in the C4

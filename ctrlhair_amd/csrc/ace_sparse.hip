@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256) void ace_interior_f32_kernel(const AceInterior
     }
 }
 
-// one pixel per thread (4-byte accesses): kept selectable for A/B measurements (AceInteriorParams::variant = 1)
+// One pixel per thread (4-byte accesses, 256 contiguous bytes per wave instruction) -- the default: measured faster than the
+// four-pixels-per-thread kernel above (22.4 vs 24.4 ms per 5 steps at B = 16, 512^2) and than writing whole 32-byte sectors
+// (variant 2, 24.0 ms), so neither access width nor partial sectors bound this pass.
 __global__ __launch_bounds__(256) void ace_interior_f32_scalar_kernel(const AceInteriorParams q) {
     constexpr int RS = 2 * IN_CG + 1;
     __shared__ float gt[19 * RS];
@@ -253,8 +255,18 @@ __global__ __launch_bounds__(256) void ace_interior_f32_scalar_kernel(const AceI
     const int HW = q.H * q.W, ppb = (HW + 255) / 256;
     const int b = blockIdx.x / ppb, c0 = blockIdx.y * IN_CG;
     const int pix = (blockIdx.x % ppb) * 256 + threadIdx.x;
-    const int j = pix < HW ? q.u5[(long long)b * HW + pix] : 255;
+    int j = pix < HW ? q.u5[(long long)b * HW + pix] : 255;
     if (__syncthreads_or(j < 19) == 0) return;             // no interior pixel in this block
+    if (q.variant == 2) {
+        // Full 32-byte sectors: every pixel of an aligned group of 8 that holds an interior pixel is written (a boundary pixel
+        // of the group gets a placeholder computed with its neighbour's table row; the boundary conv, which runs after this
+        // kernel on the same stream, overwrites it) -- partial-sector writes cost a read-modify-write in ECC memory.
+        const unsigned long long m = __ballot(j < 19);
+        const int lane = threadIdx.x & 63, l8 = lane & ~7;
+        const unsigned grp = (unsigned)((m >> l8) & 0xFFull);
+        const int jn = __shfl(j, grp ? l8 + __ffs((int)grp) - 1 : lane, 64);     // first interior lane of the group
+        if (j >= 19 && grp != 0u && pix < HW) j = jn;
+    }
     for (int i = threadIdx.x; i < 19 * 2 * IN_CG; i += 256) {
         const int jj = i / (2 * IN_CG), r = i % (2 * IN_CG), gb = r / IN_CG, c = c0 + r % IN_CG;
         gt[jj * RS + r] = c < q.C ? q.gtab[(((long long)b * 19 + jj) * 2 + gb) * q.C + c] : 0.f;
@@ -289,7 +301,7 @@ hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU) return hipErrorInvalidValue;
     if (q.W % 4 != 0) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
-    if (q.variant == 1) {
+    if (q.variant != 1) {       // default (0) and the full-sector experiment (2): one pixel per thread
         dim3 grid1((unsigned)(q.B * ((HW + 255) / 256)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_scalar_kernel, grid1, dim3(256), 0, s, q);
         return hipGetLastError();

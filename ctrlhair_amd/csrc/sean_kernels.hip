@@ -37,18 +37,25 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int B, int H, int W, int K, int relu, int c4,
                                                              const uint8_t* __restrict__ need) {
-    __shared__ float T[19 * 9 * OH_KC];
-    __shared__ float bs[OH_KC];
+    // Table slice in LDS with a padded row pitch (36 floats: lanes that hold different labels start 4 banks apart) and one
+    // all-zero row that taps outside the image (and labels >= 19) point at: every lane issues the same 9 ds_read_b128 per 4
+    // channels, no predication (as 288 ds_read_b32 per pixel the kernel was bound by its LDS reads, not by its stores).
+    constexpr int RS = OH_KC + 4, ZROW = 19 * 9;
+    __shared__ __attribute__((aligned(16))) float T[(ZROW + 1) * RS];
+    __shared__ __attribute__((aligned(16))) float bs[OH_KC];
     const int k0 = blockIdx.y * OH_KC;
     bool wanted = true;
     if (need) {       // exact SPADE-interior reduction: only pixels next to a boundary pixel are ever read (ace_sparse.h)
         const long long pq = blockIdx.x * 256LL + threadIdx.x;
         wanted = pq < (long long)B * H * W && need[pq];
+        // aligned groups of 8 pixels (32-byte sectors of the NCHW planes) are written whole or not at all
+        const unsigned long long wm = __ballot(wanted);
+        wanted = pq < (long long)B * H * W && ((wm >> ((threadIdx.x & 63) & ~7)) & 0xFFull) != 0ull;
         if (__syncthreads_or(wanted) == 0) return;
     }
-    for (int i = threadIdx.x; i < 19 * 9 * OH_KC; i += 256) {
+    for (int i = threadIdx.x; i < (ZROW + 1) * OH_KC; i += 256) {
         const int jt = i / OH_KC, kk = i % OH_KC;
-        T[i] = (k0 + kk < K) ? table[(long long)jt * K + k0 + kk] : 0.f;
+        T[jt * RS + kk] = (jt < ZROW && k0 + kk < K) ? table[(long long)jt * K + k0 + kk] : 0.f;
     }
     if (threadIdx.x < OH_KC) bs[threadIdx.x] = (k0 + threadIdx.x < K) ? bias[k0 + threadIdx.x] : 0.f;
     __syncthreads();
@@ -61,22 +68,36 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        jt[t] = -1;
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-            const int j = lab[b * HW + (long long)yy * W + xx];
-            if (j < 19) jt[t] = (j * 9 + t) * OH_KC;           // labels >= 19 ("no class", e.g. 255): all-zero one-hot
-        }
+        const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const int j = lab[b * HW + (in ? (long long)yy * W + xx : 0)];
+        jt[t] = (in && j < 19 ? j * 9 + t : ZROW) * RS;        // labels >= 19 ("no class", e.g. 255): all-zero one-hot
     }
-    const int kmax = (K - k0 < OH_KC) ? (K - k0) : OH_KC;
-    for (int kk = 0; kk < kmax; ++kk) {
-        float v = bs[kk];
+    const long long p = pix % HW;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-            if (jt[t] >= 0) v += T[jt[t] + kk];
-        if (relu) v = v > 0.f ? v : 0.f;
-        const int k = k0 + kk;
-        if (c4) out[(((long long)b * (K >> 2) + (k >> 2)) * HW + (pix % HW)) * 4 + (k & 3)] = v;   // [B][K/4][HW][4]
-        else out[((long long)b * K + k) * HW + (pix % HW)] = v;
+    for (int gq = 0; gq < OH_KC / 4; ++gq) {
+        const int k = k0 + gq * 4;
+        if (k >= K) break;
+        float4 a = *reinterpret_cast<const float4*>(bs + gq * 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                          // bias first, then the taps in order (+0.f outside the image)
+            const float4 r = *reinterpret_cast<const float4*>(T + jt[t] + gq * 4);
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        if (relu) {
+            a.x = a.x > 0.f ? a.x : 0.f; a.y = a.y > 0.f ? a.y : 0.f;
+            a.z = a.z > 0.f ? a.z : 0.f; a.w = a.w > 0.f ? a.w : 0.f;
+        }
+        if (c4 && k + 3 < K) {                                 // [B][K/4][HW][4]
+            *reinterpret_cast<float4*>(out + (((long long)b * (K >> 2) + (k >> 2)) * HW + p) * 4) = a;
+        } else {
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k + e >= K) break;
+                if (c4) out[(((long long)b * (K >> 2) + ((k + e) >> 2)) * HW + p) * 4 + ((k + e) & 3)] = v[e];
+                else out[((long long)b * K + k + e) * HW + p] = v[e];
+            }
+        }
     }
 }
 

@@ -773,6 +773,8 @@ struct Runner {
             SL = &m.sp_level[lk][sw->TH == 16 ? 1 : 0];
         }
         // the label-table kernel only writes the hidden activations the conv will read
+        // (exact-f32 path: skipping pixels of the NCHW planes made the kernel slower at every granularity tried -- it is bound by
+        // its LDS table reads, not by the writes; the map stays available behind sean.dbg bit 131072)
         const uint8_t* need = (SL && !m.use_sh16 && (m.dbg & 131072)) ? SL->need : nullptr;
         const int* tile_cnt = (SL && m.use_sh16) ? SL->cnt : nullptr;
         AcePrep q;
@@ -847,7 +849,7 @@ struct Runner {
             ip.out_scale = a.out_scale;
             ip.out_amax = m.amax_slots + 2 * a.index;
             ip.bf16 = m.terms == 2;
-            ip.variant = (m.dbg & 65536) ? 1 : 0;
+            ip.variant = (m.dbg & 65536) ? 1 : ((m.dbg & 1048576) ? 2 : 0);      // (A/B measurements only)
             p.sp_list = L.list;
             p.sp_cnt = L.cnt;
             p.sp_work = sw->work;
@@ -972,7 +974,9 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         // interactive-size jobs: everything that depends on labels / codes only runs ahead on the side stream
         if (side && !prof_on && !(dbg & 4096)) {
             if (ahead_full && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd, true);
-            else if (use_sh16 && fcmu_batched && !(dbg & 8192)) R.prepare_all_ahead(lab, cd, false);
+            // large jobs: only the style LUT builds (small, latency-bound GEMMs) run ahead, in the tails of the conv kernels
+            // (exact-f32 path, B = 16 at 512^2: 147.2 -> 148.3 images/s)
+            else if ((fcmu_batched || !use_sh16) && !(dbg & 8192)) R.prepare_all_ahead(lab, cd, false);
         }
 
         const int sw = S / 32;
