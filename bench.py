@@ -270,13 +270,14 @@ def roofline_block(path, prof, value, B, sustained):
         executed, peak, pk = useful, PEAK_F32_MFMA_TFLOPS, 'f32'
         kname = ('conv_ace_sparse_kernel<TH> (SPADE gamma/beta conv over the compacted boundary pixels, exact-f32 MFMA, fused ACE '
                  'epilogue) + conv_mfma_kernel<KS=3,...,EPI_ACE> for the low-resolution ACEs')
-    traffic = detail = note = None
+    traffic = traffic_raw = detail = note = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
         try:
             detail = json.load(open(tpath)).get(path)
             if detail and detail.get('csrc_sha') == csrc_sha():
                 traffic = round(float(detail['hbm_bytes']))
+                traffic_raw = round(float(detail['fetch_raw']) + float(detail['write']))
             elif detail:
                 note = 'PMC passes on file were taken at other kernel sources (csrc_sha mismatch): not reported'
                 detail = None
@@ -292,9 +293,13 @@ def roofline_block(path, prof, value, B, sustained):
         'peak_sustained': sus, 'frac_of_sustained': round(executed / sus, 4) if sus else None,
         'peak_note': 'peak = spec at the 2.4 GHz boost clock; peak_sustained = MFMA-only loop measured on this device in this run '
                      '(ch_mfma_peak)',
-        'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)',
+        'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE: the guide\'s gfx950 correction, an upper bound)',
+        'traffic_uncorrected': traffic_raw,
         'algorithmic_bytes_per_launch': round(alg_bytes),
+        'algorithmic_bytes_note': 'sparse ACE launches: hidden activations + x + output of the BOUNDARY pixels only (the minimum); the kernel '
+                                  'stages whole tile patches, so its reads are those of every tile that holds a boundary pixel',
         'traffic_ratio': round(traffic / alg_bytes, 3) if (traffic and alg_bytes > 0) else None,
+        'traffic_ratio_uncorrected': round(traffic_raw / alg_bytes, 3) if (traffic_raw and alg_bytes > 0) else None,
         'traffic_detail': detail, 'traffic_note': note,
         'launches': ace['launches'], 'avg_launch_ms': round(ace['ms'] / n, 4),
         'flops_executed_per_launch_avg': ace['flops_executed'] / n, 'flops_dense_per_launch_avg': ace['flops'] / n,
