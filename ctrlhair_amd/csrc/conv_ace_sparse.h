@@ -76,8 +76,14 @@ __device__ __forceinline__ void ace_sparse_body(const ConvParams& p, float* smem
 
     const float4* Ap = reinterpret_cast<const float4*>(p.wpk) + ((long long)mtile64 * p.nchunks) * (NG * 2 * 64) + lane;
 
+    // sean.dbg bit 256 (profiling only): lane 0 of every wave stamps s_memtime at block start / after the prologue barrier /
+    // after the k-loop / after the epilogue, plus its NSUB (tools/sparse_timeline.py)
+    const bool stamp = (p.dbg & 256) && p.partial && lane == 0;
+    long long* stamps = reinterpret_cast<long long*>(p.partial) + ((long long)blockIdx.x * 4 + (tid >> 6)) * 5;
+    if (stamp) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[4] = NSUB; }
     stage(0, 0);
     __syncthreads();
+    if (stamp) stamps[1] = __builtin_amdgcn_s_memtime();
     for (int ch = 0; ch < p.nchunks; ++ch) {
         if (ch + 1 < p.nchunks) stage(ch + 1, (ch + 1) & 1);
         if constexpr (NSUB > 0) {
@@ -122,57 +128,20 @@ __device__ __forceinline__ void ace_sparse_body(const ConvParams& p, float* smem
         __syncthreads();
     }
 
-    // ---- ACE epilogue (conv_mfma.h EPI_ACE) on the compacted pixels: acc[0] = gamma rows, acc[1] = beta rows of 32 channels
+    if (stamp) stamps[2] = __builtin_amdgcn_s_memtime();
+    // ---- ACE epilogue (conv_mfma.h ace_epilogue_f32) on the compacted pixels
     if constexpr (NSUB > 0) {
-        const int hi = lane >> 5;
-        const int C = p.C;
-        const int xW = p.W >> p.x_up, xH = p.H >> p.x_up;
+        int py[NA], px[NA];
 #pragma unroll
         for (int n = 0; n < NSUB; ++n) {
-            if (!pok_[n]) continue;
-            const int b = b0, y = y0 + (pix_[n] >> 5), x = x0 + (pix_[n] & 31);
-            float sg[16], sbt[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sg[r] = 0.f; sbt[r] = 0.f; }
-            if (p.lut) {
-                const uint8_t* lb = p.lab + (long long)b * HW;
-#pragma unroll 1
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                    const int j0 = lb[in ? yy * p.W + xx : 0];
-                    const int j = j0 < 19 ? j0 : 0;                      // labels >= 19 ("no class"): no style term
-                    const float w = (in && j0 < 19) ? 1.f : 0.f;
-                    const float* Lp = p.lut + ((long long)(b * 19 + j) * 9 + t) * (2 * C);
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const int c4 = mtile64 * 32 + 8 * rq + 4 * hi;
-                        const int cc = c4 < C ? c4 : 0;
-                        const float4 g4 = *reinterpret_cast<const float4*>(Lp + cc);
-                        const float4 b4 = *reinterpret_cast<const float4*>(Lp + C + cc);
-                        sg[rq * 4 + 0] += w * g4.x; sg[rq * 4 + 1] += w * g4.y;
-                        sg[rq * 4 + 2] += w * g4.z; sg[rq * 4 + 3] += w * g4.w;
-                        sbt[rq * 4 + 0] += w * b4.x; sbt[rq * 4 + 1] += w * b4.y;
-                        sbt[rq * 4 + 2] += w * b4.z; sbt[rq * 4 + 3] += w * b4.w;
-                    }
-                }
-            }
-            const float nz = p.noise[(long long)b * p.noise_bstride + (long long)x * p.H + y];
-            const long long xpix = (long long)(y >> p.x_up) * xW + (x >> p.x_up);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = mtile64 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int cc = c < C ? c : 0;
-                const float gam = acc[0][n][r] + p.bias_g[cc] + sg[r];
-                const float bet = acc[1][n][r] + p.bias_b[cc] + sbt[r];
-                const float xv = p.x[((long long)b * C + cc) * (xW * xH) + xpix];
-                const float nrm = p.bn_a[cc] * xv + p.nv[cc] * nz + p.bn_d[cc];
-                float o = nrm * (1.f + gam) + bet;
-                o = apply_act(o, p.act);
-                if (c < C) p.out[((long long)b * C + c) * HW + (long long)y * p.W + x] = o;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            py[n] = y0 + (pix_[n] >> 5);
+            px[n] = x0 + (pix_[n] & 31);
         }
+        ace_epilogue_f32<NA>(p, acc, mtile64, lane >> 5, b0, py, px, pok_);
+    }
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (profiling only) include the store drain
+        stamps[3] = __builtin_amdgcn_s_memtime();
     }
 }
 

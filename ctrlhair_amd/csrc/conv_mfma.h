@@ -121,6 +121,96 @@ __device__ __forceinline__ int xcd_remap(int p, int n) {
     return base + k;
 }
 
+// Fused ACE epilogue of the exact-f32 SPADE convs (conv_mfma_kernel<..., EPI_ACE>, conv_ace_sparse_kernel): a wave tile holds
+// gamma rows in acc[0] and beta rows in acc[1] of 32 channels; lane (hi = lane >> 5) owns channels 8 rq + 4 hi + (0..3) of
+// its pixel of every sub-tile n.  normalization.py:111-112,117-153,172-187; architecture.py:95.
+// Written for memory-level parallelism (round 3: cycle stamps showed the former per-element version -- 80 scalar parameter
+// loads, 16 x loads and a serial 9-tap gather loop per pixel -- at 29 % (unstyled) to 44 % (styled) of a wave's lifetime):
+// channel-run (rq) outer, so the five per-channel parameters are one float4 each per run; the 3x3 label neighbourhood of a
+// pixel is fetched once and packed into 45 bits; the 18 style-LUT float4 of a (pixel, run) are independent loads.
+template <int NN>
+__device__ __forceinline__ void ace_epilogue_f32(const ConvParams& p, f32x16 (&acc)[2][NN], int mtile64, int hi, int b,
+                                                 const int (&py)[NN], const int (&px)[NN], const bool (&ok)[NN]) {
+    const int C = p.C, HW = p.H * p.W;
+    const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
+    float nz[NN];
+    int xo[NN], oo[NN];
+    unsigned long long labs[NN];          // 9 neighbour labels x 5 bits (31 = outside the image / "no class": no style term)
+    const uint8_t* lb = p.lab + (long long)b * HW;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const int y = py[n], x = px[n];
+        nz[n] = ok[n] ? p.noise[(long long)b * p.noise_bstride + (long long)x * p.H + y] : 0.f;
+        xo[n] = (y >> p.x_up) * xW + (x >> p.x_up);
+        oo[n] = y * p.W + x;
+        unsigned long long lv = 0;
+        if (p.lut && ok[n]) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                const unsigned jv = lb[in ? yy * p.W + xx : 0];              // unconditional load, select after
+                lv |= (unsigned long long)((in && jv < 19u) ? jv : 31u) << (5 * t);
+            }
+        }
+        labs[n] = lv;
+    }
+    const float* xb = p.x + (long long)b * C * xHW;
+    float* ob = p.out + (long long)b * C * HW;
+    const float* Lb = p.lut ? p.lut + (long long)b * 19 * 9 * 2 * C : nullptr;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const int c0 = mtile64 * 32 + 8 * rq + 4 * hi;
+        if (c0 >= C) continue;                                   // C % 4 == 0: a run is valid as a whole
+        const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + c0), pb = *reinterpret_cast<const float4*>(p.bias_b + c0);
+        const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + c0), pd = *reinterpret_cast<const float4*>(p.bn_d + c0);
+        const float4 pn = *reinterpret_cast<const float4*>(p.nv + c0);
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            if (!ok[n]) continue;
+            float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+            if (Lb) {
+                // three groups of three taps: six independent 16-byte gathers in flight (all eighteen spilled accumulators)
+#pragma unroll 1
+                for (int tg = 0; tg < 9; tg += 3) {
+                    float4 g4[3], b4[3];
+                    float w[3];
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) {
+                        const int t = tg + tt;
+                        const unsigned j0 = (unsigned)(labs[n] >> (5 * t)) & 31u;
+                        w[tt] = j0 < 19u ? 1.f : 0.f;
+                        const float* Lp = Lb + ((long long)((j0 < 19u ? j0 : 0u) * 9 + t) * 2) * C + c0;
+                        g4[tt] = *reinterpret_cast<const float4*>(Lp);
+                        b4[tt] = *reinterpret_cast<const float4*>(Lp + C);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) {
+                        sg.x += w[tt] * g4[tt].x; sg.y += w[tt] * g4[tt].y; sg.z += w[tt] * g4[tt].z; sg.w += w[tt] * g4[tt].w;
+                        sb.x += w[tt] * b4[tt].x; sb.y += w[tt] * b4[tt].y; sb.z += w[tt] * b4[tt].z; sb.w += w[tt] * b4[tt].w;
+                    }
+                }
+            }
+            const float* xp = xb + (long long)c0 * xHW + xo[n];
+            const float xv[4] = {xp[0], xp[xHW], xp[2 * xHW], xp[3 * xHW]};
+            const float g_[4] = {pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w};
+            const float b_[4] = {pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w};
+            const float a_[4] = {pa.x, pa.y, pa.z, pa.w}, d_[4] = {pd.x, pd.y, pd.z, pd.w}, n_[4] = {pn.x, pn.y, pn.z, pn.w};
+            float* op = ob + (long long)c0 * HW + oo[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = rq * 4 + e;
+                const float gam = acc[0][n][r] + g_[e];
+                const float bet = acc[1][n][r] + b_[e];
+                const float nrm = a_[e] * xv[e] + n_[e] * nz[n] + d_[e];
+                float o = nrm * (1.f + gam) + bet;
+                o = apply_act(o, p.act);
+                op[(long long)e * HW] = o;
+            }
+        }
+    }
+}
+
 template <int KS, int STRIDE, int WM, int TW, int TH, int TB, int CK, int EPI>
 struct ConvCfg {
     static constexpr int WN = 4 / WM;
@@ -385,55 +475,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 }
             }
     } else {  // EPI_ACE: wave tile = 32 channels: acc[0] = gamma rows, acc[1] = beta rows
-        const int C = p.C;
-        const int xW = p.W >> p.x_up, xH = p.H >> p.x_up;
+        int py[4], px[4];
+        bool ok[4];
+        int bq = b0;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
             const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
-            const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
-            if (b >= p.B || y >= p.H || x >= p.W) continue;
-            float sg[16], sbt[16];
+            py[n] = y0 + ty;
+            px[n] = x0 + tx;
+            ok[n] = b0 + tb < p.B && py[n] < p.H && px[n] < p.W;
+            if (n == 0) bq = b0 + tb;
+        }
+        if constexpr (TB == 1) {
+            ace_epilogue_f32<4>(p, acc, mtile64, hi, b0, py, px, ok);
+        } else {
+            // several samples per tile (low resolutions): a wave's four sub-tiles may belong to different samples
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sg[r] = 0.f; sbt[r] = 0.f; }
-            if (p.lut) {
-                const uint8_t* lb = p.lab + (long long)b * HW;
-#pragma unroll 1
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                    const int j0 = lb[in ? yy * p.W + xx : 0];
-                    const int j = j0 < 19 ? j0 : 0;                      // labels >= 19 ("no class"): no style term
-                    const float w = (in && j0 < 19) ? 1.f : 0.f;
-                    const float* Lp = p.lut + ((long long)(b * 19 + j) * 9 + t) * (2 * C);
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const int c4 = mtile64 * 32 + 8 * rq + 4 * hi;
-                        const int cc = c4 < C ? c4 : 0;               // clamped, rows >= C are never stored
-                        const float4 g4 = *reinterpret_cast<const float4*>(Lp + cc);
-                        const float4 b4 = *reinterpret_cast<const float4*>(Lp + C + cc);
-                        sg[rq * 4 + 0] += w * g4.x; sg[rq * 4 + 1] += w * g4.y;
-                        sg[rq * 4 + 2] += w * g4.z; sg[rq * 4 + 3] += w * g4.w;
-                        sbt[rq * 4 + 0] += w * b4.x; sbt[rq * 4 + 1] += w * b4.y;
-                        sbt[rq * 4 + 2] += w * b4.z; sbt[rq * 4 + 3] += w * b4.w;
-                    }
-                }
+            for (int n = 0; n < 4; ++n) {
+                const int idx = wn * 128 + n * 32 + col;
+                const int tb = idx / (TW * TH);
+                f32x16 a1[2][1] = {{acc[0][n]}, {acc[1][n]}};
+                const int py1[1] = {py[n]}, px1[1] = {px[n]};
+                const bool ok1[1] = {ok[n]};
+                ace_epilogue_f32<1>(p, a1, mtile64, hi, b0 + tb < p.B ? b0 + tb : b0, py1, px1, ok1);
             }
-            const float nz = p.noise[(long long)b * p.noise_bstride + (long long)x * p.H + y];
-            const long long xpix = (long long)(y >> p.x_up) * xW + (x >> p.x_up);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = mtile64 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int cc = c < C ? c : 0;
-                const float gam = acc[0][n][r] + p.bias_g[cc] + sg[r];
-                const float bet = acc[1][n][r] + p.bias_b[cc] + sbt[r];
-                const float xv = p.x[((long long)b * C + cc) * (xW * xH) + xpix];
-                const float nrm = p.bn_a[cc] * xv + p.nv[cc] * nz + p.bn_d[cc];
-                float o = nrm * (1.f + gam) + bet;
-                o = apply_act(o, p.act);
-                if (c < C) p.out[((long long)b * C + c) * HW + (long long)y * p.W + x] = o;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            (void)bq;
         }
     }
 }
