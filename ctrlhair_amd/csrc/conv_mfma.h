@@ -128,6 +128,7 @@ __device__ __forceinline__ int xcd_remap(int p, int n) {
 // loads, 16 x loads and a serial 9-tap gather loop per pixel -- at 29 % (unstyled) to 44 % (styled) of a wave's lifetime):
 // channel-run (rq) outer, so the five per-channel parameters are one float4 each per run; the 3x3 label neighbourhood of a
 // pixel is fetched once and packed into 45 bits; the 18 style-LUT float4 of a (pixel, run) are independent loads.
+constexpr int ACE_TG = 3;
 template <int NN>
 __device__ __forceinline__ void ace_epilogue_f32(const ConvParams& p, f32x16 (&acc)[2][NN], int mtile64, int hi, int b,
                                                  const int (&py)[NN], const int (&px)[NN], const bool (&ok)[NN]) {
@@ -170,22 +171,23 @@ __device__ __forceinline__ void ace_epilogue_f32(const ConvParams& p, f32x16 (&a
             if (!ok[n]) continue;
             float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
             if (Lb) {
-                // three groups of three taps: six independent 16-byte gathers in flight (all eighteen spilled accumulators)
+                // taps in groups of ACE_TG: 2 x ACE_TG independent 16-byte gathers in flight per round (all eighteen at once
+                // spilled accumulators); every round costs one L2 / MALL round trip
 #pragma unroll 1
-                for (int tg = 0; tg < 9; tg += 3) {
-                    float4 g4[3], b4[3];
-                    float w[3];
+                for (int tg = 0; tg < 9; tg += ACE_TG) {
+                    float4 g4[ACE_TG], b4[ACE_TG];
+                    float w[ACE_TG];
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) {
-                        const int t = tg + tt;
+                    for (int tt = 0; tt < ACE_TG; ++tt) {
+                        const int t = tg + tt < 9 ? tg + tt : 8;
                         const unsigned j0 = (unsigned)(labs[n] >> (5 * t)) & 31u;
-                        w[tt] = j0 < 19u ? 1.f : 0.f;
+                        w[tt] = (j0 < 19u && tg + tt < 9) ? 1.f : 0.f;
                         const float* Lp = Lb + ((long long)((j0 < 19u ? j0 : 0u) * 9 + t) * 2) * C + c0;
                         g4[tt] = *reinterpret_cast<const float4*>(Lp);
                         b4[tt] = *reinterpret_cast<const float4*>(Lp + C);
                     }
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) {
+                    for (int tt = 0; tt < ACE_TG; ++tt) {
                         sg.x += w[tt] * g4[tt].x; sg.y += w[tt] * g4[tt].y; sg.z += w[tt] * g4[tt].z; sg.w += w[tt] * g4[tt].w;
                         sb.x += w[tt] * b4[tt].x; sb.y += w[tt] * b4[tt].y; sb.z += w[tt] * b4[tt].z; sb.w += w[tt] * b4[tt].w;
                     }
@@ -431,32 +433,52 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     // ---- epilogue --------------------------------------------------------------------------------------
     const int hi = lane >> 5, col = lane & 31;
     if (EPI == EPI_PLAIN) {
+        // channel-run (m, rq) outer: the four bias values of a run are loaded once, not once per pixel; pixel offsets are
+        // computed once per sub-tile (the per-element version spent a third of its instructions on 64-bit address arithmetic)
+        const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
+        int pb_[4], pix_[4], rpix_[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = wn * 128 + n * 32 + col;
             const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
             const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
-            if (b >= p.B || y >= p.H || x >= p.W) continue;
-            const long long pix = (long long)y * p.W + x;
-            const int rW = p.W >> p.res_up, rH = p.H >> p.res_up;
-            const long long rpix = (long long)(y >> p.res_up) * rW + (x >> p.res_up);
+            pb_[n] = (b < p.B && y < p.H && x < p.W) ? b : -1;
+            pix_[n] = y * p.W + x;
+            rpix_[n] = (y >> p.res_up) * rW + (x >> p.res_up);
+        }
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mtile64 * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < p.Mrows && p.splitk > 1) {
-                        p.partial[(((long long)ks * p.B + b) * p.Mrows + row) * HW + pix] = acc[m][n][r];
-                    } else if (row < p.Mrows) {
-                        float v = acc[m][n][r];
-                        if (p.bias) v += p.bias[row];
-                        float rv = 0.f;
-                        if (p.res) rv = p.res[((long long)b * p.Mrows + row) * (rW * rH) + rpix];
+            for (int rq = 0; rq < 4; ++rq) {
+                const int row0 = mtile64 * 64 + m * 32 + 8 * rq + 4 * hi;
+                if (row0 >= p.Mrows) continue;
+                float bs[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && p.splitk <= 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bs[e] = row0 + e < p.Mrows ? p.bias[row0 + e] : 0.f;
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (pb_[n] < 0) continue;
+                    const long long ob = ((long long)pb_[n] * p.Mrows + row0) * HW + pix_[n];
+                    if (p.splitk > 1) {
+                        float* pp = p.partial + (long long)ks * p.B * p.Mrows * HW + ob;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row0 + e < p.Mrows) pp[(long long)e * HW] = acc[m][n][rq * 4 + e];
+                        continue;
+                    }
+                    const float* rp = p.res ? p.res + ((long long)pb_[n] * p.Mrows + row0) * rHW + rpix_[n] : nullptr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (row0 + e >= p.Mrows) break;
+                        float v = acc[m][n][rq * 4 + e] + bs[e];
+                        const float rv = rp ? rp[(long long)e * rHW] : 0.f;
                         v = p.res_after_act ? apply_act(v, p.act) + rv : apply_act(v + rv, p.act);
-                        p.out[((long long)b * p.Mrows + row) * HW + pix] = v;
+                        p.out[ob + (long long)e * HW] = v;
                     }
                 }
-        }
+            }
     } else if (EPI == EPI_NHWC) {
         // swapped operands: D[i = pixel in subtile][j = row in M-subtile]; lane col = row, regs = pixels
 #pragma unroll

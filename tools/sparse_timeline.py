@@ -42,8 +42,12 @@ def main():
     ok = (st[:, 4] >= 0) & (st[:, 4] <= 4) & (st[:, 0] > 0) & (st[:, 1] >= st[:, 0]) & (st[:, 2] >= st[:, 1]) & (st[:, 3] >= st[:, 2]) & \
         (st[:, 3] - st[:, 0] < 10 ** 8)
     if ok.any():
-        med = np.median(st[ok, 0])
-        ok &= np.abs(st[:, 0] - med) < 10 ** 9
+        last = st[ok, 0].max()                       # the most recent stamped launch only
+        ok &= (last - st[:, 0] < 10 ** 8) & (last - st[:, 0] >= 0)
+    print(f'(records: plausible NSUB {int(((st[:, 4] >= 0) & (st[:, 4] <= 4) & (st[:, 0] > 0)).sum())}, kept {int(ok.sum())})', file=sys.stderr)
+    if not ok.any():
+        print(st[:8], file=sys.stderr)
+        return
     st = st[ok]
     t0 = st[:, 0].min()
     span = st[:, 3].max() - t0
