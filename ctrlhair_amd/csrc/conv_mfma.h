@@ -134,77 +134,74 @@ __device__ __forceinline__ void ace_epilogue_f32(const ConvParams& p, f32x16 (&a
                                                  const int (&py)[NN], const int (&px)[NN], const bool (&ok)[NN]) {
     const int C = p.C, HW = p.H * p.W;
     const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
-    float nz[NN];
-    int xo[NN], oo[NN];
-    unsigned long long labs[NN];          // 9 neighbour labels x 5 bits (31 = outside the image / "no class": no style term)
     const uint8_t* lb = p.lab + (long long)b * HW;
+    const float* xb = p.x + (long long)b * C * xHW;
+    float* ob = p.out + (long long)b * C * HW;
+    const float* Lb = (p.lut && !(p.dbg & 4194304)) ? p.lut + (long long)b * 19 * 9 * 2 * C : nullptr;   // (bit: timing ablation)
+    // Pixel (n) outer: the nine (label, tap) row offsets of the pixel's style-LUT gathers are computed once and shared by its
+    // four channel runs (as 32-bit element offsets from the sample's LUT: <= 19*9*2*C floats); the five parameter float4 of a
+    // run are re-read per pixel from L1 instead (per-tap 64-bit address arithmetic was the larger cost).
 #pragma unroll
     for (int n = 0; n < NN; ++n) {
+        if (!ok[n]) continue;
         const int y = py[n], x = px[n];
-        nz[n] = ok[n] ? p.noise[(long long)b * p.noise_bstride + (long long)x * p.H + y] : 0.f;
-        xo[n] = (y >> p.x_up) * xW + (x >> p.x_up);
-        oo[n] = y * p.W + x;
-        unsigned long long lv = 0;
-        if (p.lut && ok[n]) {
+        const float nzn = p.noise[(long long)b * p.noise_bstride + (long long)x * p.H + y];
+        const int xon = (y >> p.x_up) * xW + (x >> p.x_up), oon = y * p.W + x;
+        unsigned lo[9];
+        unsigned lmask = 0;               // bit t: the tap carries a style term (inside the image, label < 19)
+        if (Lb) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
                 const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
                 const unsigned jv = lb[in ? yy * p.W + xx : 0];              // unconditional load, select after
-                lv |= (unsigned long long)((in && jv < 19u) ? jv : 31u) << (5 * t);
+                const bool on = in && jv < 19u;
+                lmask |= on ? 1u << t : 0u;
+                lo[t] = ((on ? jv : 0u) * 9u + (unsigned)t) * 2u * (unsigned)C;
             }
         }
-        labs[n] = lv;
-    }
-    const float* xb = p.x + (long long)b * C * xHW;
-    float* ob = p.out + (long long)b * C * HW;
-    const float* Lb = p.lut ? p.lut + (long long)b * 19 * 9 * 2 * C : nullptr;
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-        const int c0 = mtile64 * 32 + 8 * rq + 4 * hi;
-        if (c0 >= C) continue;                                   // C % 4 == 0: a run is valid as a whole
-        const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + c0), pb = *reinterpret_cast<const float4*>(p.bias_b + c0);
-        const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + c0), pd = *reinterpret_cast<const float4*>(p.bn_d + c0);
-        const float4 pn = *reinterpret_cast<const float4*>(p.nv + c0);
-#pragma unroll
-        for (int n = 0; n < NN; ++n) {
-            if (!ok[n]) continue;
+        for (int rq = 0; rq < 4; ++rq) {
+            const int c0 = mtile64 * 32 + 8 * rq + 4 * hi;
+            if (c0 >= C) continue;                               // C % 4 == 0: a run is valid as a whole
             float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
             if (Lb) {
+                const float* Lc = Lb + c0;
                 // taps in groups of ACE_TG: 2 x ACE_TG independent 16-byte gathers in flight per round (all eighteen at once
-                // spilled accumulators); every round costs one L2 / MALL round trip
-#pragma unroll 1
+                // spilled accumulators)
+#pragma unroll
                 for (int tg = 0; tg < 9; tg += ACE_TG) {
                     float4 g4[ACE_TG], b4[ACE_TG];
-                    float w[ACE_TG];
 #pragma unroll
                     for (int tt = 0; tt < ACE_TG; ++tt) {
                         const int t = tg + tt < 9 ? tg + tt : 8;
-                        const unsigned j0 = (unsigned)(labs[n] >> (5 * t)) & 31u;
-                        w[tt] = (j0 < 19u && tg + tt < 9) ? 1.f : 0.f;
-                        const float* Lp = Lb + ((long long)((j0 < 19u ? j0 : 0u) * 9 + t) * 2) * C + c0;
-                        g4[tt] = *reinterpret_cast<const float4*>(Lp);
-                        b4[tt] = *reinterpret_cast<const float4*>(Lp + C);
+                        g4[tt] = *reinterpret_cast<const float4*>(Lc + lo[t]);
+                        b4[tt] = *reinterpret_cast<const float4*>(Lc + lo[t] + C);
                     }
 #pragma unroll
                     for (int tt = 0; tt < ACE_TG; ++tt) {
-                        sg.x += w[tt] * g4[tt].x; sg.y += w[tt] * g4[tt].y; sg.z += w[tt] * g4[tt].z; sg.w += w[tt] * g4[tt].w;
-                        sb.x += w[tt] * b4[tt].x; sb.y += w[tt] * b4[tt].y; sb.z += w[tt] * b4[tt].z; sb.w += w[tt] * b4[tt].w;
+                        const float w = (tg + tt < 9 && ((lmask >> (tg + tt)) & 1u)) ? 1.f : 0.f;
+                        sg.x += w * g4[tt].x; sg.y += w * g4[tt].y; sg.z += w * g4[tt].z; sg.w += w * g4[tt].w;
+                        sb.x += w * b4[tt].x; sb.y += w * b4[tt].y; sb.z += w * b4[tt].z; sb.w += w * b4[tt].w;
                     }
+                    __builtin_amdgcn_sched_barrier(0);           // keep the groups apart (register pressure)
                 }
             }
-            const float* xp = xb + (long long)c0 * xHW + xo[n];
+            const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + c0), pb = *reinterpret_cast<const float4*>(p.bias_b + c0);
+            const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + c0), pd = *reinterpret_cast<const float4*>(p.bn_d + c0);
+            const float4 pn = *reinterpret_cast<const float4*>(p.nv + c0);
+            const float* xp = xb + (long long)c0 * xHW + xon;
             const float xv[4] = {xp[0], xp[xHW], xp[2 * xHW], xp[3 * xHW]};
             const float g_[4] = {pg.x + sg.x, pg.y + sg.y, pg.z + sg.z, pg.w + sg.w};
             const float b_[4] = {pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w};
             const float a_[4] = {pa.x, pa.y, pa.z, pa.w}, d_[4] = {pd.x, pd.y, pd.z, pd.w}, n_[4] = {pn.x, pn.y, pn.z, pn.w};
-            float* op = ob + (long long)c0 * HW + oo[n];
+            float* op = ob + (long long)c0 * HW + oon;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = rq * 4 + e;
                 const float gam = acc[0][n][r] + g_[e];
                 const float bet = acc[1][n][r] + b_[e];
-                const float nrm = a_[e] * xv[e] + n_[e] * nz[n] + d_[e];
+                const float nrm = a_[e] * xv[e] + n_[e] * nzn + d_[e];
                 float o = nrm * (1.f + gam) + bet;
                 o = apply_act(o, p.act);
                 op[(long long)e * HW] = o;

@@ -29,7 +29,7 @@ def main():
     nz = torch.from_numpy(P.noise_planes(B, S, ngf)).to(dev)
     gen.generate(lab, cd, nz)
     gen.handle.set_option('sean.dbg_sel', sel)
-    gen.handle.set_option('sean.dbg', 256)
+    gen.handle.set_option('sean.dbg', 256 | (int(sys.argv[3]) if len(sys.argv) > 3 else 0))
     nmax = 32768 * 4
     zero = np.zeros(nmax * 5, np.int64)
     for _ in range(2):
