@@ -81,7 +81,8 @@ hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t
 // ---- work list: exclusive scan of the block tasks per tile, one block of 1024 threads ------------------------------------
 // mode 0: block tasks of conv_ace_sparse_kernel (entry = tile | block task << 20); mode 1: tile-skip mode of the f16x3
 // wave-specialised kernel -- one entry (tile | row tile << 20) per row tile of every spatial tile with a boundary pixel, the
-// tile's 512 pixels all go through the conv (statistics count them as such)
+// tile's 512 pixels all go through the conv (statistics count them as such); mode 2: the same entries for the compacting
+// variant of that kernel (statistics count the boundary pixels / their 32-pixel sub-tiles)
 __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restrict__ cnt, int ntiles, int mtiles, int mode, int tile_px,
                                                             unsigned* __restrict__ work, int* __restrict__ total) {
     __shared__ int wsum[16];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restric
             int c = cnt[tile];
             if (mode == 1 && c > 0) c = tile_px;
             const int NS = (c + 31) >> 5;
-            if (mode == 1) {
+            if (mode >= 1) {           // mode 2: the same entries, but the conv only runs over the compacted boundary pixels
                 nbt = c > 0 ? mtiles : 0;
             } else {
                 int ng, per;
@@ -341,9 +342,10 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInterio
         bool mine = false;
         int j = 255;
         if (pix < HW) {
-            mine = q.cnt[(b * tiles_y + (y >> 4)) * tiles_x + (x >> 5)] == 0;
+            // variant 0: the pixels of boundary-free tiles (tile-skip mode); 1: every interior pixel (compacting conv kernel)
+            mine = q.variant == 1 || q.cnt[(b * tiles_y + (y >> 4)) * tiles_x + (x >> 5)] == 0;
             if (mine) j = q.u5[(long long)b * HW + pix];
-            mine = mine && j < 19;                            // (always true in such a tile)
+            mine = mine && j < 19;
         }
         if (__syncthreads_or(mine) == 0) continue;
         const float nz = mine ? q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y] : 0.f;

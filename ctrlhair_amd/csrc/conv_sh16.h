@@ -727,8 +727,15 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
+// CP (EPI_ACE, 32x16 tiles): pixel-level compaction of the exact SPADE-interior reduction (ace_sparse.h).  The loaders still
+// stage the whole patch and the A fragments of every listed tile, but the consumers run their MFMAs and the ACE epilogue over the
+// tile's BOUNDARY pixels only: the per-tile list (uint16 in-tile offsets, raster order) and count reach LDS a tile ahead
+// (double-buffered, staged by the loaders), a consumer wave takes the 32-pixel sub-tiles wn, wn + 4, ... and reads its B fragments
+// at the patch offsets of ITS pixels.  Operand delivery (76 KB per chunk at ~12 B/cycle/CU) then bounds a sparse tile's k-loop,
+// not the MFMAs; the epilogue shrinks with the pixel count.
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool CP = false>
 __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p) {
+    static_assert(!CP || (EPI == EPI_ACE && KS == 3 && TW == 32 && TH == 16 && TB == 1), "CP: the ACE kernel's 32x16 tiles only");
     using Cfg = ShCfg<KS, TW, TH, TB>;
     constexpr int PW = Cfg::PW, PH = Cfg::PH, PLANE = Cfg::PLANE, UNITS = Cfg::UNITS, HALO = Cfg::HALO;
     constexpr int NT = KS * KS;
@@ -741,6 +748,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     constexpr int AUNITS = NT * 4 * 64, STAGE = UNITS + AUNITS;
     constexpr int NPAR = 5;                                  // float4 per channel run: s(1+bias_g), s*bias_b, bn_a, bn_d, nv
     constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + 8 * NPAR, LAB0 = NZ0 + 128;
+    [[maybe_unused]] constexpr int LIST0 = LAB0 + (TB * (TH + 2) * (TW + 2) + 15) / 16, META0 = LIST0 + 128;   // CP: 2 x 1 KB lists, 2 x count
     constexpr int NDA = AUNITS / 256;                        // A DMA instructions per loader thread per chunk
     constexpr int LW = TW + 2, LH = TH + 2;
     constexpr bool pre = EPI == EPI_ACE;    /* host guarantees nchunks >= 3 */       // epilogue operands prefetched through LDS
@@ -898,14 +906,32 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                 }
             }
         };
+        // CP: boundary-pixel list + count of tile k -> LDS buffer k & 1, one tile ahead of the consumers
+        [[maybe_unused]] unsigned listr = 0;
+        [[maybe_unused]] int cntr = 0;
+        auto list_load = [&](int k) {
+            if constexpr (CP) {
+                const unsigned tile = p.sp_work[first + k * (int)gridDim.x] & 0xFFFFFu;
+                listr = reinterpret_cast<const unsigned*>(p.sp_list + (long long)tile * (TW * TH))[ltid];
+                if (ltid == 0) cntr = p.sp_cnt[tile];
+            }
+        };
+        auto list_store = [&](int k) {
+            if constexpr (CP) {
+                reinterpret_cast<unsigned*>(smem_u + LIST0 + (k & 1) * 64)[ltid] = listr;
+                if (ltid == 0) reinterpret_cast<int*>(smem_u + META0)[k & 1] = cntr;
+            }
+        };
         if (Q > 0) {
             dma_A(0);
             load_chunk(0, stgA);
             if (Q > 1) load_chunk(1, stgB);
             store_chunk(0, stgA);
             if (Q > 2) load_chunk(2, stgA);
+            list_load(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (Q > 0) list_store(0);
         __syncthreads();                                      // stage 0 ready
         // iteration q: A(q+1) by DMA and patch q+1 (requested two iterations ago) -> LDS stage (q+1)&1, request patch q+3.
         // Vector-memory results return in order, so waiting until only the NLD newest loads (the patch just requested)
@@ -916,14 +942,20 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                 dma_A(q + 1);
                 store_chunk((q + 1) & 1, stg);
             }
-            if (pre && ch == p.nchunks - 1) epi_store();      // consumers read these after this iteration's barrier
+            if (pre && ch == p.nchunks - 1) {                 // consumers read these after this iteration's barrier
+                epi_store();
+                if (k + 1 < my_tiles) list_store(k + 1);
+            }
             if (q + 3 < Q) {
                 load_chunk(q + 3, stg);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (pre && ch == p.nchunks - 2) epi_load(k);      // younger than everything waited on above
+            if (pre && ch == p.nchunks - 2) {                 // younger than everything waited on above
+                epi_load(k);
+                if (k + 1 < my_tiles) list_load(k + 1);
+            }
             __syncthreads();
         };
         for (int q = 0; q < Q; q += 2) {
@@ -953,6 +985,20 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         int mtile64, x0, y0, b0;
         tile_coords(k, mtile64, x0, y0, b0);
         if (stamp && k < 64) stamps[k * 3] = __builtin_amdgcn_s_memtime();
+        [[maybe_unused]] int nsub = 4, cnt = 0;               // CP: this wave's sub-tiles wn, wn + 4, ... of the tile's compacted pixels
+        [[maybe_unused]] const uint16_t* lst = nullptr;
+        if constexpr (CP) {
+            cnt = reinterpret_cast<const int*>(smem_u + META0)[k & 1];
+            lst = reinterpret_cast<const uint16_t*>(smem_u + LIST0 + (k & 1) * 64);
+            const int NS = (cnt + 31) >> 5;
+            nsub = NS > wn ? (NS - wn + 3) >> 2 : 0;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int slot = (wn + 4 * n) * 32 + (lane & 31);
+                const int idx = lst[slot < cnt ? slot : cnt - 1];     // slots beyond the count repeat the last boundary pixel
+                ub[n] = (lane >> 5) * 2 * PLANE + (idx >> 5) * PW + (idx & 31);
+            }
+        }
         f32x16 acc[2][4];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -960,6 +1006,64 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        // CP, at most two sub-tiles: plain double-buffered k-step (the hand-ordered one below is written for four sub-tiles)
+        auto kloop_small = [&](auto ns_) {
+            constexpr int NS_ = decltype(ns_)::value;
+            for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
+                if constexpr (NS_ > 0) {
+                    const uint4* sb = smem_u + (q & 1) * STAGE;
+                    const uint4* sa = sb + UNITS + lane;
+                    uint4 a_c[4], bh_c[NS_], bl_c[NS_];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a_c[i] = sa[i * 64];
+#pragma unroll
+                    for (int n = 0; n < NS_; ++n) {
+                        bh_c[n] = sb[ub[n]];
+                        bl_c[n] = sb[ub[n] + PLANE];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        uint4 a_n[4], bh_n[NS_], bl_n[NS_];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a_n[i] = a_c[i];
+#pragma unroll
+                        for (int n = 0; n < NS_; ++n) { bh_n[n] = bh_c[n]; bl_n[n] = bl_c[n]; }
+                        if (t + 1 < NT) {
+                            const int knxt = ((t + 1) / KS) * PW + ((t + 1) % KS);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) a_n[i] = sa[((t + 1) * 4 + i) * 64];
+#pragma unroll
+                            for (int n = 0; n < NS_; ++n) {
+                                bh_n[n] = sb[ub[n] + knxt];
+                                bl_n[n] = sb[ub[n] + knxt + PLANE];
+                            }
+                        }
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < NS_; ++n) {
+                                if (TERMS == 3) {
+                                    acc[m][n] = mfma16<TERMS>(a_c[m * 2 + 1], bh_c[n], acc[m][n]);
+                                    acc[m][n] = mfma16<TERMS>(a_c[m * 2 + 0], bl_c[n], acc[m][n]);
+                                }
+                                acc[m][n] = mfma16<TERMS>(a_c[m * 2 + 0], bh_c[n], acc[m][n]);
+                            }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a_c[i] = a_n[i];
+#pragma unroll
+                        for (int n = 0; n < NS_; ++n) { bh_c[n] = bh_n[n]; bl_c[n] = bl_n[n]; }
+                    }
+                }
+                __syncthreads();
+            }
+        };
+        bool small_done = false;
+        if constexpr (CP) {
+            if (nsub == 0) { kloop_small(std::integral_constant<int, 0>{}); small_done = true; }
+            else if (nsub == 1) { kloop_small(std::integral_constant<int, 1>{}); small_done = true; }
+            else if (nsub == 2) { kloop_small(std::integral_constant<int, 2>{}); small_done = true; }
+        }
+        if (!small_done)
         for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
             const uint4* sb = smem_u + (q & 1) * STAGE;
             const uint4* sa = sb + UNITS + lane;
@@ -1043,7 +1147,12 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                 constexpr bool RESC = decltype(resc)::value;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const int idx = wn * 128 + n * 32 + col;
+                    int idx = wn * 128 + n * 32 + col;
+                    if constexpr (CP) {                              // this lane's compacted boundary pixel of sub-tile wn + 4 n
+                        const int slot = (wn + 4 * n) * 32 + col;
+                        if (n >= nsub || slot >= cnt) continue;
+                        idx = lst[slot];
+                    }
                     const int tx = idx % TW, ty = (idx / TW) % TH, tb = idx / (TW * TH);
                     const int b = b0 + tb, y = y0 + ty, x = x0 + tx;
                     if (b >= p.B || y >= p.H || x >= p.W) continue;
@@ -1105,14 +1214,15 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     }
 }
 
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool CP = false>
 hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     if (p.in_mode != IN_DIRECT) return hipErrorInvalidValue;     // input views are implemented in conv_sh16_kernel only
-    auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS>;
+    if (CP && !(p.sp_work && p.sp_list && p.sp_cnt && p.sp_total)) return hipErrorInvalidValue;
+    auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS, CP>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
-    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16
+    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16 + (CP ? 129 * 16 : 0)
                                           : 2 * V3_STAGE * 16;
     // per device: a process may own handles on several GPUs (ch_api.cpp DeviceGuard)
     static bool attr_set[64] = {};
@@ -1260,8 +1370,12 @@ hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
     // but its half-size tiles double the A-fragment traffic and the loaders cannot deliver it: DESIGN.md section 7)
     if ((p.dbg & 2048) && p.Cin == 128 && p.W >= 32) return launch_sh16_ws2<TERMS>(p, rows, s);
     const bool ws_ok = p.W >= 32 && p.Cin >= 48;
-    if (ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512)))
+    if (ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512))) {
+        if constexpr (TERMS == 3) {        // pixel-level compaction when the caller passes the per-tile lists (sean_model.cpp)
+            if (p.sp_work && p.sp_list) return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, true>(p, rows, s);
+        }
         return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS>(p, rows, s);
+    }
     if (p.W >= 32) return launch_sh16<3, 32, 16, 1, EPI_ACE, TERMS>(p, rows, s);
     if (p.W > 8) return launch_sh16<3, 16, 16, 2, EPI_ACE, TERMS>(p, rows, s);
     return launch_sh16<3, 8, 8, 8, EPI_ACE, TERMS>(p, rows, s);

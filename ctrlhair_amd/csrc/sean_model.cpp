@@ -501,7 +501,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     SparseWork w;
                     w.mtiles = mt;
                     w.TH = L.TH;
-                    w.mode = use_sh16 ? 1 : 0;
+                    w.mode = use_sh16 ? ((sh16_compact && terms == 3) ? 2 : 1) : 0;
                     w.cap = (long long)L.cap_tiles * (use_sh16 ? mt : sparse_max_tasks(L.TH, mt));
                     w.work = static_cast<unsigned*>(B.dalloc((size_t)w.cap * sizeof(unsigned)));
                     w.total = static_cast<int*>(B.dalloc(4 * sizeof(int)));
@@ -775,8 +775,11 @@ struct Runner {
         // the label-table kernel only writes the hidden activations the conv will read
         // (exact-f32 path: skipping pixels of the NCHW planes made the kernel slower at every granularity tried -- it is bound by
         // its LDS table reads, not by the writes; the map stays available behind sean.dbg bit 131072)
-        const uint8_t* need = (SL && !m.use_sh16 && (m.dbg & 131072)) ? SL->need : nullptr;
-        const int* tile_cnt = (SL && m.use_sh16) ? SL->cnt : nullptr;
+        const uint8_t* need0 = (SL && !m.use_sh16 && (m.dbg & 131072)) ? SL->need : nullptr;
+        const uint8_t* need = need0;
+        const bool compact = SL && m.use_sh16 && sw->mode == 2;      // f16x3: pixel-level compaction inside the ws kernel
+        if (compact) need = SL->need;
+        const int* tile_cnt = (SL && m.use_sh16 && !compact) ? SL->cnt : nullptr;
         AcePrep q;
         if (ahead) {
             q = prepared[a.index];
@@ -849,8 +852,8 @@ struct Runner {
             ip.out_scale = a.out_scale;
             ip.out_amax = m.amax_slots + 2 * a.index;
             ip.bf16 = m.terms == 2;
-            ip.variant = (m.dbg & 65536) ? 1 : ((m.dbg & 1048576) ? 2 : 0);      // (A/B measurements only)
-            p.sp_list = L.list;
+            ip.variant = m.use_sh16 ? (compact ? 1 : 0) : ((m.dbg & 65536) ? 1 : ((m.dbg & 1048576) ? 2 : 0));
+            p.sp_list = (m.use_sh16 && !compact) ? nullptr : L.list;      // f16x3: the lists request the compacting kernel
             p.sp_cnt = L.cnt;
             p.sp_work = sw->work;
             p.sp_total = sw->total;
