@@ -789,6 +789,175 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     };
 
     if (loader) {
+        if constexpr (CP) {
+            // ------------------------------------------------------------ loaders of the compacting kernel: split roles
+            // A wave's vector-memory results return in order.  In the shared loader below every wave issues both the chunk's A
+            // DMA and its patch prefetch and must see the DMA land inside the chunk's own iteration -- which also drains the
+            // patch loads issued one iteration earlier, i.e. gives them ONE chunk time to return.  On compacted tiles a chunk
+            // is 4x shorter than an HBM round trip under load, and the k-loop ran at that latency (39 k cycles for 13.8 k of
+            // MFMAs).  Here waves 4-5 only move A fragments (+ the small epilogue operands and the pixel lists) and waves 6-7
+            // only prefetch patches three chunks ahead, each with its own vmcnt.
+            const int lw = wave - 4, ht = ltid & 127;                     // role-local thread id 0..127
+            if (lw < 2) {
+                const uint4* gA = reinterpret_cast<const uint4*>(p.wpk);
+                int dma_k = -1, dma_mt = 0;
+                auto dmaA = [&](int q) {
+                    const int kq = q / p.nchunks;
+                    if (kq != dma_k) {
+                        int x0, y0, b0;
+                        tile_coords(kq, dma_mt, x0, y0, b0);
+                        dma_k = kq;
+                    }
+                    const uint4* src = gA + ((long long)dma_mt * p.nchunks + q % p.nchunks) * AUNITS + ht;
+                    uint4* dst = smem_u + (q & 1) * STAGE + UNITS + lw * 64;
+#pragma unroll
+                    for (int i = 0; i < AUNITS / 128; ++i)
+                        __builtin_amdgcn_global_load_lds((glb_void*)(src + i * 128), (lds_void*)(dst + i * 128), 16, 0, 0);
+                };
+                float4 parr = make_float4(0.f, 0.f, 0.f, 0.f);
+                float nzr[4] = {0.f, 0.f, 0.f, 0.f};
+                uint8_t labr[5] = {255, 255, 255, 255, 255};
+                unsigned listr[2] = {0u, 0u};
+                int cntr = 0;
+                auto small_load = [&](int k) {                            // epilogue operands of tile k, pixel list of tile k + 1
+                    int mt, x0, y0, b0;
+                    tile_coords(k, mt, x0, y0, b0);
+                    const int C = p.C;
+                    if (ht < 8 * NPAR) {
+                        const int run = ht / NPAR, which = ht % NPAR;
+                        const int c0 = (mt * 8 + run) * 4;
+                        const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
+                        parr = *reinterpret_cast<const float4*>(src + (c0 < C ? c0 : 0));
+                        const float osc = p.out_scale != 0.f ? p.out_scale : 1.f;
+                        if (which == 0) parr = make_float4((parr.x + 1.f) * osc, (parr.y + 1.f) * osc, (parr.z + 1.f) * osc, (parr.w + 1.f) * osc);
+                        if (which == 1) parr = make_float4(parr.x * osc, parr.y * osc, parr.z * osc, parr.w * osc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int idx = ht + i * 128;
+                        const int y = y0 + idx / TW, x = x0 + idx % TW;
+                        const bool ok = b0 < p.B && y < p.H && x < p.W;
+                        nzr[i] = p.noise[ok ? (long long)b0 * p.noise_bstride + (long long)x * p.H + y : 0];
+                    }
+                    if (p.lut) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            const int e = ht + i * 128;
+                            labr[i] = 255;
+                            if (e < LH * LW) {
+                                const int y = y0 - 1 + e / LW, x = x0 - 1 + e % LW;
+                                const bool in = b0 < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                                const uint8_t v = p.lab[in ? (long long)b0 * HW + y * p.W + x : 0];
+                                labr[i] = in ? v : (uint8_t)255;
+                            }
+                        }
+                    }
+                };
+                auto small_store = [&]() {
+                    if (ht < 8 * NPAR) reinterpret_cast<float4*>(smem_u + PAR0)[ht] = parr;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) reinterpret_cast<float*>(smem_u + NZ0)[ht + i * 128] = nzr[i];
+                    if (p.lut) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            const int e = ht + i * 128;
+                            if (e < LH * LW) reinterpret_cast<uint8_t*>(smem_u + LAB0)[e] = labr[i];
+                        }
+                    }
+                };
+                auto list_load = [&](int k) {
+                    const unsigned tile = p.sp_work[first + k * (int)gridDim.x] & 0xFFFFFu;
+                    const unsigned* src = reinterpret_cast<const unsigned*>(p.sp_list + (long long)tile * (TW * TH));
+                    listr[0] = src[ht];
+                    listr[1] = src[ht + 128];
+                    if (ht == 0) cntr = p.sp_cnt[tile];
+                };
+                auto list_store = [&](int k) {
+                    unsigned* dst = reinterpret_cast<unsigned*>(smem_u + LIST0 + (k & 1) * 64);
+                    dst[ht] = listr[0];
+                    dst[ht + 128] = listr[1];
+                    if (ht == 0) reinterpret_cast<int*>(smem_u + META0)[k & 1] = cntr;
+                };
+                if (Q > 0) {
+                    dmaA(0);
+                    list_load(0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (Q > 0) list_store(0);
+                __syncthreads();                                  // stage 0 ready
+                for (int q = 0; q < Q; ++q) {
+                    const int k = q / p.nchunks, ch = q % p.nchunks;
+                    if (q + 1 < Q) dmaA(q + 1);
+                    if (ch == p.nchunks - 1) {                    // consumers read these after this iteration's barrier
+                        small_store();
+                        if (k + 1 < my_tiles) list_store(k + 1);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the A fragments of chunk q + 1 have landed
+                    if (ch == p.nchunks - 2) {
+                        small_load(k);
+                        if (k + 1 < my_tiles) list_load(k + 1);
+                    }
+                    __syncthreads();
+                }
+            } else {
+                constexpr int NL2 = (UNITS + 127) / 128;
+                int soff[NL2];
+                int cur_tile = -1;
+                auto set_tile = [&](int k) {
+                    int mt, x0, y0, b0;
+                    tile_coords(k, mt, x0, y0, b0);
+#pragma unroll
+                    for (int i = 0; i < NL2; ++i) {
+                        const int u = ht + i * 128;
+                        soff[i] = -1;
+                        if (u < UNITS) {
+                            const int gh = u / PLANE, rem = u % PLANE;
+                            const int py = rem / PW, px = rem % PW;
+                            const int y = y0 + py - HALO, x = x0 + px - HALO;
+                            if (b0 < p.B && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                                soff[i] = ((b0 * G + (gh >> 1)) * 2 + (gh & 1)) * HW + y * p.W + x;
+                        }
+                    }
+                    cur_tile = k;
+                };
+                uint4 stgA[NL2], stgB[NL2];
+                auto load_chunk = [&](int q, uint4 (&stg)[NL2]) {
+                    const int k = q / p.nchunks, ch = q % p.nchunks;
+                    if (k != cur_tile) set_tile(k);
+                    const uint4* src = gin + (long long)ch * 4 * HW;
+#pragma unroll
+                    for (int i = 0; i < NL2; ++i) {
+                        const uint4 v = src[soff[i] >= 0 ? soff[i] : 0];
+                        stg[i] = soff[i] >= 0 ? v : make_uint4(0, 0, 0, 0);
+                    }
+                };
+                auto store_chunk = [&](int stage, const uint4 (&stg)[NL2]) {
+                    uint4* dst = smem_u + stage * STAGE;
+#pragma unroll
+                    for (int i = 0; i < NL2; ++i) {
+                        const int u = ht + i * 128;
+                        if (u < UNITS) dst[u] = stg[i];
+                    }
+                };
+                if (Q > 0) {
+                    load_chunk(0, stgA);
+                    if (Q > 1) load_chunk(1, stgB);
+                    store_chunk(0, stgA);
+                    if (Q > 2) load_chunk(2, stgA);
+                }
+                __syncthreads();                                  // stage 0 ready
+                auto iter = [&](int q, uint4 (&stg)[NL2]) {
+                    if (q + 1 < Q) store_chunk((q + 1) & 1, stg);  // requested two iterations ago
+                    if (q + 3 < Q) load_chunk(q + 3, stg);
+                    __syncthreads();
+                };
+                for (int q = 0; q < Q; q += 2) {
+                    iter(q, stgB);
+                    if (q + 1 < Q) iter(q + 1, stgA);
+                }
+            }
+            return;
+        }
         // ---------------------------------------------------------------- loaders
         int soff[NLD];
         int cur_tile = -1;
