@@ -93,6 +93,9 @@ struct AceInteriorParams {
     unsigned* out_amax;
     int pass, bf16;
     const int* cnt;             // f16x3 path: boundary-pixel count per tile of 32 x 16 (tiles_x = ceil(W / 32))
+    int impl;                   // f16x3 kernel: 0 = blocks of 32 x 8 pixels (default), 1 = blocks of 256 consecutive pixels (A/B)
+    int fill_min;               // f16x3 kernel, variant 1: a block with at least this many interior pixels (of 256) writes ALL its
+                                // pixels -- the boundary conv, launched after this pass, overwrites the others; 0 = 128
     int variant;                // exact-f32 kernel: 0 = one pixel per thread (default), 1 = four pixels per thread (16-byte
                                 // accesses), 2 = one pixel per thread writing whole 32-byte sectors (A/B measurements)
 };

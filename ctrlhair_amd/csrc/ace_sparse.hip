@@ -298,10 +298,63 @@ __global__ __launch_bounds__(256) void ace_interior_f32_scalar_kernel(const AceI
     }
 }
 
+// Blocks of 32 x 8 pixels (the default; tools/interior_bench.hip measures it against the row kernel above): whole 32-byte
+// sectors of the [W][H] noise plane instead of 4 bytes out of each of 256 lines, and a block that is mostly interior writes ALL
+// its pixels -- no divergence, no byte-masked sectors; the boundary conv runs after this pass on the same stream and
+// overwrites the boundary pixels (a filler pixel is computed with table row 0).
+__global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInteriorParams q) {
+    constexpr int RS = 2 * IN_CG + 1;
+    __shared__ float gt[19 * RS];
+    __shared__ float pa[IN_CG], pd[IN_CG], pn[IN_CG];
+    const int HW = q.H * q.W, tpr = (q.W + 31) >> 5, tpc = (q.H + 7) >> 3;
+    const int b = blockIdx.x / (tpr * tpc), r = blockIdx.x - b * (tpr * tpc), tyi = r / tpr, c0 = blockIdx.y * IN_CG;
+    const int x = (r - tyi * tpr) * 32 + (threadIdx.x & 31), y = tyi * 8 + (threadIdx.x >> 5);
+    const bool inimg = x < q.W && y < q.H;
+    const int pix = y * q.W + x;
+    int j = inimg ? q.u5[(long long)b * HW + pix] : 255;
+    const bool mine = j < 19;
+    const int nmine = __syncthreads_count(mine);
+    if (nmine == 0) return;                                  // no interior pixel in this block
+    const bool wr = inimg && (mine || nmine >= (q.fill_min > 0 ? q.fill_min : 128));
+    if (!mine) j = 0;
+    const float nz = wr ? q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y] : 0.f;
+    for (int i = threadIdx.x; i < 19 * 2 * IN_CG; i += 256) {
+        const int jj = i / (2 * IN_CG), rr = i % (2 * IN_CG), gb = rr / IN_CG, c = c0 + rr % IN_CG;
+        gt[jj * RS + rr] = c < q.C ? q.gtab[(((long long)b * 19 + jj) * 2 + gb) * q.C + c] : 0.f;
+    }
+    if (threadIdx.x < IN_CG) {
+        const int c = c0 + threadIdx.x;
+        pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
+        pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
+        pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
+    }
+    __syncthreads();
+    if (!wr) return;
+    const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up);
+    const float* __restrict__ xp = q.x + ((long long)b * q.C + c0) * xHW + (y >> q.x_up) * xW + (x >> q.x_up);
+    float* __restrict__ op = reinterpret_cast<float*>(q.out) + ((long long)b * q.C + c0) * HW + pix;
+    const float* g = gt + j * RS;
+    const int cmax = q.C - c0 < IN_CG ? q.C - c0 : IN_CG;
+    const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
+#pragma unroll 8
+    for (int c = 0; c < cmax; ++c) {
+        const float xv = xp[(long long)c * xHW];
+        const float nrm = pa[c] * xv + pn[c] * nz + pd[c];
+        float o = nrm * (1.f + g[c]) + g[IN_CG + c];
+        o = fmaxf(o, slope * o);
+        op[(long long)c * HW] = o;
+    }
+}
+
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU) return hipErrorInvalidValue;
     if (q.W % 4 != 0) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
+    if (q.impl == 0) {
+        dim3 gridt((unsigned)(q.B * ((q.W + 31) / 32) * ((q.H + 7) / 8)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
+        hipLaunchKernelGGL(ace_interior_f32_tile_kernel, gridt, dim3(256), 0, s, q);
+        return hipGetLastError();
+    }
     if (q.variant != 1) {       // default (0) and the full-sector experiment (2): one pixel per thread
         dim3 grid1((unsigned)(q.B * ((HW + 255) / 256)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_scalar_kernel, grid1, dim3(256), 0, s, q);
@@ -411,9 +464,123 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInterio
     if (q.pass == 0 && q.out_amax) sh16_block_slot_max(q.out_amax, amax);
 }
 
+// Same arithmetic, blocks of 32 x 8 pixels (tools/interior_bench.hip measures both):
+//  * the noise plane is stored [W][H]: a block of 256 consecutive pixels of a row touched 256 different 64-byte lines of it for
+//    4 bytes each (and the 15 other rows of a line sit in blocks that run on other XCDs, behind other L2s); 8 rows of 32 pixels
+//    use whole 32-byte sectors;
+//  * the slab's x loads are issued BEFORE the table staging and its barriers (they do not depend on the table), so a slab
+//    exposes one memory latency instead of two; the table is staged with 16-byte loads;
+//  * pixel-level mode: a block that is mostly interior writes ALL its pixels (no divergence, no byte-masked partial sectors);
+//    the boundary conv runs after this pass on the same stream and overwrites the boundary pixels.  Those pixels never enter
+//    the recorded maximum.
+__global__ __launch_bounds__(256) void ace_interior_sh16_tile_kernel(const AceInteriorParams q) {
+    constexpr int CB = IS_GPB * 8, RS = 2 * CB + 4;
+    __shared__ __attribute__((aligned(16))) float gt[19 * RS];
+    __shared__ __attribute__((aligned(16))) float pa[CB], pd[CB], pn[CB];
+    sh16_mode_on();
+    float extra = 1.f;
+    if (q.pass == 1) {
+        extra = sh16_dyn_extra(*q.out_amax);
+        if (extra == 1.f) return;                             // nothing to repair (the normal case)
+    }
+    const int HW = q.H * q.W;
+    const int tpr = (q.W + 31) >> 5, tpc = (q.H + 7) >> 3, ntile = q.B * tpr * tpc;
+    const int tiles_x = tpr, tiles_y = (q.H + 15) >> 4;
+    const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up), Go = (q.C + 7) >> 3;
+    const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
+    const float osc = q.out_scale * extra;
+    const int fill_min = q.variant == 1 ? (q.fill_min > 0 ? q.fill_min : 128) : 257;
+    float amax = 0.f;
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int b = t / (tpr * tpc), r = t - b * (tpr * tpc), tyi = r / tpr;
+        const int x = (r - tyi * tpr) * 32 + (threadIdx.x & 31), y = tyi * 8 + (threadIdx.x >> 5);
+        const bool inimg = x < q.W && y < q.H;
+        const int pix = y * q.W + x;
+        bool mine = false;
+        int j = 255;
+        if (inimg) {
+            mine = q.variant == 1 || q.cnt[(b * tiles_y + (y >> 4)) * tiles_x + (x >> 5)] == 0;
+            if (mine) j = q.u5[(long long)b * HW + pix];
+            mine = mine && j < 19;
+        }
+        const int nmine = __syncthreads_count(mine);
+        if (nmine == 0) continue;
+        const bool wr = inimg && (mine || nmine >= fill_min);
+        if (!mine) j = 0;
+        const float nz = wr ? q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y] : 0.f;
+        const long long xpix = (long long)(y >> q.x_up) * xW + (x >> q.x_up);
+        const float4* __restrict__ xp = reinterpret_cast<const float4*>(q.x) + (long long)b * (q.C >> 2) * xHW + (inimg ? xpix : 0);
+        uint4* __restrict__ op = reinterpret_cast<uint4*>(q.out) + (long long)b * Go * 2 * HW + pix;
+        for (int c0 = 0; c0 < q.C; c0 += CB) {
+            float4 xa[IS_GPB][2];
+#pragma unroll
+            for (int gq = 0; gq < IS_GPB; ++gq) {
+                const int c = c0 + gq * 8;
+                xa[gq][0] = xa[gq][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wr && c < q.C) {
+                    xa[gq][0] = xp[(long long)(c >> 2) * xHW];
+                    if (c + 4 < q.C) xa[gq][1] = xp[(long long)((c >> 2) + 1) * xHW];
+                }
+            }
+            __syncthreads();                                  // the previous slab's table is no longer read
+            for (int i = threadIdx.x; i < 19 * 2 * (CB / 4); i += 256) {
+                const int jj = i / (2 * (CB / 4)), r4 = i % (2 * (CB / 4)), gb = r4 / (CB / 4), c = c0 + (r4 % (CB / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < q.C) v = *reinterpret_cast<const float4*>(q.gtab + (((long long)b * 19 + jj) * 2 + gb) * q.C + c);
+                *reinterpret_cast<float4*>(gt + jj * RS + gb * CB + (r4 % (CB / 4)) * 4) = v;
+            }
+            if (threadIdx.x < CB) {
+                const int c = c0 + threadIdx.x;
+                pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
+                pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
+                pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
+            }
+            __syncthreads();
+            if (!wr) continue;
+            const float* g = gt + j * RS;
+#pragma unroll
+            for (int gq = 0; gq < IS_GPB; ++gq) {
+                const int c = c0 + gq * 8;
+                if (c >= q.C) break;
+                const float xv[8] = {xa[gq][0].x, xa[gq][0].y, xa[gq][0].z, xa[gq][0].w, xa[gq][1].x, xa[gq][1].y, xa[gq][1].z, xa[gq][1].w};
+                is_h8 vh, vl;
+                float am = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int cc = gq * 8 + e;
+                    const float nrm = pa[cc] * xv[e] + pn[cc] * nz + pd[cc];
+                    float o = nrm * (1.f + g[cc]) + g[CB + cc];
+                    o = fmaxf(o, slope * o) * osc;
+                    if (c + e >= q.C) o = 0.f;                 // padding channels of the last group hold zeros
+                    am = fmaxf(am, fabsf(o));
+                    if (q.bf16) {
+                        const __bf16 tb = (__bf16)o;
+                        vh[e] = __builtin_bit_cast(_Float16, tb);
+                        vl[e] = (_Float16)0.f;
+                    } else {
+                        const _Float16 h = (_Float16)o;
+                        vh[e] = h;
+                        vl[e] = (_Float16)(o - (float)h);
+                    }
+                }
+                if (mine) amax = fmaxf(amax, am);              // filler pixels are overwritten: they do not set the scale
+                const long long u = (long long)(c >> 3) * 2 * HW;
+                op[u] = __builtin_bit_cast(uint4, vh);
+                op[u + HW] = __builtin_bit_cast(uint4, vl);
+            }
+        }
+    }
+    if (q.pass == 0 && q.out_amax) sh16_block_slot_max(q.out_amax, amax);
+}
+
 hipError_t ace_interior_sh16(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU || !q.cnt || (q.C & 3)) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
+    if (q.impl == 0) {
+        const int ntile = q.B * ((q.W + 31) / 32) * ((q.H + 7) / 8);
+        hipLaunchKernelGGL(ace_interior_sh16_tile_kernel, dim3((unsigned)(ntile < 2048 ? ntile : 2048)), dim3(256), 0, s, q);
+        return hipGetLastError();
+    }
     const int nblk = q.B * ((HW + 255) / 256);
     hipLaunchKernelGGL(ace_interior_sh16_kernel, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), 0, s, q);
     return hipGetLastError();

@@ -853,6 +853,11 @@ struct Runner {
             ip.out_amax = m.amax_slots + 2 * a.index;
             ip.bf16 = m.terms == 2;
             ip.variant = m.use_sh16 ? (compact ? 1 : 0) : ((m.dbg & 65536) ? 1 : ((m.dbg & 1048576) ? 2 : 0));
+            // blocks of 32 x 8 pixels; mostly-interior blocks write every pixel (the conv below overwrites the boundary pixels).
+            // Exact-f32 pass: filling pays only where x is read at full size (measured, tools/interior_bench.hip).
+            // dbg bit 2097152: the row-shaped kernels of the first version (A/B)
+            ip.impl = (m.dbg & 2097152) ? 1 : 0;
+            ip.fill_min = m.use_sh16 ? 128 : (x_up ? 257 : 128);
             p.sp_list = (m.use_sh16 && !compact) ? nullptr : L.list;      // f16x3: the lists request the compacting kernel
             p.sp_cnt = L.cnt;
             p.sp_work = sw->work;
