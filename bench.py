@@ -155,8 +155,10 @@ class PipelineJob:
         from ctrlhair_amd.pipeline import EditPipeline
         S = args.size
         # throughput configuration: full run-ahead mode up to this batch (+1.6 % at 8 x 512^2 for 4.3 GB of per-ACE buffers)
-        self.pipe = EditPipeline(weights, device=dev.index, img_size=S, max_batch=B, f16x3=PATH_OPTION[path],
-                                 options={'sean.ahead': max(B, 2)})
+        opts = {'sean.ahead': max(B, 2)}
+        if args.dbg:
+            opts['sean.dbg'] = args.dbg
+        self.pipe = EditPipeline(weights, device=dev.index, img_size=S, max_batch=B, f16x3=PATH_OPTION[path], options=opts)
         self.img = torch.from_numpy(P.synthetic_images(B, S, seed=11 + rank * B)).to(dev)
         self.handle = self.pipe.models.generator.handle
         self.images = B

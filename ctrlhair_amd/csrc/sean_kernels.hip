@@ -199,8 +199,154 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_kernel(const uint8_t*
     }
 }
 
+// Persistent variant for the `need`-masked launches of the exact SPADE-interior reduction (tools/interior_bench.hip measures
+// both).  The kernel above stages its 25 KB table slice once per 256 pixels -- 22 KB of table reads for at most 32 KB of
+// output, and for far less where only the pixels next to a boundary are wanted.  Here a block keeps its slice in LDS and walks
+// over blocks of 32 x 8 pixels (grid-stride); a wave whose 2 x 32 pixels hold no wanted pixel moves on without a barrier.
+__global__ __launch_bounds__(256) void onehot_conv3x3_sh16_need_kernel(const uint8_t* __restrict__ lab,
+                                                                       const float* __restrict__ table,
+                                                                       const float* __restrict__ bias, uint4* __restrict__ out,
+                                                                       int B, int H, int W, int K, int relu, float scale, int bf16,
+                                                                       const uint8_t* __restrict__ need) {
+    constexpr int RS = OH_KC + 4, ZROW = 19 * 9;
+    sh16_mode_on();
+    __shared__ __attribute__((aligned(16))) float T[(ZROW + 1) * RS];
+    __shared__ __attribute__((aligned(16))) float U[19 * RS];          // U[j] = bias + T[j][0] + ... + T[j][8], added in tap order
+    __shared__ __attribute__((aligned(16))) float bs[OH_KC];
+    const int k0 = blockIdx.y * OH_KC;
+    for (int i = threadIdx.x; i < (ZROW + 1) * (OH_KC / 4); i += 256) {
+        const int jt = i / (OH_KC / 4), kk = (i % (OH_KC / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jt < ZROW) {
+            if (k0 + kk + 3 < K && (K & 3) == 0) {
+                v = *reinterpret_cast<const float4*>(table + (long long)jt * K + k0 + kk);
+            } else {
+                const float* tp = table + (long long)jt * K + k0 + kk;
+                v.x = k0 + kk < K ? tp[0] : 0.f; v.y = k0 + kk + 1 < K ? tp[1] : 0.f;
+                v.z = k0 + kk + 2 < K ? tp[2] : 0.f; v.w = k0 + kk + 3 < K ? tp[3] : 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(T + jt * RS + kk) = v;
+    }
+    if (threadIdx.x < OH_KC) bs[threadIdx.x] = (k0 + threadIdx.x < K) ? bias[k0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    // A pixel whose 3x3 neighbourhood is inside the image and holds one label j < 19 sums the nine rows of that label: the same
+    // adds in the same order are done once here, and a wave whose wanted pixels are all of that kind reads 2 x 16 bytes of LDS
+    // per 8 channels instead of 18 x 16 (the kernel is bound by its LDS reads).  Bit-identical by construction.
+    for (int i = threadIdx.x; i < 19 * OH_KC; i += 256) {
+        const int j = i / OH_KC, kk = i % OH_KC;
+        float a = bs[kk];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a += T[(j * 9 + t) * RS + kk];
+        U[j * RS + kk] = a;
+    }
+    __syncthreads();
+    // Blocks of 32 x 32 pixels.  The wanted pixels are thin bands (the 3-pixel neighbourhood of label boundaries): taken as they
+    // lie, nearly every wave of 64 consecutive pixels holds a few of them and runs the whole gather for 3 active lanes -- the
+    // masked launch then costs what the dense one does (measured: 495 vs 518 us at 512^2 with 18 % of the pixels wanted).  So the
+    // block first compacts its wanted pixels into an LDS list (four independent `need` loads per thread, ballot + one LDS atomic
+    // per wave), then walks the list with full waves.
+    __shared__ unsigned short plist[1024];
+    __shared__ int pcount;
+    if (threadIdx.x == 0) pcount = 0;
+    __syncthreads();
+    const int HW = H * W, tpr = (W + 31) >> 5, tpc = (H + 31) >> 5, ntile = B * tpr * tpc;
+    const int G = (K + 7) / 8, lane = threadIdx.x & 63;
+    for (int tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const int b = tl / (tpr * tpc), r = tl - b * (tpr * tpc), tyi = r / tpr;
+        const int x0 = (r - tyi * tpr) * 32, y0 = tyi * 32;
+        const uint8_t* lb = lab + (long long)b * HW;
+        bool wanted[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x0 + (threadIdx.x & 31), y = y0 + (threadIdx.x >> 5) + 8 * i;
+            wanted[i] = x < W && y < H && need[(long long)b * HW + y * W + x];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned long long m = __ballot(wanted[i]);
+            if (m == 0ull) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&pcount, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (wanted[i])
+                plist[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((((threadIdx.x >> 5) + 8 * i) << 5) | (threadIdx.x & 31));
+        }
+        __syncthreads();
+        const int n = pcount;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int pl = plist[e];
+            const int x = x0 + (pl & 31), y = y0 + (pl >> 5), pix = y * W + x;
+            int jt[9];
+            const int jc = lb[pix];
+            bool uni = jc < 19;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                const int j = lb[in ? yy * W + xx : 0];
+                jt[t] = (in && j < 19 ? j * 9 + t : ZROW) * RS;     // labels >= 19 ("no class"): all-zero one-hot
+                uni = uni && in && j == jc;
+            }
+            const bool fast = __ballot(!uni) == 0ull;              // (only lanes with a list entry are active)
+#pragma unroll
+            for (int gq = 0; gq < OH_KC / 8; ++gq) {
+                const int g = k0 / 8 + gq;
+                if (g >= G) break;
+                float4 a0, a1;
+                if (fast) {
+                    a0 = *reinterpret_cast<const float4*>(U + jc * RS + gq * 8);
+                    a1 = *reinterpret_cast<const float4*>(U + jc * RS + gq * 8 + 4);
+                } else {
+                    a0 = *reinterpret_cast<const float4*>(bs + gq * 8);
+                    a1 = *reinterpret_cast<const float4*>(bs + gq * 8 + 4);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {               // same summation order as the kernels above
+                        const float4* rr = reinterpret_cast<const float4*>(T + jt[t] + gq * 8);
+                        const float4 r0 = rr[0], r1 = rr[1];
+                        a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
+                        a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
+                    }
+                }
+                const float v8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                h8 vh, vl;
+#pragma unroll
+                for (int e2 = 0; e2 < 8; ++e2) {
+                    float v = v8[e2];
+                    if (relu) v = v > 0.f ? v : 0.f;
+                    if (k0 + gq * 8 + e2 >= K) v = 0.f;
+                    _Float16 h, l;
+                    sh16_split_any(v, scale, bf16, h, l);
+                    vh[e2] = h;
+                    vl[e2] = l;
+                }
+                const long long unit = (((long long)b * G + g) * 2) * HW + pix;
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, vh), reinterpret_cast<u32x4*>(out + unit));
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, vl), reinterpret_cast<u32x4*>(out + unit + HW));
+            }
+        }
+        __syncthreads();                                          // every wave has read the list
+        if (threadIdx.x == 0) pcount = 0;
+        // (the next iteration's atomics come after its own barrier-free ballot phase: order them behind the reset)
+        __syncthreads();
+    }
+}
+
+// 0 = compacting kernel where the wanted pixels are sparse (levels of 512^2 and up: at 256^2 and below most pixels of a
+// segmentation map are within 3 pixels of a boundary and the plain kernel is faster), 1 = never, 2 = always (A/B)
+int g_onehot_need_impl = 0;
+
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
                                int K, int relu, float scale, hipStream_t s, int bf16, const uint8_t* need, const int* tile_cnt) {
+    if (need && !tile_cnt && (g_onehot_need_impl == 0 ? W >= 512 : g_onehot_need_impl == 2)) {
+        const int ntile = B * ((W + 31) / 32) * ((H + 31) / 32), ky = (K + OH_KC - 1) / OH_KC;
+        int gx = 1280 / ky;                                   // 5 blocks of 28 KB LDS per CU
+        if (gx > ntile) gx = ntile;
+        hipLaunchKernelGGL(onehot_conv3x3_sh16_need_kernel, dim3((unsigned)gx, (unsigned)ky), dim3(256), 0, s, lab, table, bias,
+                           static_cast<uint4*>(out), B, H, W, K, relu, scale, bf16, need);
+        return hipGetLastError();
+    }
     const long long npix = (long long)B * H * W;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
     hipLaunchKernelGGL(onehot_conv3x3_sh16_kernel, grid, dim3(256), 0, s, lab, table, bias, static_cast<uint4*>(out), B, H,
