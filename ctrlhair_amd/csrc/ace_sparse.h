@@ -93,7 +93,8 @@ struct AceInteriorParams {
     unsigned* out_amax;
     int pass, bf16;
     const int* cnt;             // f16x3 path: boundary-pixel count per tile of 32 x 16 (tiles_x = ceil(W / 32))
-    int impl;                   // f16x3 kernel: 0 = blocks of 32 x 8 pixels (default), 1 = blocks of 256 consecutive pixels (A/B)
+    int impl;                   // 0 = blocks of 32 x 8 pixels (default), 1 = blocks of 256 consecutive pixels (first version, A/B),
+                                // 2 = exact-f32 kernel only: four pixels per thread, blocks of 128 x 8 (W >= 128)
     int fill_min;               // f16x3 kernel, variant 1: a block with at least this many interior pixels (of 256) writes ALL its
                                 // pixels -- the boundary conv, launched after this pass, overwrites the others; 0 = 128
     int variant;                // exact-f32 kernel: 0 = one pixel per thread (default), 1 = four pixels per thread (16-byte

@@ -346,11 +346,88 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
     }
 }
 
+// Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
+// values of a thread share their 32-byte sectors with the seven other rows of the block.
+__global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {
+    constexpr int RS = 2 * IN_CG + 1;
+    __shared__ float gt[19 * RS];
+    __shared__ float pa[IN_CG], pd[IN_CG], pn[IN_CG];
+    const int HW = q.H * q.W, tpr = (q.W + 127) >> 7, tpc = (q.H + 7) >> 3;
+    const int b = blockIdx.x / (tpr * tpc), r = blockIdx.x - b * (tpr * tpc), tyi = r / tpr, c0 = blockIdx.y * IN_CG;
+    const int x = (r - tyi * tpr) * 128 + (threadIdx.x & 31) * 4, y = tyi * 8 + (threadIdx.x >> 5);
+    const bool inimg = x < q.W && y < q.H;                   // W % 4 == 0: the four pixels are inside together
+    const int pix = y * q.W + x;
+    uchar4 j4 = make_uchar4(255, 255, 255, 255);
+    if (inimg) j4 = *reinterpret_cast<const uchar4*>(q.u5 + (long long)b * HW + pix);
+    const bool i0 = j4.x < 19, i1 = j4.y < 19, i2 = j4.z < 19, i3 = j4.w < 19;
+    const int nmine = __syncthreads_count(i0) + __syncthreads_count(i1) + __syncthreads_count(i2) + __syncthreads_count(i3);
+    if (nmine == 0) return;                                  // no interior pixel in this block
+    const bool fill = nmine >= 4 * (q.fill_min > 0 ? q.fill_min : 128);
+    const bool any = inimg && (fill || i0 || i1 || i2 || i3);
+    float nz0 = 0.f, nz1 = 0.f, nz2 = 0.f, nz3 = 0.f;
+    if (any) {
+        const float* np = q.noise + (long long)b * q.noise_bstride + (long long)x * q.H + y;      // plane layout [W][H]
+        nz0 = np[0]; nz1 = np[q.H]; nz2 = np[2 * q.H]; nz3 = np[3 * q.H];
+    }
+    for (int i = threadIdx.x; i < 19 * 2 * IN_CG; i += 256) {
+        const int jj = i / (2 * IN_CG), rr = i % (2 * IN_CG), gb = rr / IN_CG, c = c0 + rr % IN_CG;
+        gt[jj * RS + rr] = c < q.C ? q.gtab[(((long long)b * 19 + jj) * 2 + gb) * q.C + c] : 0.f;
+    }
+    if (threadIdx.x < IN_CG) {
+        const int c = c0 + threadIdx.x;
+        pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
+        pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
+        pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
+    }
+    __syncthreads();
+    if (!any) return;
+    const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up);
+    const float* __restrict__ xp = q.x + ((long long)b * q.C + c0) * xHW + (y >> q.x_up) * xW + (x >> q.x_up);
+    float* __restrict__ op = reinterpret_cast<float*>(q.out) + ((long long)b * q.C + c0) * HW + pix;
+    const float *g0 = gt + (i0 ? j4.x : 0) * RS, *g1 = gt + (i1 ? j4.y : 0) * RS, *g2 = gt + (i2 ? j4.z : 0) * RS,
+                *g3 = gt + (i3 ? j4.w : 0) * RS;
+    const int cmax = q.C - c0 < IN_CG ? q.C - c0 : IN_CG;
+    const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
+    const bool all4 = fill || (i0 && i1 && i2 && i3);
+#pragma unroll 4
+    for (int c = 0; c < cmax; ++c) {
+        float4 xv;
+        if (q.x_up) {
+            const float2 t = *reinterpret_cast<const float2*>(xp + (long long)c * xHW);
+            xv = make_float4(t.x, t.x, t.y, t.y);
+        } else {
+            xv = *reinterpret_cast<const float4*>(xp + (long long)c * xHW);
+        }
+        const float a = pa[c], n = pn[c], d = pd[c];
+        float4 o;
+        o.x = (a * xv.x + n * nz0 + d) * (1.f + g0[c]) + g0[IN_CG + c];
+        o.y = (a * xv.y + n * nz1 + d) * (1.f + g1[c]) + g1[IN_CG + c];
+        o.z = (a * xv.z + n * nz2 + d) * (1.f + g2[c]) + g2[IN_CG + c];
+        o.w = (a * xv.w + n * nz3 + d) * (1.f + g3[c]) + g3[IN_CG + c];
+        o.x = fmaxf(o.x, slope * o.x); o.y = fmaxf(o.y, slope * o.y);
+        o.z = fmaxf(o.z, slope * o.z); o.w = fmaxf(o.w, slope * o.w);
+        float* oc = op + (long long)c * HW;
+        if (all4) {
+            *reinterpret_cast<float4*>(oc) = o;
+        } else {
+            if (i0) oc[0] = o.x;
+            if (i1) oc[1] = o.y;
+            if (i2) oc[2] = o.z;
+            if (i3) oc[3] = o.w;
+        }
+    }
+}
+
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU) return hipErrorInvalidValue;
     if (q.W % 4 != 0) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
-    if (q.impl == 0) {
+    if (q.impl == 2 && q.W >= 128) {
+        dim3 gridt((unsigned)(q.B * ((q.W + 127) / 128) * ((q.H + 7) / 8)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
+        hipLaunchKernelGGL(ace_interior_f32_tile4_kernel, gridt, dim3(256), 0, s, q);
+        return hipGetLastError();
+    }
+    if (q.impl == 0 || q.impl == 2) {
         dim3 gridt((unsigned)(q.B * ((q.W + 31) / 32) * ((q.H + 7) / 8)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_tile_kernel, gridt, dim3(256), 0, s, q);
         return hipGetLastError();

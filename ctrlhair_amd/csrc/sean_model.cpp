@@ -858,6 +858,12 @@ struct Runner {
             // dbg bit 2097152: the row-shaped kernels of the first version (A/B)
             ip.impl = (m.dbg & 2097152) ? 1 : 0;
             ip.fill_min = m.use_sh16 ? 128 : (x_up ? 257 : 128);
+            // (impl 2, four pixels per thread: 10 % ahead at 512^2 in tools/interior_bench.hip, no difference in the generator
+            // step -- 159.7 vs 159.9 images/s -- so the one-pixel kernel stays; dbg bit 16777216 selects it)
+            if (!m.use_sh16 && (m.dbg & 16777216) && r >= 128) {
+                ip.impl = 2;
+                ip.fill_min = 128;
+            }
             p.sp_list = (m.use_sh16 && !compact) ? nullptr : L.list;      // f16x3: the lists request the compacting kernel
             p.sp_cnt = L.cnt;
             p.sp_work = sw->work;

@@ -130,11 +130,21 @@ int main(int argc, char** argv) {
                             if (u5[(size_t)b * HW + p] < 19) bad += r32[((size_t)b * C + ch) * HW + p] != g32[((size_t)b * C + ch) * HW + p];
                 printf("  f32 check fill_min=%3d: %zu mismatching words on interior pixels\n", fm, bad);
             }
-            const char* n32[] = {"f32 rows (old)   ", "f32 tiles masked ", "f32 tiles fill128", "f32 tiles fill 64"};
-            for (int which = 0; which < 4; ++which) {
+            for (int fm : {257, 1}) {
+                CK(hipMemset(d_out, 0, nout * 4));
+                q.impl = 2; q.fill_min = fm; CK(ace_interior_f32(q, 0)); CK(hipMemcpy(g32.data(), d_out, nout * 4, hipMemcpyDeviceToHost));
+                size_t bad = 0;
+                for (int b = 0; b < B; ++b)
+                    for (int ch = 0; ch < C; ++ch)
+                        for (int p = 0; p < HW; ++p)
+                            if (u5[(size_t)b * HW + p] < 19) bad += r32[((size_t)b * C + ch) * HW + p] != g32[((size_t)b * C + ch) * HW + p];
+                printf("  f32 tile4 check fill_min=%3d: %zu mismatching words on interior pixels\n", fm, bad);
+            }
+            const char* n32[] = {"f32 rows (old)   ", "f32 tiles masked ", "f32 tiles fill128", "f32 tile4 masked ", "f32 tile4 fill128", "f32 tile4 fill 64"};
+            for (int which = 0; which < 6; ++which) {
                 float best = 1e9f;
-                q.impl = which == 0 ? 1 : 0;
-                q.fill_min = which == 1 ? 257 : (which == 2 ? 128 : 64);
+                q.impl = which == 0 ? 1 : (which < 3 ? 0 : 2);
+                q.fill_min = (which == 1 || which == 3) ? 257 : (which == 5 ? 64 : 128);
                 for (int it = 0; it < 6; ++it) {
                     CK(hipEventRecord(e0, 0));
                     CK(ace_interior_f32(q, 0));
