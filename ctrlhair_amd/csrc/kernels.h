@@ -11,7 +11,9 @@ hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* b
 // `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
                                int K, int relu, float scale, hipStream_t s, int bf16 = 0, const uint8_t* need = nullptr,
-                               const int* tile_cnt = nullptr);   // tile_cnt: boundary pixels per tile of 32 x 16 (tile-skip mode)
+                               const int* tile_cnt = nullptr,    // tile_cnt: boundary pixels per tile of 32 x 16 (tile-skip mode)
+                               int need_impl = 0);               // need-masked launches: 0 = compacting kernel at W >= 512,
+                                                                 // 1 = never, 2 = always (A/B, tools/onehot_bench.hip)
 // amax: device slot of a dynamically scaled tensor (sh16.h), null = static scale
 hipError_t sh16_decode(const void* in, float* out, int B, int C, long long HW, float scale, const unsigned* amax,
                        hipStream_t s, int bf16 = 0);

@@ -333,13 +333,12 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_sh16_need_kernel(const uin
     }
 }
 
-// 0 = compacting kernel where the wanted pixels are sparse (levels of 512^2 and up: at 256^2 and below most pixels of a
-// segmentation map are within 3 pixels of a boundary and the plain kernel is faster), 1 = never, 2 = always (A/B)
-int g_onehot_need_impl = 0;
-
+// need_impl 0: the compacting kernel where the wanted pixels are sparse (levels of 512^2 and up: at 256^2 and below most pixels
+// of a segmentation map are within 3 pixels of a boundary and the plain kernel is faster), 1 = never, 2 = always (A/B)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
-                               int K, int relu, float scale, hipStream_t s, int bf16, const uint8_t* need, const int* tile_cnt) {
-    if (need && !tile_cnt && (g_onehot_need_impl == 0 ? W >= 512 : g_onehot_need_impl == 2)) {
+                               int K, int relu, float scale, hipStream_t s, int bf16, const uint8_t* need, const int* tile_cnt,
+                               int need_impl) {
+    if (need && !tile_cnt && (need_impl == 0 ? W >= 512 : need_impl == 2)) {
         const int ntile = B * ((W + 31) / 32) * ((H + 31) / 32), ky = (K + OH_KC - 1) / OH_KC;
         int gx = 1280 / ky;                                   // 5 blocks of 28 KB LDS per CU
         if (gx > ntile) gx = ntile;

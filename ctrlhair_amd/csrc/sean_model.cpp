@@ -722,7 +722,8 @@ struct Runner {
         }
         if (!(what & 2)) return q;
         if (m.use_sh16)
-            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2, need, tile_cnt), "mlp_shared");
+            check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2, need, tile_cnt,
+                                      (m.dbg & 33554432) ? 1 : 0), "mlp_shared");
         else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, need), "mlp_shared");
         return q;

@@ -117,3 +117,24 @@ def test_executed_flops_accounting(hip_lib, path):
     else:                   # tile granularity (tiles of 32 x 16 without any boundary pixel are skipped)
         assert frac['one_region'] < 0.95 and frac['face'] <= frac['diag'] + 1e-9      # (a 128-pixel face has no boundary-free tile)
     gen.handle.close()
+
+
+@pytest.mark.parametrize('path', ['f32', 'f16x3'])
+def test_interior_and_label_table_kernels_match_their_first_versions(hip_lib, path):
+    """The interior pass on blocks of 32 x 8 pixels (mostly-interior blocks write every pixel, the boundary conv overwrites the
+    rest) and the compacting label-table kernel of the 512^2 level against the row-shaped kernels they replaced (sean.dbg bits
+    2097152 / 33554432): the same arithmetic in the same order, so the images must be bit-identical."""
+    from ctrlhair_amd import procedural as P
+    ngf, S, B = 16, 512, 2
+    sd = P.sean_state_dict(0, ngf)
+    codes, noise = P.style_codes(B), P.noise_planes(B, S, ngf)
+    new = _gen(sd, B, S, path, 1)
+    old = _gen(sd, B, S, path, 1)
+    old.handle.set_option('sean.dbg', (64 if path == 'f16x3' else 0) | 2097152 | 33554432)
+    sets = _label_sets(B, S)
+    for name in ('face', 'blocky', 'noclass', 'stripes5'):
+        a, b = _run(new, sets[name], codes, noise), _run(old, sets[name], codes, noise)
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
+    new.handle.close()
+    old.handle.close()

@@ -36,10 +36,10 @@ int main() {
         CK(hipMalloc(&d_out, nout * 4));
         std::vector<uint32_t> ref(nout), got(nout);
         CK(hipMemset(d_out, 0, nout * 4));
-        g_onehot_need_impl = 1; CK(onehot_conv3x3_sh16(d_lab, d_tab, d_bias, d_out, B, H, W, K, 1, 64.f, 0, 0, d_need, nullptr));
+        CK(onehot_conv3x3_sh16(d_lab, d_tab, d_bias, d_out, B, H, W, K, 1, 64.f, 0, 0, d_need, nullptr, 1));
         CK(hipMemcpy(ref.data(), d_out, nout * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(d_out, 0, nout * 4));
-        g_onehot_need_impl = 2; CK(onehot_conv3x3_sh16(d_lab, d_tab, d_bias, d_out, B, H, W, K, 1, 64.f, 0, 0, d_need, nullptr));
+        CK(onehot_conv3x3_sh16(d_lab, d_tab, d_bias, d_out, B, H, W, K, 1, 64.f, 0, 0, d_need, nullptr, 2));
         CK(hipMemcpy(got.data(), d_out, nout * 4, hipMemcpyDeviceToHost));
         size_t bad = 0;
         for (size_t i = 0; i < nout; ++i) bad += ref[i] != got[i];
@@ -47,10 +47,9 @@ int main() {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int which = 0; which < 3; ++which) {
             float best = 1e9f;
-            g_onehot_need_impl = which == 0 ? 1 : 2;
             for (int it = 0; it < 6; ++it) {
                 CK(hipEventRecord(e0, 0));
-                CK(onehot_conv3x3_sh16(d_lab, d_tab, d_bias, d_out, B, H, W, K, 1, 64.f, 0, 0, which == 2 ? nullptr : d_need, nullptr));
+                CK(onehot_conv3x3_sh16(d_lab, d_tab, d_bias, d_out, B, H, W, K, 1, 64.f, 0, 0, which == 2 ? nullptr : d_need, nullptr, which == 0 ? 1 : 2));
                 CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 if (it > 0 && ms < best) best = ms;
