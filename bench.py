@@ -120,6 +120,8 @@ class GeneratorJob:
             opts['sean.ahead'] = args.ahead
         if args.sparse_th:
             opts['sean.sparse_th'] = args.sparse_th
+        if args.compact is not None:
+            opts['sean.sh16_compact'] = args.compact
         if args.dbg:
             opts['sean.dbg'] = args.dbg          # (some experiment bits act at ch_finalize)
         self.gen = SeanGenerator(dev.index, f16x3=PATH_OPTION[path], options=opts).load_state_dict(sd, max_batch=B, max_size=S)
@@ -158,6 +160,8 @@ class PipelineJob:
         opts = {'sean.ahead': max(B, 2)}
         if args.dbg:
             opts['sean.dbg'] = args.dbg
+        if args.compact is not None:
+            opts['sean.sh16_compact'] = args.compact
         self.pipe = EditPipeline(weights, device=dev.index, img_size=S, max_batch=B, f16x3=PATH_OPTION[path], options=opts)
         self.img = torch.from_numpy(P.synthetic_images(B, S, seed=11 + rank * B)).to(dev)
         self.handle = self.pipe.models.generator.handle
@@ -367,6 +371,7 @@ def main():
     ap.add_argument('--ahead', type=int, default=-1, help=argparse.SUPPRESS)       # option sean.ahead (experiments)
     ap.add_argument('--sparse', type=int, default=1, help='0: every pixel through the SPADE convs (no interior reduction)')
     ap.add_argument('--sparse-th', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--compact', type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--sync-gather', action='store_true',
                     help='N > 1: all-gather each step on the compute stream instead of overlapping it with the next step')
     ap.add_argument('--force-dist', action='store_true', help='1-rank process group: exercises the RCCL code path on one GPU')

@@ -82,25 +82,30 @@ hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t
 // mode 0: block tasks of conv_ace_sparse_kernel (entry = tile | block task << 20); mode 1: tile-skip mode of the f16x3
 // wave-specialised kernel -- one entry (tile | row tile << 20) per row tile of every spatial tile with a boundary pixel, the
 // tile's 512 pixels all go through the conv (statistics count them as such); mode 2: the same entries for the compacting
-// variant of that kernel (statistics count the boundary pixels / their 32-pixel sub-tiles)
+// variant of that kernel (statistics count the boundary pixels / their 32-pixel sub-tiles); mode 3: as 2, but a spatial tile
+// with at most four sub-tiles gets one entry per PAIR of row tiles, in the second list `work2` (row-tile field = pair index:
+// conv_sh16_ws_kernel<..., CP = 2>)
 __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restrict__ cnt, int ntiles, int mtiles, int mode, int tile_px,
-                                                            unsigned* __restrict__ work, int* __restrict__ total) {
-    __shared__ int wsum[16];
-    __shared__ int carry;
+                                                            unsigned* __restrict__ work, int* __restrict__ total,
+                                                            unsigned* __restrict__ work2, int* __restrict__ total2) {
+    __shared__ int wsum[16], wsum2[16];
+    __shared__ int carry, carry2;
     __shared__ int stat[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
+    if (tid == 0) carry = carry2 = 0;
     if (tid < 3) stat[tid] = 0;
     __syncthreads();
     int s_px = 0, s_sub = 0, s_ws = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 1024) {
         const int tile = t0 + tid;
-        int nbt = 0;
+        int nbt = 0, nbp = 0;                          // entries of this tile in `work` / in `work2` (pair entries, mode 3)
         if (tile < ntiles) {
             int c = cnt[tile];
             if (mode == 1 && c > 0) c = tile_px;
             const int NS = (c + 31) >> 5;
-            if (mode >= 1) {           // mode 2: the same entries, but the conv only runs over the compacted boundary pixels
+            if (mode == 3 && NS >= 1 && NS <= 4) {      // one entry per pair of row tiles (conv_sh16_ws_kernel<..., CP = 2>)
+                nbp = (mtiles + 1) >> 1;
+            } else if (mode >= 1) {    // mode 2 / 3: the same entries, but the conv only runs over the compacted boundary pixels
                 nbt = c > 0 ? mtiles : 0;
             } else {
                 int ng, per;
@@ -111,20 +116,21 @@ __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restric
             s_sub += NS;
             s_ws += NS * mtiles;
         }
-        int v = nbt;                                   // inclusive scan inside the wave
+        int v = nbt, vp = nbp;                         // inclusive scans inside the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int u = __shfl_up(v, off, 64);
-            if (lane >= off) v += u;
+            const int u = __shfl_up(v, off, 64), up = __shfl_up(vp, off, 64);
+            if (lane >= off) { v += u; vp += up; }
         }
-        if (lane == 63) wsum[wave] = v;
+        if (lane == 63) { wsum[wave] = v; wsum2[wave] = vp; }
         __syncthreads();
-        int base = carry;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        const int excl = base + v - nbt;
+        int base = carry, base2 = carry2;
+        for (int w = 0; w < wave; ++w) { base += wsum[w]; base2 += wsum2[w]; }
+        const int excl = base + v - nbt, excl2 = base2 + vp - nbp;
         for (int i = 0; i < nbt; ++i) work[excl + i] = (unsigned)tile | ((unsigned)i << 20);
+        for (int i = 0; i < nbp; ++i) work2[excl2 + i] = (unsigned)tile | ((unsigned)i << 20);
         __syncthreads();
-        if (tid == 1023) carry = base + v;
+        if (tid == 1023) { carry = base + v; carry2 = base2 + vp; }
         __syncthreads();
     }
     atomicAdd(&stat[0], s_px);
@@ -136,12 +142,15 @@ __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restric
         total[1] = stat[0];
         total[2] = stat[1];
         total[3] = stat[2];
+        if (total2) total2[0] = carry2;
     }
 }
 
-hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s, int mode, int tile_px) {
+hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s, int mode, int tile_px,
+                        unsigned* work2, int* total2) {
     if (ntiles >= (1 << 20) || mtiles >= (1 << 12)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ace_worklist_kernel, dim3(1), dim3(1024), 0, s, cnt, ntiles, mtiles, mode, tile_px, work, total);
+    if (mode == 3 && !(work2 && total2)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ace_worklist_kernel, dim3(1), dim3(1024), 0, s, cnt, ntiles, mtiles, mode, tile_px, work, total, work2, total2);
     return hipGetLastError();
 }
 

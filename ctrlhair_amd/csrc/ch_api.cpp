@@ -349,7 +349,7 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
     }
     if (std::strcmp(key, "sean.sh16_compact") == 0) {   // f16x3 path: pixel-level compaction (1) or tile skipping only (0)
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.sh16_compact) must precede ch_finalize");
-        h->sean.sh16_compact = value != 0;
+        h->sean.sh16_compact = value < 0 ? 0 : (value > 2 ? 2 : value);    // 2: without pair entries (A/B)
         return CH_OK;
     }
     if (std::strcmp(key, "sean.sparse_th") == 0) {  // tile height of the compaction: 8 / 16, 0 = chosen per layer

@@ -99,6 +99,8 @@ struct ConvParams {
     const int* sp_cnt;
     const unsigned* sp_work;
     const int* sp_total;
+    const unsigned* sp_work2;   // f16x3 compacting kernel: second list (pair entries, ace_worklist mode 3) or null
+    const int* sp_total2;
     // EPI_NHWC
     int npix_valid;         // number of valid linear pixels (y*W+x < npix_valid)
 };

@@ -301,7 +301,7 @@ __device__ __forceinline__ void sh16_epilogue(const ConvParams& p, f32x16 (&acc)
         }
         // Addressing: wave-uniform 64-bit bases (sample b0) + 32-bit per-lane byte offsets.
         const float osc = p.out_scale != 0.f ? p.out_scale : 1.f, slope = act_slope(p.act);
-        const float st = (p.wscale ? p.wscale[mtile64 * 64] : 1.f) * (p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f) * osc;
+        const float st = (p.wscale ? p.wscale[(mtile64 < p.mtiles ? mtile64 : 0) * 64] : 1.f) * (p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f) * osc;
         const float extra = p.pass == 1 ? sh16_dyn_extra(*p.out_amax) : 1.f;
         float amax = 0.f;
         const int xHW = xW * xH;
@@ -733,7 +733,7 @@ typedef __attribute__((address_space(1))) const void glb_void;
 // (double-buffered, staged by the loaders), a consumer wave takes the 32-pixel sub-tiles wn, wn + 4, ... and reads its B fragments
 // at the patch offsets of ITS pixels.  Operand delivery (76 KB per chunk at ~12 B/cycle/CU) then bounds a sparse tile's k-loop,
 // not the MFMAs; the epilogue shrinks with the pixel count.
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool CP = false>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, int CP = 0>      // CP: 0 / 1 compacting / 2 compacting, pair entries
 __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p) {
     static_assert(!CP || (EPI == EPI_ACE && KS == 3 && TW == 32 && TH == 16 && TB == 1), "CP: the ACE kernel's 32x16 tiles only");
     using Cfg = ShCfg<KS, TW, TH, TB>;
@@ -747,7 +747,9 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     // per lane, no VGPR round trip), so the consumers' MFMA stream never waits on an L2 round trip.
     constexpr int AUNITS = NT * 4 * 64, STAGE = UNITS + AUNITS;
     constexpr int NPAR = 5;                                  // float4 per channel run: s(1+bias_g), s*bias_b, bn_a, bn_d, nv
-    constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + 8 * NPAR, LAB0 = NZ0 + 128;
+    constexpr bool PAIR = CP == 2;
+    constexpr int NRUN = PAIR ? 16 : 8;                      // pair entries: the parameters of two 64-row tiles
+    constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + NRUN * NPAR, LAB0 = NZ0 + 128;
     [[maybe_unused]] constexpr int LIST0 = LAB0 + (TB * (TH + 2) * (TW + 2) + 15) / 16, META0 = LIST0 + 128;   // CP: 2 x 1 KB lists, 2 x count
     constexpr int NDA = AUNITS / 256;                        // A DMA instructions per loader thread per chunk
     constexpr int LW = TW + 2, LH = TH + 2;
@@ -778,6 +780,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         if (sp) {
             const unsigned wk = p.sp_work[L];
             mtile64 = (int)(wk >> 20);
+            if (PAIR) mtile64 *= 2;                               // pair entry: first of the two row tiles
             nt = (int)(wk & 0xFFFFFu);
         } else {
             mtile64 = L % p.mtiles;
@@ -788,6 +791,11 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         x0 = txi * TW; y0 = tyi * TH; b0 = nt * TB;
     };
 
+    // CP == 2, pair entries (ace_worklist mode 3: spatial tiles with at most four 32-pixel sub-tiles of boundary pixels): one
+    // iteration serves TWO row tiles of the spatial tile.  Waves 0-1 own row tile 2m, waves 2-3 row tile 2m + 1, each wave at
+    // most two sub-tiles, and every wave streams the A fragments of ITS row tile from L2 straight into registers (kloop_direct)
+    // -- nothing goes through the loaders' A DMA, whose issue -> land -> barrier chain (~4.5 k cycles per chunk) bounded these
+    // tiles at one sub-tile (1.7 k cycles of MFMA) per wave; the staged patch now feeds twice the rows.
     if (loader) {
         if constexpr (CP) {
             // ------------------------------------------------------------ loaders of the compacting kernel: split roles
@@ -808,6 +816,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                         tile_coords(kq, dma_mt, x0, y0, b0);
                         dma_k = kq;
                     }
+                    if constexpr (PAIR) return;                         // the consumers read the A fragments themselves
                     const uint4* src = gA + ((long long)dma_mt * p.nchunks + q % p.nchunks) * AUNITS + ht;
                     uint4* dst = smem_u + (q & 1) * STAGE + UNITS + lw * 64;
 #pragma unroll
@@ -823,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     int mt, x0, y0, b0;
                     tile_coords(k, mt, x0, y0, b0);
                     const int C = p.C;
-                    if (ht < 8 * NPAR) {
+                    if (ht < NRUN * NPAR) {                                  // (runs 8..15: the second row tile of a pair entry)
                         const int run = ht / NPAR, which = ht % NPAR;
                         const int c0 = (mt * 8 + run) * 4;
                         const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
@@ -854,7 +863,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     }
                 };
                 auto small_store = [&]() {
-                    if (ht < 8 * NPAR) reinterpret_cast<float4*>(smem_u + PAR0)[ht] = parr;
+                    if (ht < NRUN * NPAR) reinterpret_cast<float4*>(smem_u + PAR0)[ht] = parr;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) reinterpret_cast<float*>(smem_u + NZ0)[ht + i * 128] = nzr[i];
                     if (p.lut) {
@@ -1156,23 +1165,28 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         if (stamp && k < 64) stamps[k * 3] = __builtin_amdgcn_s_memtime();
         [[maybe_unused]] int nsub = 4, cnt = 0;               // CP: this wave's sub-tiles wn, wn + 4, ... of the tile's compacted pixels
         [[maybe_unused]] const uint16_t* lst = nullptr;
+        constexpr int sst = PAIR ? 2 : 4;                     // CP: this wave's sub-tiles are sw0, sw0 + sst, ...
+        [[maybe_unused]] const int sw0 = PAIR ? (wn & 1) : wn;
         if constexpr (CP) {
             cnt = reinterpret_cast<const int*>(smem_u + META0)[k & 1];
             lst = reinterpret_cast<const uint16_t*>(smem_u + LIST0 + (k & 1) * 64);
             const int NS = (cnt + 31) >> 5;
-            nsub = NS > wn ? (NS - wn + 3) >> 2 : 0;
+            if constexpr (PAIR) mtile64 += wn >> 1;
+            nsub = NS > sw0 ? (NS - sw0 + sst - 1) / sst : 0;
+            if (PAIR && mtile64 >= p.mtiles) nsub = 0;        // odd number of row tiles: the last pair is half empty
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int slot = (wn + 4 * n) * 32 + (lane & 31);
+                const int slot = (sw0 + sst * n) * 32 + (lane & 31);
                 const int idx = lst[slot < cnt ? slot : cnt - 1];     // slots beyond the count repeat the last boundary pixel
                 ub[n] = (lane >> 5) * 2 * PLANE + (idx >> 5) * PW + (idx & 31);
             }
         }
-        f32x16 acc[2][4];
+        constexpr int NACC = PAIR ? 2 : 4;                    // sub-tiles a wave accumulates
+        f32x16 acc[2][NACC];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < NACC; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
         // CP, at most two sub-tiles: plain double-buffered k-step (the hand-ordered one below is written for four sub-tiles)
@@ -1226,12 +1240,80 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                 __syncthreads();
             }
         };
+        // pair entries: A fragments of this wave's row tile straight from L2, four to six taps ahead in a 9-slot register ring (the
+        // stream does not depend on the chunk barriers); B fragments from the staged patch as above
+        auto kloop_direct = [&](auto ns_) {
+            constexpr int NS_ = decltype(ns_)::value;
+            constexpr int PD = NS_ <= 1 ? 6 : 4;               // taps of lead: one sub-tile is ~200 cycles of MFMA per tap, an L2 trip ~1.5 k
+            const uint4* ga = reinterpret_cast<const uint4*>(p.wpk) + (long long)mtile64 * p.nchunks * AUNITS + lane;
+            uint4 ar[NT][4];
+            if constexpr (NS_ > 0) {
+#pragma unroll
+                for (int d = 0; d < PD; ++d)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ar[d][i] = ga[(d * 4 + i) * 64];
+            }
+            for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
+                if constexpr (NS_ > 0) {
+                    const uint4* sb = smem_u + (q & 1) * STAGE;
+                    const uint4* gc = ga + (long long)ch * AUNITS;
+                    const bool more = ch + 1 < p.nchunks;
+                    uint4 bh_c[NS_], bl_c[NS_];
+#pragma unroll
+                    for (int n = 0; n < NS_; ++n) {
+                        bh_c[n] = sb[ub[n]];
+                        bl_c[n] = sb[ub[n] + PLANE];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (t + PD < NT) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) ar[t + PD][i] = gc[((t + PD) * 4 + i) * 64];
+                        } else if (more) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) ar[t + PD - NT][i] = gc[AUNITS + ((t + PD - NT) * 4 + i) * 64];
+                        }
+                        uint4 bh_n[NS_], bl_n[NS_];
+#pragma unroll
+                        for (int n = 0; n < NS_; ++n) { bh_n[n] = bh_c[n]; bl_n[n] = bl_c[n]; }
+                        if (t + 1 < NT) {
+                            const int knxt = ((t + 1) / KS) * PW + ((t + 1) % KS);
+#pragma unroll
+                            for (int n = 0; n < NS_; ++n) {
+                                bh_n[n] = sb[ub[n] + knxt];
+                                bl_n[n] = sb[ub[n] + knxt + PLANE];
+                            }
+                        }
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < NS_; ++n) {
+                                if (TERMS == 3) {
+                                    acc[m][n] = mfma16<TERMS>(ar[t][m * 2 + 1], bh_c[n], acc[m][n]);
+                                    acc[m][n] = mfma16<TERMS>(ar[t][m * 2 + 0], bl_c[n], acc[m][n]);
+                                }
+                                acc[m][n] = mfma16<TERMS>(ar[t][m * 2 + 0], bh_c[n], acc[m][n]);
+                            }
+#pragma unroll
+                        for (int n = 0; n < NS_; ++n) { bh_c[n] = bh_n[n]; bl_c[n] = bl_n[n]; }
+                    }
+                }
+                __syncthreads();
+            }
+        };
         bool small_done = false;
         if constexpr (CP) {
+            if constexpr (PAIR) {
+                if (nsub == 0) kloop_direct(std::integral_constant<int, 0>{});
+                else if (nsub == 1) kloop_direct(std::integral_constant<int, 1>{});
+                else kloop_direct(std::integral_constant<int, 2>{});
+                small_done = true;
+            } else
             if (nsub == 0) { kloop_small(std::integral_constant<int, 0>{}); small_done = true; }
             else if (nsub == 1) { kloop_small(std::integral_constant<int, 1>{}); small_done = true; }
             else if (nsub == 2) { kloop_small(std::integral_constant<int, 2>{}); small_done = true; }
         }
+        if constexpr (!PAIR) {
         if (!small_done)
         for (int ch = 0; ch < p.nchunks; ++ch, ++q) {
             const uint4* sb = smem_u + (q & 1) * STAGE;
@@ -1290,6 +1372,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             }
             __syncthreads();
         }
+        }
         // after the last chunk's barrier the consumers no longer touch LDS: the loaders go on staging the next tile
         // while the epilogue runs
         if (stamp && k < 64) stamps[k * 3 + 1] = __builtin_amdgcn_s_memtime();
@@ -1302,11 +1385,11 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             const int hi = lane >> 5, col = lane & 31;
             const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
             const char* xbase = reinterpret_cast<const char*>(p.x) + (long long)b0 * (C >> 2) * xHW * 16;
-            const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0);
+            const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0) + (PAIR ? (wn >> 1) * 8 * NPAR : 0);
             const float* nzs = reinterpret_cast<const float*>(smem_u + NZ0);
             const uint8_t* labs8 = reinterpret_cast<const uint8_t*>(smem_u + LAB0);
             const float slope = act_slope(p.act);
-            const float st = (p.wscale ? p.wscale[mtile64 * 64] : 1.f) * (p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f) *
+            const float st = (p.wscale ? p.wscale[(mtile64 < p.mtiles ? mtile64 : 0) * 64] : 1.f) * (p.in_scale_inv != 0.f ? p.in_scale_inv : 1.f) *
                              (p.out_scale != 0.f ? p.out_scale : 1.f);
             char* obase = reinterpret_cast<char*>(p.out) + (long long)b0 * Go * 2 * HW * 16;
             const unsigned lrs = (unsigned)p.lut_rs * 4u, lns = (unsigned)p.lut_ns * 4u;
@@ -1315,10 +1398,10 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             auto body = [&](auto resc) {
                 constexpr bool RESC = decltype(resc)::value;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
+                for (int n = 0; n < NACC; ++n) {
                     int idx = wn * 128 + n * 32 + col;
                     if constexpr (CP) {                              // this lane's compacted boundary pixel of sub-tile wn + 4 n
-                        const int slot = (wn + 4 * n) * 32 + col;
+                        const int slot = (sw0 + sst * n) * 32 + col;
                         if (n >= nsub || slot >= cnt) continue;
                         idx = lst[slot];
                     }
@@ -1383,7 +1466,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     }
 }
 
-template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, bool CP = false>
+template <int KS, int TW, int TH, int TB, int EPI, int TERMS = 3, int CP = 0>
 hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     using Cfg = ShCfg<KS, TW, TH, TB>;
     if (p.in_mode != IN_DIRECT) return hipErrorInvalidValue;     // input views are implemented in conv_sh16_kernel only
@@ -1391,7 +1474,7 @@ hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS, CP>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
-    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16 + (CP ? 129 * 16 : 0)
+    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16 + (CP ? (129 + (CP == 2 ? 40 : 0)) * 16 : 0)
                                           : 2 * V3_STAGE * 16;
     // per device: a process may own handles on several GPUs (ch_api.cpp DeviceGuard)
     static bool attr_set[64] = {};
@@ -1541,7 +1624,14 @@ hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
     const bool ws_ok = p.W >= 32 && p.Cin >= 48;
     if (ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512))) {
         if constexpr (TERMS == 3) {        // pixel-level compaction when the caller passes the per-tile lists (sean_model.cpp)
-            if (p.sp_work && p.sp_list) return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, true>(p, rows, s);
+            if (p.sp_work && p.sp_list) {
+                hipError_t e = launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, 1>(p, rows, s);
+                if (e != hipSuccess || !p.sp_work2) return e;
+                ConvParams p2 = p;                                // the tiles with at most four sub-tiles: two row tiles per entry
+                p2.sp_work = p.sp_work2;
+                p2.sp_total = p.sp_total2;
+                return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, 2>(p2, rows, s);
+            }
         }
         return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS>(p, rows, s);
     }

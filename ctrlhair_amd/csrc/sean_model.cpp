@@ -501,10 +501,14 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     SparseWork w;
                     w.mtiles = mt;
                     w.TH = L.TH;
-                    w.mode = use_sh16 ? ((sh16_compact && terms == 3) ? 2 : 1) : 0;
+                    w.mode = use_sh16 ? ((sh16_compact && terms == 3) ? (sh16_compact >= 2 ? 2 : 3) : 1) : 0;   // 3: with pair entries
                     w.cap = (long long)L.cap_tiles * (use_sh16 ? mt : sparse_max_tasks(L.TH, mt));
                     w.work = static_cast<unsigned*>(B.dalloc((size_t)w.cap * sizeof(unsigned)));
                     w.total = static_cast<int*>(B.dalloc(4 * sizeof(int)));
+                    if (w.mode == 3) {
+                        w.work2 = static_cast<unsigned*>(B.dalloc((size_t)L.cap_tiles * ((mt + 1) / 2) * sizeof(unsigned)));
+                        w.total2 = static_cast<int*>(B.dalloc(4 * sizeof(int)));
+                    }
                     sp_work[k].push_back(w);
                 }
                 cmax = std::max(cmax, a->C);
@@ -626,7 +630,7 @@ struct Runner {
                 bool done = false;
                 for (int d : work_done[k]) done = done || d == mt;
                 if (!done) {
-                    check(ace_worklist(L.cnt, ntiles, mt, w.work, w.total, st, w.mode, 32 * L.TH), "ace_worklist");
+                    check(ace_worklist(L.cnt, ntiles, mt, w.work, w.total, st, w.mode, 32 * L.TH, w.work2, w.total2), "ace_worklist");
                     work_done[k].push_back(mt);
                 }
                 return &w;
@@ -778,7 +782,7 @@ struct Runner {
         // its LDS table reads, not by the writes; the map stays available behind sean.dbg bit 131072)
         const uint8_t* need0 = (SL && !m.use_sh16 && (m.dbg & 131072)) ? SL->need : nullptr;
         const uint8_t* need = need0;
-        const bool compact = SL && m.use_sh16 && sw->mode == 2;      // f16x3: pixel-level compaction inside the ws kernel
+        const bool compact = SL && m.use_sh16 && sw->mode >= 2;      // f16x3: pixel-level compaction inside the ws kernel
         if (compact) need = SL->need;
         const int* tile_cnt = (SL && m.use_sh16 && !compact) ? SL->cnt : nullptr;
         AcePrep q;
@@ -869,6 +873,8 @@ struct Runner {
             p.sp_cnt = L.cnt;
             p.sp_work = sw->work;
             p.sp_total = sw->total;
+            p.sp_work2 = sw->work2;
+            p.sp_total2 = sw->total2;
             timed(3, 0.0, 0.0, sw->total, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
                 // (the f16x3 LUT is stored pre-multiplied by the ACE output scale)
                 check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, m.use_sh16 ? 1.f / a.out_scale : 1.f,
