@@ -61,7 +61,8 @@ struct SparseLevel {            // device buffers of one resolution level (sean_
 struct SparseWork {             // block tasks of one (level, mtiles) pair
     unsigned* work = nullptr;   // tile | (block task within the tile << 20)
     unsigned* work2 = nullptr;  // mode 3: tile | (pair of row tiles << 20) for the tiles with at most four sub-tiles
-    int* total2 = nullptr;      // [0] entries of work2
+    int* total2 = nullptr;      // [0] entries of work2, [1] entries of work3
+    unsigned* work3 = nullptr;  // mode 3, at least four row tiles: tile | (group of four row tiles << 20) for the tiles with one or two sub-tiles
     int* total = nullptr;       // [0] number of block tasks, [1] boundary pixels, [2] sub-tiles (x32 = pixels the MFMAs run over)
                                 // [3] wave tasks x sub-tiles (x 32 x 64 rows = accumulators computed)
     int mtiles = 0;
@@ -76,7 +77,8 @@ hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t
                         hipStream_t s);
 // mode 0: block tasks of conv_ace_sparse_kernel; mode 1: (tile, row tile) pairs of the tiles with a boundary pixel (f16x3 tile-skip)
 hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s, int mode = 0,
-                        int tile_px = 512, unsigned* work2 = nullptr, int* total2 = nullptr);   // mode 3: second list (pair entries)
+                        int tile_px = 512, unsigned* work2 = nullptr, int* total2 = nullptr,    // mode 3: second list (pair entries)
+                        unsigned* work3 = nullptr);                                              // and third (quad entries; may be null)
 // gtab[b][j][gamma|beta][C] = bias + gconst[j] + sum_t lut[(t, gamma|beta, c)][(b, j)]   (lut may be null: unstyled ACE)
 // lut element (row = (t*2+gb)*C + c, n = b*lut_bs + j) at lut[row*lut_rs + n*lut_ns]; lut_mul undoes a pre-multiplied LUT
 hipError_t ace_gtable(const float* bias_g, const float* bias_b, const float* gconst, const float* lut, int lut_rs, int lut_ns,

@@ -87,23 +87,26 @@ hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t
 // conv_sh16_ws_kernel<..., CP = 2>)
 __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restrict__ cnt, int ntiles, int mtiles, int mode, int tile_px,
                                                             unsigned* __restrict__ work, int* __restrict__ total,
-                                                            unsigned* __restrict__ work2, int* __restrict__ total2) {
-    __shared__ int wsum[16], wsum2[16];
-    __shared__ int carry, carry2;
+                                                            unsigned* __restrict__ work2, int* __restrict__ total2,
+                                                            unsigned* __restrict__ work3) {
+    __shared__ int wsum[16], wsum2[16], wsum3[16];
+    __shared__ int carry, carry2, carry3;
     __shared__ int stat[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = carry2 = 0;
+    if (tid == 0) carry = carry2 = carry3 = 0;
     if (tid < 3) stat[tid] = 0;
     __syncthreads();
     int s_px = 0, s_sub = 0, s_ws = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 1024) {
         const int tile = t0 + tid;
-        int nbt = 0, nbp = 0;                          // entries of this tile in `work` / in `work2` (pair entries, mode 3)
+        int nbt = 0, nbp = 0, nbq = 0;                 // entries of this tile in `work` / `work2` (pairs) / `work3` (quads), mode 3
         if (tile < ntiles) {
             int c = cnt[tile];
             if (mode == 1 && c > 0) c = tile_px;
             const int NS = (c + 31) >> 5;
-            if (mode == 3 && NS >= 1 && NS <= 4) {      // one entry per pair of row tiles (conv_sh16_ws_kernel<..., CP = 2>)
+            if (mode == 3 && work3 && NS >= 1 && NS <= 2) {   // one entry per four row tiles (conv_sh16_ws_kernel<..., CP = 3>)
+                nbq = (mtiles + 3) >> 2;
+            } else if (mode == 3 && NS >= 1 && NS <= 4) {     // one entry per pair of row tiles (CP = 2)
                 nbp = (mtiles + 1) >> 1;
             } else if (mode >= 1) {    // mode 2 / 3: the same entries, but the conv only runs over the compacted boundary pixels
                 nbt = c > 0 ? mtiles : 0;
@@ -116,21 +119,22 @@ __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restric
             s_sub += NS;
             s_ws += NS * mtiles;
         }
-        int v = nbt, vp = nbp;                         // inclusive scans inside the wave
+        int v = nbt, vp = nbp, vq = nbq;               // inclusive scans inside the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int u = __shfl_up(v, off, 64), up = __shfl_up(vp, off, 64);
-            if (lane >= off) { v += u; vp += up; }
+            const int u = __shfl_up(v, off, 64), up = __shfl_up(vp, off, 64), uq = __shfl_up(vq, off, 64);
+            if (lane >= off) { v += u; vp += up; vq += uq; }
         }
-        if (lane == 63) { wsum[wave] = v; wsum2[wave] = vp; }
+        if (lane == 63) { wsum[wave] = v; wsum2[wave] = vp; wsum3[wave] = vq; }
         __syncthreads();
-        int base = carry, base2 = carry2;
-        for (int w = 0; w < wave; ++w) { base += wsum[w]; base2 += wsum2[w]; }
-        const int excl = base + v - nbt, excl2 = base2 + vp - nbp;
+        int base = carry, base2 = carry2, base3 = carry3;
+        for (int w = 0; w < wave; ++w) { base += wsum[w]; base2 += wsum2[w]; base3 += wsum3[w]; }
+        const int excl = base + v - nbt, excl2 = base2 + vp - nbp, excl3 = base3 + vq - nbq;
         for (int i = 0; i < nbt; ++i) work[excl + i] = (unsigned)tile | ((unsigned)i << 20);
         for (int i = 0; i < nbp; ++i) work2[excl2 + i] = (unsigned)tile | ((unsigned)i << 20);
+        for (int i = 0; i < nbq; ++i) work3[excl3 + i] = (unsigned)tile | ((unsigned)i << 20);
         __syncthreads();
-        if (tid == 1023) { carry = base + v; carry2 = base2 + vp; }
+        if (tid == 1023) { carry = base + v; carry2 = base2 + vp; carry3 = base3 + vq; }
         __syncthreads();
     }
     atomicAdd(&stat[0], s_px);
@@ -142,15 +146,15 @@ __global__ __launch_bounds__(1024) void ace_worklist_kernel(const int* __restric
         total[1] = stat[0];
         total[2] = stat[1];
         total[3] = stat[2];
-        if (total2) total2[0] = carry2;
+        if (total2) { total2[0] = carry2; total2[1] = carry3; }
     }
 }
 
 hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s, int mode, int tile_px,
-                        unsigned* work2, int* total2) {
+                        unsigned* work2, int* total2, unsigned* work3) {
     if (ntiles >= (1 << 20) || mtiles >= (1 << 12)) return hipErrorInvalidValue;
     if (mode == 3 && !(work2 && total2)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ace_worklist_kernel, dim3(1), dim3(1024), 0, s, cnt, ntiles, mtiles, mode, tile_px, work, total, work2, total2);
+    hipLaunchKernelGGL(ace_worklist_kernel, dim3(1), dim3(1024), 0, s, cnt, ntiles, mtiles, mode, tile_px, work, total, work2, total2, work3);
     return hipGetLastError();
 }
 

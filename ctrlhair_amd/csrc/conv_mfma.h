@@ -100,7 +100,8 @@ struct ConvParams {
     const unsigned* sp_work;
     const int* sp_total;
     const unsigned* sp_work2;   // f16x3 compacting kernel: second list (pair entries, ace_worklist mode 3) or null
-    const int* sp_total2;
+    const int* sp_total2;       // [0] entries of sp_work2, [1] entries of sp_work3
+    const unsigned* sp_work3;   // third list (quad entries) or null
     // EPI_NHWC
     int npix_valid;         // number of valid linear pixels (y*W+x < npix_valid)
 };

@@ -747,8 +747,9 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
     // per lane, no VGPR round trip), so the consumers' MFMA stream never waits on an L2 round trip.
     constexpr int AUNITS = NT * 4 * 64, STAGE = UNITS + AUNITS;
     constexpr int NPAR = 5;                                  // float4 per channel run: s(1+bias_g), s*bias_b, bn_a, bn_d, nv
-    constexpr bool PAIR = CP == 2;
-    constexpr int NRUN = PAIR ? 16 : 8;                      // pair entries: the parameters of two 64-row tiles
+    constexpr bool PAIR = CP >= 2;                           // CP 2 / 3: entries of two / four row tiles (MG), direct A stream
+    constexpr int MG = CP == 3 ? 4 : (CP == 2 ? 2 : 1);
+    constexpr int NRUN = 8 * MG;                             // the epilogue parameters of MG 64-row tiles
     constexpr int PAR0 = 2 * STAGE, NZ0 = PAR0 + NRUN * NPAR, LAB0 = NZ0 + 128;
     [[maybe_unused]] constexpr int LIST0 = LAB0 + (TB * (TH + 2) * (TW + 2) + 15) / 16, META0 = LIST0 + 128;   // CP: 2 x 1 KB lists, 2 x count
     constexpr int NDA = AUNITS / 256;                        // A DMA instructions per loader thread per chunk
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         if (sp) {
             const unsigned wk = p.sp_work[L];
             mtile64 = (int)(wk >> 20);
-            if (PAIR) mtile64 *= 2;                               // pair entry: first of the two row tiles
+            if (PAIR) mtile64 *= MG;                              // pair / quad entry: first of its row tiles
             nt = (int)(wk & 0xFFFFFu);
         } else {
             mtile64 = L % p.mtiles;
@@ -823,7 +824,10 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     for (int i = 0; i < AUNITS / 128; ++i)
                         __builtin_amdgcn_global_load_lds((glb_void*)(src + i * 128), (lds_void*)(dst + i * 128), 16, 0, 0);
                 };
-                float4 parr = make_float4(0.f, 0.f, 0.f, 0.f);
+                constexpr int NPI = (NRUN * NPAR + 127) / 128;
+                float4 parr[NPI];
+#pragma unroll
+                for (int pi = 0; pi < NPI; ++pi) parr[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
                 float nzr[4] = {0.f, 0.f, 0.f, 0.f};
                 uint8_t labr[5] = {255, 255, 255, 255, 255};
                 unsigned listr[2] = {0u, 0u};
@@ -832,14 +836,18 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     int mt, x0, y0, b0;
                     tile_coords(k, mt, x0, y0, b0);
                     const int C = p.C;
-                    if (ht < NRUN * NPAR) {                                  // (runs 8..15: the second row tile of a pair entry)
-                        const int run = ht / NPAR, which = ht % NPAR;
+#pragma unroll
+                    for (int pi = 0; pi < NPI; ++pi) {                       // (runs 8 and up: the further row tiles of a pair / quad entry)
+                        const int e = ht + pi * 128;
+                        if (e >= NRUN * NPAR) break;
+                        const int run = e / NPAR, which = e % NPAR;
                         const int c0 = (mt * 8 + run) * 4;
                         const float* src = which == 0 ? p.bias_g : (which == 1 ? p.bias_b : (which == 2 ? p.bn_a : (which == 3 ? p.bn_d : p.nv)));
-                        parr = *reinterpret_cast<const float4*>(src + (c0 < C ? c0 : 0));
+                        float4 pv = *reinterpret_cast<const float4*>(src + (c0 < C ? c0 : 0));
                         const float osc = p.out_scale != 0.f ? p.out_scale : 1.f;
-                        if (which == 0) parr = make_float4((parr.x + 1.f) * osc, (parr.y + 1.f) * osc, (parr.z + 1.f) * osc, (parr.w + 1.f) * osc);
-                        if (which == 1) parr = make_float4(parr.x * osc, parr.y * osc, parr.z * osc, parr.w * osc);
+                        if (which == 0) pv = make_float4((pv.x + 1.f) * osc, (pv.y + 1.f) * osc, (pv.z + 1.f) * osc, (pv.w + 1.f) * osc);
+                        if (which == 1) pv = make_float4(pv.x * osc, pv.y * osc, pv.z * osc, pv.w * osc);
+                        parr[pi] = pv;
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -863,7 +871,9 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
                     }
                 };
                 auto small_store = [&]() {
-                    if (ht < NRUN * NPAR) reinterpret_cast<float4*>(smem_u + PAR0)[ht] = parr;
+#pragma unroll
+                    for (int pi = 0; pi < NPI; ++pi)
+                        if (ht + pi * 128 < NRUN * NPAR) reinterpret_cast<float4*>(smem_u + PAR0)[ht + pi * 128] = parr[pi];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) reinterpret_cast<float*>(smem_u + NZ0)[ht + i * 128] = nzr[i];
                     if (p.lut) {
@@ -1165,13 +1175,13 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         if (stamp && k < 64) stamps[k * 3] = __builtin_amdgcn_s_memtime();
         [[maybe_unused]] int nsub = 4, cnt = 0;               // CP: this wave's sub-tiles wn, wn + 4, ... of the tile's compacted pixels
         [[maybe_unused]] const uint16_t* lst = nullptr;
-        constexpr int sst = PAIR ? 2 : 4;                     // CP: this wave's sub-tiles are sw0, sw0 + sst, ...
-        [[maybe_unused]] const int sw0 = PAIR ? (wn & 1) : wn;
+        constexpr int sst = 4 / MG;                           // CP: this wave's sub-tiles are sw0, sw0 + sst, ...
+        [[maybe_unused]] const int sw0 = wn % sst;
         if constexpr (CP) {
             cnt = reinterpret_cast<const int*>(smem_u + META0)[k & 1];
             lst = reinterpret_cast<const uint16_t*>(smem_u + LIST0 + (k & 1) * 64);
             const int NS = (cnt + 31) >> 5;
-            if constexpr (PAIR) mtile64 += wn >> 1;
+            if constexpr (PAIR) mtile64 += wn / sst;
             nsub = NS > sw0 ? (NS - sw0 + sst - 1) / sst : 0;
             if (PAIR && mtile64 >= p.mtiles) nsub = 0;        // odd number of row tiles: the last pair is half empty
 #pragma unroll
@@ -1385,7 +1395,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
             const int hi = lane >> 5, col = lane & 31;
             const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
             const char* xbase = reinterpret_cast<const char*>(p.x) + (long long)b0 * (C >> 2) * xHW * 16;
-            const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0) + (PAIR ? (wn >> 1) * 8 * NPAR : 0);
+            const float4* par = reinterpret_cast<const float4*>(smem_u + PAR0) + (PAIR ? (wn / (4 / MG)) * 8 * NPAR : 0);
             const float* nzs = reinterpret_cast<const float*>(smem_u + NZ0);
             const uint8_t* labs8 = reinterpret_cast<const uint8_t*>(smem_u + LAB0);
             const float slope = act_slope(p.act);
@@ -1474,7 +1484,7 @@ hipError_t launch_sh16_ws(ConvParams p, int rows, hipStream_t stream) {
     auto kern = conv_sh16_ws_kernel<KS, TW, TH, TB, EPI, TERMS, CP>;
     // 2 x (patch + A fragments) + (ACE) small epilogue operands: parameters, noise, label patch
     constexpr int V3_STAGE = Cfg::UNITS + KS * KS * 4 * 64;
-    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16 + (CP ? (129 + (CP == 2 ? 40 : 0)) * 16 : 0)
+    constexpr int V3_LDS = EPI == EPI_ACE ? (2 * V3_STAGE + 40 + 128) * 16 + ((TB * (TH + 2) * (TW + 2) + 15) / 16) * 16 + (CP ? (129 + (CP == 3 ? 120 : (CP == 2 ? 40 : 0))) * 16 : 0)
                                           : 2 * V3_STAGE * 16;
     // per device: a process may own handles on several GPUs (ch_api.cpp DeviceGuard)
     static bool attr_set[64] = {};
@@ -1627,10 +1637,14 @@ hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
             if (p.sp_work && p.sp_list) {
                 hipError_t e = launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, 1>(p, rows, s);
                 if (e != hipSuccess || !p.sp_work2) return e;
-                ConvParams p2 = p;                                // the tiles with at most four sub-tiles: two row tiles per entry
+                ConvParams p2 = p;                                // the tiles with three or four sub-tiles: two row tiles per entry
                 p2.sp_work = p.sp_work2;
                 p2.sp_total = p.sp_total2;
-                return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, 2>(p2, rows, s);
+                e = launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, 2>(p2, rows, s);
+                if (e != hipSuccess || !p.sp_work3) return e;
+                p2.sp_work = p.sp_work3;                          // one or two sub-tiles: four row tiles per entry
+                p2.sp_total = p.sp_total2 + 1;
+                return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, 3>(p2, rows, s);
             }
         }
         return launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS>(p, rows, s);

@@ -508,6 +508,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     if (w.mode == 3) {
                         w.work2 = static_cast<unsigned*>(B.dalloc((size_t)L.cap_tiles * ((mt + 1) / 2) * sizeof(unsigned)));
                         w.total2 = static_cast<int*>(B.dalloc(4 * sizeof(int)));
+                        if (mt >= 4 && !(dbg & 67108864))
+                            w.work3 = static_cast<unsigned*>(B.dalloc((size_t)L.cap_tiles * ((mt + 3) / 4) * sizeof(unsigned)));
                     }
                     sp_work[k].push_back(w);
                 }
@@ -630,7 +632,7 @@ struct Runner {
                 bool done = false;
                 for (int d : work_done[k]) done = done || d == mt;
                 if (!done) {
-                    check(ace_worklist(L.cnt, ntiles, mt, w.work, w.total, st, w.mode, 32 * L.TH, w.work2, w.total2), "ace_worklist");
+                    check(ace_worklist(L.cnt, ntiles, mt, w.work, w.total, st, w.mode, 32 * L.TH, w.work2, w.total2, w.work3), "ace_worklist");
                     work_done[k].push_back(mt);
                 }
                 return &w;
@@ -875,6 +877,7 @@ struct Runner {
             p.sp_total = sw->total;
             p.sp_work2 = sw->work2;
             p.sp_total2 = sw->total2;
+            p.sp_work3 = sw->work3;
             timed(3, 0.0, 0.0, sw->total, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
                 // (the f16x3 LUT is stored pre-multiplied by the ACE output scale)
                 check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, m.use_sh16 ? 1.f / a.out_scale : 1.f,
