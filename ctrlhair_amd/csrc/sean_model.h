@@ -103,7 +103,8 @@ struct SeanModel {
     int sparse = 1;                            // option "sean.sparse" (0 = every pixel through the conv)
     int sparse_min_r = 64;                     // option "sean.sparse_min": smallest resolution served by the sparse path
     int sh16_compact = 1;                      // option "sean.sh16_compact": f16x3 path, 1 = pixel-level compaction inside the
-                                               //   wave-specialised ACE kernel (3-term path), 0 = tile skipping only
+                                               //   wave-specialised ACE kernel (3-term path) with pair / quad entries for
+                                               //   sparse tiles, 2 = without those entries (A/B), 0 = tile skipping only
     int sparse_th = 0;                         // option "sean.sparse_th": tile height 8 / 16 (0 = by the layer's row tiles)
     SparseLevel sp_level[6][2];                // [level][0: tiles of 32 x 8 | 1: tiles of 32 x 16]
     std::vector<SparseWork> sp_work[6];
