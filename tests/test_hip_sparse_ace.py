@@ -138,3 +138,23 @@ def test_interior_and_label_table_kernels_match_their_first_versions(hip_lib, pa
         assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
     new.handle.close()
     old.handle.close()
+
+
+def test_pair_and_quad_entries_match_single_row_tile_entries(hip_lib):
+    """f16x3 compacting kernel: tiles with at most four sub-tiles of boundary pixels are served two or four row tiles per
+    iteration, with the A fragments streamed by the consumer waves (conv_sh16_ws_kernel<..., CP = 2 / 3>); option
+    sean.sh16_compact = 2 serves every tile one row tile at a time through the loaders' A DMA.  Same products added in the same
+    order: bit-identical images.  ngf = 64 at 256^2 gives 2 ... 32 row tiles per layer (quad entries need at least four)."""
+    from ctrlhair_amd import procedural as P
+    ngf, S, B = 64, 256, 2
+    sd = P.sean_state_dict(0, ngf)
+    codes, noise = P.style_codes(B), P.noise_planes(B, S, ngf)
+    a_gen = _gen(sd, B, S, 'f16x3', 1)
+    b_gen = _gen(sd, B, S, 'f16x3', 1, {'sean.sh16_compact': 2})
+    sets = _label_sets(B, S)
+    for name in ('face', 'blocky', 'one_region', 'stripes5'):
+        a, b = _run(a_gen, sets[name], codes, noise), _run(b_gen, sets[name], codes, noise)
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
+    a_gen.handle.close()
+    b_gen.handle.close()
