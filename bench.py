@@ -115,7 +115,7 @@ class GeneratorJob:
         from ctrlhair_amd import procedural as P
         from ctrlhair_amd.sean.generator import SeanGenerator
         B, S, ngf = args.batch, args.size, args.ngf
-        opts = {'sean.sparse': args.sparse}
+        opts = {'sean.sparse': args.sparse, 'sean.wino': args.wino}
         if args.ahead >= 0:
             opts['sean.ahead'] = args.ahead
         if args.sparse_th:
@@ -370,6 +370,7 @@ def main():
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--ahead', type=int, default=-1, help=argparse.SUPPRESS)       # option sean.ahead (experiments)
     ap.add_argument('--sparse', type=int, default=1, help='0: every pixel through the SPADE convs (no interior reduction)')
+    ap.add_argument('--wino', type=int, default=1, help='exact-f32 path: 0 = 3x3 convs evaluated directly (no Winograd F(2x2,3x3))')
     ap.add_argument('--sparse-th', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--compact', type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--sync-gather', action='store_true',

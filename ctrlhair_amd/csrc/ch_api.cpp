@@ -343,6 +343,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.ahead_pixels = (long long)value * 512 * 512;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.wino") == 0) {       // exact-f32 path: 3x3 convs as Winograd F(2x2,3x3) on the f32 matrix cores (conv_wino.h)
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino) must precede ch_finalize");
+        h->sean.wino = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.sparse") == 0) {     // exact SPADE-interior reduction (ace_sparse.h); buffers are sized at ch_finalize
         h->sean.sparse = value != 0;
         return CH_OK;
@@ -410,7 +415,7 @@ int ch_profile_read_ex(ch_handle* h, int kind, int* launches, double* total_ms, 
                 fx += (double)st[3] * r.sp_flops_unit;
                 by += r.sp_bytes_fixed + r.sp_bytes_px * (r.kind == 3 ? r.sp_npix - (double)st[1] : (double)st[1]);
             } else {
-                fx += r.flops;
+                fx += r.flops_exec >= 0.0 ? r.flops_exec : r.flops;
                 by += r.bytes;
             }
             ++n;

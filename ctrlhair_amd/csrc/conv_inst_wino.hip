@@ -1,0 +1,179 @@
+// conv_inst_wino.hip -- instantiations + launchers of the Winograd F(2x2,3x3) exact-f32 MFMA kernels (conv_wino.h)
+#include "conv_wino.h"
+
+namespace chk {
+
+static int wino_num_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+template <class K>
+static hipError_t wino_attr(K kern, int bytes, bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    return hipSuccess;
+}
+
+hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
+    if (!wino_supported(p.H, p.W, p.Cin) || !p.zero) return hipErrorInvalidValue;
+    wino_fill_launch(p);
+    const int grid = p.ntasks < wino_num_cus() ? p.ntasks : wino_num_cus();
+    static bool d0[64] = {};
+    hipError_t e = wino_attr(wino_plain_kernel<0>, wino::LDS_BYTES, d0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wino_plain_kernel<0>, dim3(grid), dim3(512), wino::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+
+hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s) {
+    if (p.H % wino::TH || p.W % wino::TW || !p.zero || !p.qlist || !p.qcnt || !p.work || !p.total || (p.C & 3)) return hipErrorInvalidValue;
+    p.nrt = (p.C + 15) / 16;
+    p.ntx = p.W / wino::TW;
+    p.nty = p.H / wino::TH;
+    p.K = 128 + (p.wsty ? 20 : 0);
+    static bool d0[64] = {};
+    hipError_t e = wino_attr(wino_ace_kernel<0>, WA_LDS_BYTES, d0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wino_ace_kernel<0>, dim3(wino_num_cus()), dim3(512), WA_LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+// ---- boundary quads of a tile of 32 x 16 pixels: one block of 128 threads = the tile's 16 x 8 quads, ordered compaction ----------
+__global__ __launch_bounds__(128) void wino_quad_list_kernel(const uint8_t* __restrict__ u5, uint8_t* __restrict__ qlist, int* __restrict__ qcnt,
+                                                             int H, int W, int ntx, int nty) {
+    __shared__ int wc[2];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int b = tile / (ntx * nty), tr = tile % (ntx * nty);
+    const int y = (tr / ntx) * 16 + 2 * (tid >> 4), x = (tr % ntx) * 32 + 2 * (tid & 15);
+    const uint8_t* up = u5 + ((long long)b * H + y) * W + x;
+    const bool bnd = up[0] == 255 || up[1] == 255 || up[W] == 255 || up[W + 1] == 255;
+    const unsigned long long m = __ballot(bnd);
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane == 0) wc[wave] = __popcll(m);
+    __syncthreads();
+    const int base = wave ? wc[0] : 0;
+    if (bnd) qlist[(long long)tile * 128 + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    if (tid == 0) qcnt[tile] = wc[0] + wc[1];
+}
+hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int B, int H, int W, hipStream_t s) {
+    if (H % 16 || W % 32) return hipErrorInvalidValue;
+    const int ntx = W / 32, nty = H / 16;
+    hipLaunchKernelGGL(wino_quad_list_kernel, dim3(B * ntx * nty), dim3(128), 0, s, u5, qlist, qcnt, H, W, ntx, nty);
+    return hipGetLastError();
+}
+
+// ---- block tasks of conv_wino_ace: per tile ceil(quads / 64) halves x ceil(nrt / 2) row pairs; one block of 1024 threads scans ------
+// total: [0] entries, [1] boundary quads, [2] 16-quad groups, [3] groups x row tiles (wave tasks: x 32 rows x 16 quads of accumulators)
+__global__ __launch_bounds__(1024) void wino_ace_worklist_kernel(const int* __restrict__ qcnt, int ntiles, int nrt, unsigned* __restrict__ work,
+                                                                 int* __restrict__ total) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    __shared__ int stat[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int npair = (nrt + 1) >> 1;
+    if (tid == 0) carry = 0;
+    if (tid < 3) stat[tid] = 0;
+    __syncthreads();
+    int s_q = 0, s_g = 0, s_w = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+        const int tile = t0 + tid;
+        int ne = 0, halves = 0;
+        if (tile < ntiles) {
+            const int c = qcnt[tile], g = (c + 15) >> 4;
+            halves = (c + 63) >> 6;
+            ne = halves * npair;
+            s_q += c;
+            s_g += g;
+            s_w += g * nrt;
+        }
+        int v = ne;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(v, off, 64);
+            if (lane >= off) v += u;
+        }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int o = base + v - ne;
+        for (int h = 0; h < halves; ++h)
+            for (int pr = 0; pr < npair; ++pr) work[o++] = (unsigned)tile | ((unsigned)pr << 20) | ((unsigned)h << 31);
+        __syncthreads();
+        if (tid == 1023) carry = base + v;
+        __syncthreads();
+    }
+    atomicAdd(&stat[0], s_q);
+    atomicAdd(&stat[1], s_g);
+    atomicAdd(&stat[2], s_w);
+    __syncthreads();
+    if (tid == 0) {
+        total[0] = carry;
+        total[1] = stat[0];
+        total[2] = stat[1];
+        total[3] = stat[2];
+    }
+}
+hipError_t wino_ace_worklist(const int* qcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s) {
+    if (ntiles >= (1 << 20) || nrt >= (1 << 11)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(wino_ace_worklist_kernel, dim3(1), dim3(1024), 0, s, qcnt, ntiles, nrt, work, total);
+    return hipGetLastError();
+}
+
+// ---- style LUT -> per-sample Winograd A images --------------------------------------------------------------------------------------
+// lut[((b*19 + j)*9 + t)*2C + gb*C + c]  (P = W[:, :, t] relu(fc_mu_j(code)), blend factor folded in; sean_model.cpp)
+// wsty[((b*nrt + rt)*5 + s)*2048 + (idx*64 + lane)*4 + e]: fragment a = 4 idx + e = (xi = a >> 1, m = a & 1) of row (m ? beta : gamma) of
+// channel 16 rt + (lane & 15), input "channel" = label j = 4 s + (lane >> 4) (j = 19: the zero plane).  U = G P G^T in f32.
+__global__ __launch_bounds__(256) void wino_style_pack_kernel(const float* __restrict__ lut, float* __restrict__ wsty, int B, int C, int nrt) {
+    const long long n = (long long)B * nrt * 5 * 512;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    const int lane = (int)(i & 63), idx = (int)((i >> 6) & 7), s = (int)((i >> 9) % 5);
+    const int rt = (int)((i / (512 * 5)) % nrt), b = (int)(i / (512LL * 5 * nrt));
+    const int c = rt * 16 + (lane & 15), j = 4 * s + (lane >> 4);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C && j < 19) {
+        const float* P = lut + ((long long)(b * 19 + j) * 9) * 2 * C + c;
+        float u[2][2];
+#pragma unroll
+        for (int gb = 0; gb < 2; ++gb) {
+            float g[3][3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = P[(long long)t * 2 * C + gb * C];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int xi = 2 * idx + e, ii = xi >> 2, jj = xi & 3;
+                // row ii of G applied to the rows of g, then column jj:  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+                float r[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    r[q] = ii == 0 ? g[0][q] : (ii == 3 ? g[2][q] : 0.5f * (g[0][q] + (ii == 1 ? g[1][q] : -g[1][q]) + g[2][q]));
+                u[e][gb] = jj == 0 ? r[0] : (jj == 3 ? r[2] : 0.5f * (r[0] + (jj == 1 ? r[1] : -r[1]) + r[2]));
+            }
+        }
+        o = make_float4(u[0][0], u[0][1], u[1][0], u[1][1]);
+    }
+    reinterpret_cast<float4*>(wsty)[i] = o;
+}
+hipError_t wino_style_pack(const float* lut, float* wsty, int B, int C, hipStream_t s) {
+    const int nrt = (C + 15) / 16;
+    const long long n = (long long)B * nrt * 5 * 512;
+    hipLaunchKernelGGL(wino_style_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lut, wsty, B, C, nrt);
+    return hipGetLastError();
+}
+
+}  // namespace chk

@@ -1,0 +1,769 @@
+// conv_wino.h -- 3x3 stride-1 zero-padded convolutions as Winograd F(2x2, 3x3) on the exact-f32 matrix cores of gfx950
+// (v_mfma_f32_16x16x4_f32): 16 multiplies per 2x2 output quad and channel instead of 36, every product and sum an IEEE
+// f32 operation (the transforms are f32 adds, the contraction is the MFMA's f32 fma chain).  A real-arithmetic identity of
+// the reference's conv2d (architecture.py:82-91 conv_0 / conv_1; normalization.py:249-257 mlp_gamma / mlp_beta), like the
+// other reformulations of DESIGN.md section 2; measured deviation from the direct evaluation <= 4e-6 on the generator output
+// (tests/test_hip_wino.py, tests/test_winograd_model.py).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        g: 3x3 kernel, d: 4x4 input patch, Y: 2x2 output quad
+//   M[xi][row][quad] = sum_ci U[xi][row][ci] * V[xi][ci][quad]            (xi = 0..15: sixteen independent GEMMs)
+//
+// Mapping to the hardware
+//   * One persistent 512-thread block per CU (grid = #CUs), 8 waves = 2 per SIMD.  A block task = a spatial tile of 32 x 16
+//     pixels (16 x 8 quads) of one sample x a ROW TILE of 32 GEMM rows; wave w owns quad row w (16 quads) for all 32 rows and
+//     all 16 xi: 32 accumulators of 16x16 (128 registers).  One k-step = 4 input channels = 32 MFMAs per wave.
+//   * B operand: lane (n = lane & 15, kk = lane >> 4) holds quad n, channel kk of the k-step -- exactly one (quad, channel)
+//     pair per lane, so the lane transforms ITS OWN 4x4 patch (8 ds_read_b64 from the un-expanded LDS patch + 32 f32 adds)
+//     and the 16 results are the B registers of the 16 xi.  V never exists in memory.
+//   * A operand: U = G g G^T computed in double at ch_finalize, rounded once to f32 and packed into per-lane fragment order
+//     (pack_wino_A); a k-step's 8 KB image goes L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane) and is shared by the 8
+//     waves (ds_read_b128, four fragments per read).
+//   * Input patch (tile + halo, 4 channels): LDS-DMA too, 4 B per lane with per-lane source addresses; taps outside the
+//     image read a zero word.  No vector register ever holds staged data, so the MFMA stream waits on nothing but the
+//     counted s_waitcnt in front of the one barrier per k-step.
+//   * A 6-stage ring of k-steps runs as ONE flat sequence across the block's tasks: the next task's first k-steps are in
+//     flight during the current task's last ones and its epilogue (no exposed prologue).  The first fragments of k-step
+//     q + 1 are read before the barrier that ends k-step q (its data were verified one barrier earlier), so the MFMA stream
+//     continues across barriers.
+//   * The ResBlock's learned 1x1 shortcut conv_s (architecture.py:75-79) stays a direct 1x1 GEMM (conv_mfma.h) whose output this
+//     kernel adds as the residual: folded into the Winograd accumulators it costs the same MFMAs (a centre-tap kernel is
+//     non-zero at the four central xi) but 8 MFMAs per barrier interval do not cover the interval's fixed costs (measured:
+//     +1.7 ms per fused layer against +0.8 for the separate launch, tools/wino_bench.hip at an earlier revision).
+//   * Epilogue: output transform in registers (24 adds per (row, quad)), bias / residual / activation, float2 stores
+//     (16 lanes = one 128-byte line).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "conv_mfma.h"
+
+namespace chk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void wino_lds_void;
+typedef __attribute__((address_space(1))) const void wino_glb_void;
+
+namespace wino {
+constexpr int TW = 32, TH = 16;              // spatial tile (pixels)
+constexpr int PWP = 36, PROWS = TH + 2;      // LDS patch: 18 rows of 36 floats (34 used)
+constexpr int PS = 672;                      // plane stride (floats): 648 used; 672 = 10 * 64 + 32 -> the two channel planes a
+                                             //   32-lane ds_read_b64 group touches sit on disjoint bank halves
+constexpr int NPD = 6;                       // patch DMA instructions per thread per k-step (6 * 512 >= 4 * 672)
+constexpr int PDW = NPD * 512;               // patch dwords per stage
+constexpr int ADW = 2048;                    // A dwords per stage (32 fragments x 64 lanes)
+constexpr int SDW = PDW + ADW;               // 20 KB per stage
+constexpr int NST = 6;                       // ring depth
+constexpr int NLD = NPD + 1;                 // vector-memory instructions per thread per k-step
+constexpr int LDS_BYTES = NST * SDW * 4;     // 120 KB
+}  // namespace wino
+
+struct WinoParams {
+    const float* in;        // [B][Cin][H][W]
+    const float* wpk;       // pack_wino_A image
+    float* out;             // [B][Cout][H][W]
+    int B, Cin, Cout, H, W; // H % 16 == 0, W % 32 == 0, Cin % 4 == 0
+    const float* bias;      // [Cout] or null
+    const float* res;       // [B][Cout][H >> res_up][W >> res_up] or null
+    int res_up, act;
+    const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image patch elements)
+    // set by the launcher
+    int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
+#ifdef WINO_ABLATE
+    unsigned long long* stamps;   // tools/wino_bench.hip only: per wave [wait + barrier, MFMA groups, tail] cycle sums
+    int dbg;                // tools/wino_bench.hip only (timing ablations, wrong results): 1 no MFMA, 2 no patch DMA, 4 no A DMA,
+                            //   8 no fragment reads
+#endif
+};
+#ifdef WINO_ABLATE
+#define WINO_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define WINO_DBG(p, bit) 0
+#endif
+
+// ---- host: weight transform + packing -------------------------------------------------------------------------------------
+// image of (row tile rt, k-step s): [idx 0..7][lane][4 floats]; float e of idx holds fragment a = 4 idx + e = (xi = a >> 1,
+// m = a & 1): U[xi][row = 32 rt + 16 m + (lane & 15)][ci = 4 s + (lane >> 4)]
+template <class F>
+std::vector<float> pack_wino_A(int rows, int Cin, F get) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nrt = (rows + 31) / 32, nks = Cin / 4;
+    std::vector<float> dst((size_t)nrt * nks * 2048, 0.f);
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int s = 0; s < nks; ++s) {
+            float* img = dst.data() + ((size_t)rt * nks + s) * 2048;
+            for (int m = 0; m < 2; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = rt * 32 + m * 16 + (lane & 15), ci = 4 * s + (lane >> 4);
+                    if (row >= rows) continue;
+                    double g[3][3], t[4][3];
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) g[a][b] = get(row, ci, a * 3 + b);
+                    for (int i = 0; i < 4; ++i)
+                        for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j) {
+                            const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                            const int a = (i * 4 + j) * 2 + m;
+                            img[((a >> 2) * 64 + lane) * 4 + (a & 3)] = (float)u;
+                        }
+                }
+        }
+    return dst;
+}
+// ---- device ------------------------------------------------------------------------------------------------------------------
+// task L -> (row tile, spatial tile).  32 consecutive tasks (what the 32 CUs of one XCD run at the same time) form a block of
+// `rb` row tiles x `tbk` spatial tiles, so that their A images and input patches are shared through the XCD's L2.
+__device__ __forceinline__ void wino_task(const WinoParams& p, int L, int& rt, int& tile) {
+    const int per = p.tbk * p.nrt;
+    const int tg = L / per;
+    int r = L - tg * per;
+    const int tgsz = min(p.tbk, p.ntiles - tg * p.tbk);
+    const int rg = r / (tgsz * p.rb);
+    r -= rg * tgsz * p.rb;
+    const int rgsz = min(p.rb, p.nrt - rg * p.rb);
+    const int tl = r / rgsz;
+    rt = rg * p.rb + (r - tl * rgsz);
+    tile = tg * p.tbk + tl;
+}
+
+__device__ __forceinline__ void wino_in_transform(const float (&d)[4][4], float (&v)[16]) {
+    float t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[4 * i + 0] = t[i][0] - t[i][2];
+        v[4 * i + 1] = t[i][1] + t[i][2];
+        v[4 * i + 2] = t[i][2] - t[i][1];
+        v[4 * i + 3] = t[i][1] - t[i][3];
+    }
+}
+
+__device__ __forceinline__ void wino_out_transform(const float (&M)[16], float& y00, float& y01, float& y10, float& y11) {
+    float s0[4], s1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s0[r] = M[4 * r] + M[4 * r + 1] + M[4 * r + 2];
+        s1[r] = M[4 * r + 1] - M[4 * r + 2] - M[4 * r + 3];
+    }
+    y00 = s0[0] + s0[1] + s0[2];
+    y01 = s1[0] + s1[1] + s1[2];
+    y10 = s0[1] - s0[2] - s0[3];
+    y11 = s1[1] - s1[2] - s1[3];
+}
+
+typedef unsigned wino_u32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (gfx9 family): base, stride 0, num_records bytes, 32-bit raw format word
+__device__ __forceinline__ wino_u32x4 wino_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    wino_u32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+// LDS-DMA through inline asm: hipcc orders every later ds_read behind a builtin LDS-DMA with s_waitcnt vmcnt(0) (it cannot prove
+// the ring slots disjoint), which drained the ring once per k-step; an asm statement is invisible to that bookkeeping, the
+// counted waits are ours.  buffer_load ... lds: per-lane 32-bit byte offsets (an offset >= num_records returns 0: the zero
+// padding of the conv costs nothing), the k-step's channel offset in an SGPR; M0 = LDS destination of lane 0.
+__device__ __forceinline__ void wino_dma4(unsigned voff, const wino_u32x4& d, unsigned soff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(voff), "s"(d), "s"(soff), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void wino_dma16(unsigned voff, const wino_u32x4& d, unsigned soff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(d), "s"(soff), "s"(lds) : "memory");
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) {
+    using namespace wino;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kk = lane >> 4;
+    const int G = gridDim.x;
+    const int lb = xcd_remap(blockIdx.x, G);
+    if (lb >= p.ntasks) return;
+    const int mytasks = (p.ntasks - lb + G - 1) / G;
+    const int nk = p.nks;
+    const int HW = p.H * p.W;
+    constexpr unsigned SB = SDW * 4, RING = NST * SB;
+    const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;          // LDS byte address of the ring
+
+    // ---- issue side (everything wave-uniform except the six patch offsets) -----------------------------------------------------
+    unsigned voff[NPD];
+    const unsigned va = (unsigned)tid * 16u;
+    int it = lb, is = 0;                   // task / k-step the next issue serves
+    wino_u32x4 d_in, d_a;
+    unsigned so_in = 0, so_a = 0;
+    auto issue_task = [&]() {
+        int irt, tile;
+        wino_task(p, it, irt, tile);
+        const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, ib = tile / (p.ntx * p.nty);
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {        // element e of the stage's patch image -> (channel k4, patch row, patch column)
+            const int e = i * 512 + tid;
+            const int k4 = e / PS, rem = e - k4 * PS;
+            const int py = rem / PWP, px = rem - py * PWP;
+            const int y = y0 + py, x = x0 + px;
+            const bool ok = k4 < 4 && rem < PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
+        }
+        d_in = wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
+        d_a = wino_rsrc(p.wpk + (long long)irt * p.nks * 2048, (unsigned)p.nks * 8192u);
+        so_in = 0;
+        so_a = 0;
+    };
+    issue_task();
+    unsigned islot = lds0;                 // ring slot the next issue fills
+    // issue_part(part): part 0..2 = two patch DMAs each, part 3 = the A image + advance.  The parts sit between the MFMA groups of
+    // a k-step, so that they issue in the shadow of the matrix pipe.
+    auto issue_part = [&](int part) {
+        const unsigned wb = islot + (unsigned)wave * 256u;
+        if (part < 3) {
+#pragma unroll
+            for (int i = 2 * part; i < 2 * part + 2; ++i) {
+                if (WINO_DBG(p, 2)) continue;
+                wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
+            }
+            return;
+        }
+        if (!WINO_DBG(p, 4)) {
+            const unsigned wa = islot + PDW * 4u + (unsigned)wave * 1024u;
+            wino_dma16(va, d_a, so_a, wa);
+        }
+        islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
+        so_in += 16u * (unsigned)HW;
+        so_a += 8192u;
+        if (++is == nk) {
+            if (it + G < p.ntasks) {
+                it += G;
+                is = 0;
+                issue_task();
+            } else {                       // past the end: keep re-issuing the last k-step (never read; keeps the vmcnt counting uniform)
+                is = nk - 1;
+                so_in -= 16u * (unsigned)HW;
+                so_a -= 8192u;
+            }
+        }
+    };
+
+    // ---- consumer side ---------------------------------------------------------------------------------------------------
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int boff = kk * PS + (2 * wave) * PWP + 2 * n;      // this lane's patch origin (floats) inside a stage
+    auto load_raw = [&](unsigned slot, float (&d)[4][4]) {
+        const float* sp = reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + boff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 lo = *reinterpret_cast<const float2*>(sp + i * PWP), hi = *reinterpret_cast<const float2*>(sp + i * PWP + 2);
+            d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+        }
+    };
+    auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + PDW) + lane; };
+
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(part);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 3)) : "memory");
+    __syncthreads();
+    float v[16];
+    f32x4 a0, a1;
+    {
+        float d[4][4];
+        load_raw(lds0, d);
+        wino_in_transform(d, v);
+        const f32x4* ap = a_ptr(lds0);
+        a0 = ap[0];
+        a1 = ap[64];
+    }
+
+    unsigned rslot = lds0;
+    bool after_epi = false;
+#ifdef WINO_ABLATE
+    unsigned long long st_wait = 0, st_mf = 0, st_tail = 0, st_vm = 0, tl = 0;
+#endif
+    float w[16];                                                   // the other half of the (v, w) ping-pong of B fragments
+    // one k-step: MFMAs on the B fragments `vc` (ready) while the next k-step's patch is read and transformed into `vx`
+    auto kstep = [&](float (&vc)[16], float (&vx)[16]) {
+#ifdef WINO_ABLATE
+        const unsigned long long T0 = __builtin_amdgcn_s_memtime();
+        if (p.stamps && tl != 0) st_tail += T0 - tl;
+#endif
+        if (after_epi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 3)) : "memory");
+#ifdef WINO_ABLATE
+        const unsigned long long T0b = __builtin_amdgcn_s_memtime();
+        st_vm += T0b - T0;
+#endif
+        if (!WINO_DBG(p, 32)) __syncthreads();
+#ifdef WINO_ABLATE
+        const unsigned long long T1 = __builtin_amdgcn_s_memtime();
+        st_wait += T1 - T0b;
+#endif
+        after_epi = false;
+        const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
+        const f32x4* ap = a_ptr(rslot);
+        const f32x4* apn = a_ptr(nslot);
+        float dn[4][4], t[4][4];
+        {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f32x4 c0 = a0, c1 = a1;
+                if (!WINO_DBG(p, 8)) {
+                    if (h < 3) {
+                        a0 = ap[(2 * h + 2) * 64];
+                        a1 = ap[(2 * h + 3) * 64];
+                    } else {
+                        a0 = apn[0];
+                        a1 = apn[64];
+                    }
+                    if (h == 0) load_raw(nslot, dn);               // k-step q + 1 was verified by the barrier above
+                }
+                __builtin_amdgcn_sched_barrier(0);                 // the LDS reads of the NEXT group first: this group's MFMA time
+                                                                   //   is their latency
+                // the next k-step's input transform, spread over the MFMA groups (B^T d, then (.) B two rows at a time)
+                if (h == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        t[0][j] = dn[0][j] - dn[2][j];
+                        t[1][j] = dn[1][j] + dn[2][j];
+                        t[2][j] = dn[2][j] - dn[1][j];
+                        t[3][j] = dn[1][j] - dn[3][j];
+                    }
+                }
+                if (h >= 2) {
+#pragma unroll
+                    for (int i = 2 * (h - 2); i < 2 * (h - 2) + 2; ++i) {
+                        vx[4 * i + 0] = t[i][0] - t[i][2];
+                        vx[4 * i + 1] = t[i][1] + t[i][2];
+                        vx[4 * i + 2] = t[i][2] - t[i][1];
+                        vx[4 * i + 3] = t[i][1] - t[i][3];
+                    }
+                }
+                if (!WINO_DBG(p, 1)) {
+                    acc[4 * h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, vc[4 * h], acc[4 * h][0], 0, 0, 0);
+                    acc[4 * h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, vc[4 * h], acc[4 * h][1], 0, 0, 0);
+                    acc[4 * h + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.z, vc[4 * h + 1], acc[4 * h + 1][0], 0, 0, 0);
+                    acc[4 * h + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.w, vc[4 * h + 1], acc[4 * h + 1][1], 0, 0, 0);
+                    acc[4 * h + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, vc[4 * h + 2], acc[4 * h + 2][0], 0, 0, 0);
+                    acc[4 * h + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, vc[4 * h + 2], acc[4 * h + 2][1], 0, 0, 0);
+                    acc[4 * h + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.z, vc[4 * h + 3], acc[4 * h + 3][0], 0, 0, 0);
+                    acc[4 * h + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.w, vc[4 * h + 3], acc[4 * h + 3][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                issue_part(h);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        rslot = nslot;
+#ifdef WINO_ABLATE
+        tl = __builtin_amdgcn_s_memtime();
+        st_mf += tl - T1;
+#endif
+    };
+    for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
+        for (int cs = 0; cs < nk; cs += 2) {
+            kstep(v, w);          // (nks is even: wino_supported)
+            kstep(w, v);
+        }
+        // ---- epilogue of task ct ---------------------------------------------------------------------------------------------
+        {
+            int crt, tile;
+            wino_task(p, ct, crt, tile);
+            const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
+            const int y = ty * TH + 2 * wave, x = tx * TW + 2 * n;
+            const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = crt * 32 + m * 16 + 4 * kk + i;
+                    float M[16];
+#pragma unroll
+                    for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][m][i];
+                    float y00, y01, y10, y11;
+                    wino_out_transform(M, y00, y01, y10, y11);
+                    if (row < p.Cout) {
+                        const float bs = p.bias ? p.bias[row] : 0.f;
+                        y00 += bs; y01 += bs; y10 += bs; y11 += bs;
+                        if (p.res) {
+                            const float* rp = p.res + ((long long)b * p.Cout + row) * rHW;
+                            if (p.res_up) {
+                                const float r = rp[(y >> 1) * rW + (x >> 1)];
+                                y00 += r; y01 += r; y10 += r; y11 += r;
+                            } else {
+                                const float2 r0 = *reinterpret_cast<const float2*>(rp + y * rW + x);
+                                const float2 r1 = *reinterpret_cast<const float2*>(rp + (y + 1) * rW + x);
+                                y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+                            }
+                        }
+                        if (p.act != ACT_NONE) {
+                            y00 = apply_act(y00, p.act); y01 = apply_act(y01, p.act);
+                            y10 = apply_act(y10, p.act); y11 = apply_act(y11, p.act);
+                        }
+                        float* op = p.out + ((long long)b * p.Cout + row) * HW + y * p.W + x;
+                        *reinterpret_cast<float2*>(op) = make_float2(y00, y01);
+                        *reinterpret_cast<float2*>(op + p.W) = make_float2(y10, y11);
+                    }
+                }
+#pragma unroll
+            for (int x2 = 0; x2 < 16; ++x2)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            after_epi = true;
+        }
+    }
+#ifdef WINO_ABLATE
+    if (p.stamps && lane == 0) {
+        unsigned long long* o = p.stamps + ((long long)blockIdx.x * 8 + wave) * 4;
+        o[0] = st_wait; o[1] = st_mf; o[2] = st_tail; o[3] = st_vm;
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
+}
+
+// ================================================================================================================================
+// SPADE gamma/beta conv (normalization.py:249-257) + the style convs conv_gamma / conv_beta (:117-153,172-173) + the fused ACE
+// epilogue (:111-112,177-187; architecture.py:95) on the same Winograd machinery, over the BOUNDARY QUADS only (ace_sparse.h:
+// a 2x2 quad is a boundary quad when one of its pixels has a non-uniform 5x5 label neighbourhood; the interior pass has
+// written the others).
+//   * GEMM rows: a row tile = 16 channels: rows 0-15 = their gamma rows, 16-31 = their beta rows, so a lane's accumulators
+//     hold gamma and beta of the same (channel, pixel).
+//   * K = the 128 SPADE hidden channels + (styled ACEs) 20 ONE-HOT label planes written behind them by the label-table kernel:
+//     the style term  sum_t P[(sample, label(p + t)), t]  is the 3x3 conv of the one-hot map with per-SAMPLE weights P (the
+//     style LUT), so it runs on the matrix cores as 5 more k-steps whose A images come from a per-sample buffer (wino_style_pack,
+//     Winograd-transformed LUT) -- the 18 gathers per (pixel, 4-channel run) of the direct kernel's epilogue are gone.
+//   * A block task = one spatial tile of 32 x 16 pixels x a PAIR of row tiles x up to 64 of its boundary quads: waves 0-3 / 4-7
+//     take the two row tiles, wave (w & 3) the w-th group of 16 listed quads (B-fragment addresses are per lane anyway);
+//     waves without quads only take part in the staging.  A tile with more than 64 boundary quads gets a second task.
+struct WinoAceParams {
+    const float* actv;      // [B][K][H][W]: K = 128 (+ 20 one-hot planes when wsty is set)
+    const float* wpk;       // pack_wino_A image of the (gamma | beta) rows over the 128 hidden channels
+    const float* wsty;      // [B][nrt][5][2048] per-sample style images, or null (unstyled ACE)
+    float* out;             // [B][C][H][W]
+    const float* x;         // [B][C][H >> x_up][W >> x_up]
+    int x_up, act;
+    int B, C, H, W;
+    const float *bias_g, *bias_b, *bn_a, *bn_d, *nv;
+    const float* noise;     // plane base of this ACE, sample stride noise_bstride, layout [W][H]
+    long long noise_bstride;
+    const uint8_t* qlist;   // [ntiles][128] boundary quads of each tile (qy * 16 + qx), raster order
+    const int* qcnt;        // [ntiles]
+    const unsigned* work;   // tile | row pair << 20 | half << 31
+    const int* total;       // [0] = entries of `work`
+    const float* zero;
+    int nrt, ntx, nty, K;   // set by the launcher
+};
+constexpr int WA_NST = 5, WA_ADW = 2 * wino::ADW, WA_SDW = wino::PDW + WA_ADW, WA_NLD = wino::NPD + 2;
+constexpr int WA_LDS_BYTES = WA_NST * WA_SDW * 4;            // 140 KB
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p) {
+    using namespace wino;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kk = lane >> 4;
+    const int G = gridDim.x;
+    const int ntasks = p.total[0];
+    const int lb = blockIdx.x;
+    if (lb >= ntasks) return;
+    const int mytasks = (ntasks - lb + G - 1) / G;
+    const int nks = 32, nk = nks + (p.wsty ? 5 : 0);
+    const int HW = p.H * p.W;
+    constexpr unsigned SB = WA_SDW * 4, RING = WA_NST * SB;
+    const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
+
+    // ---- issue side ------------------------------------------------------------------------------------------------------------
+    unsigned voff[NPD];
+    const unsigned va = (unsigned)tid * 16u;
+    int it = lb, is = 0;
+    wino_u32x4 d_in, d_a0, d_a1, d_s0, d_s1;
+    unsigned so_in = 0, so_a = 0;
+    auto issue_task = [&]() {
+        const unsigned wk = p.work[it];
+        const int tile = wk & 0xFFFFF, pair = (wk >> 20) & 0x7FF;
+        const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, ib = tile / (p.ntx * p.nty);
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {
+            const int e = i * 512 + tid;
+            const int k4 = e / PS, rem = e - k4 * PS;
+            const int py = rem / PWP, px = rem - py * PWP;
+            const int y = y0 + py, x = x0 + px;
+            const bool ok = k4 < 4 && rem < PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
+        }
+        const int r0 = 2 * pair, r1 = 2 * pair + 1 < p.nrt ? 2 * pair + 1 : 2 * pair;      // (odd row-tile count: the last pair repeats)
+        d_in = wino_rsrc(p.actv + (long long)ib * p.K * HW, (unsigned)p.K * HW * 4u);
+        d_a0 = wino_rsrc(p.wpk + (long long)r0 * nks * 2048, (unsigned)nks * 8192u);
+        d_a1 = wino_rsrc(p.wpk + (long long)r1 * nks * 2048, (unsigned)nks * 8192u);
+        if (p.wsty) {
+            d_s0 = wino_rsrc(p.wsty + ((long long)ib * p.nrt + r0) * 5 * 2048, 5u * 8192u);
+            d_s1 = wino_rsrc(p.wsty + ((long long)ib * p.nrt + r1) * 5 * 2048, 5u * 8192u);
+        }
+        so_in = 0;
+        so_a = 0;
+    };
+    issue_task();
+    unsigned islot = lds0;
+    auto issue_part = [&](int part) {
+        const bool hid = is < nks;
+        const unsigned wb = islot + (unsigned)wave * 256u;
+        if (part < 3) {
+#pragma unroll
+            for (int i = 2 * part; i < 2 * part + 2; ++i) wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
+            return;
+        }
+        const unsigned wa = islot + PDW * 4u + (unsigned)wave * 1024u;
+        if (hid) {
+            wino_dma16(va, d_a0, so_a, wa);
+            wino_dma16(va, d_a1, so_a, wa + ADW * 4u);
+        } else {
+            wino_dma16(va, d_s0, so_a, wa);
+            wino_dma16(va, d_s1, so_a, wa + ADW * 4u);
+        }
+        islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
+        so_in += 16u * (unsigned)HW;
+        so_a += 8192u;
+        if (++is == nk) {
+            if (it + G < ntasks) {
+                it += G;
+                is = 0;
+                issue_task();
+            } else {
+                is = nk - 1;
+                so_in -= 16u * (unsigned)HW;
+                so_a -= 8192u;
+            }
+        } else if (is == nks) {
+            so_a = 0;
+        }
+    };
+
+    // ---- consumer side ---------------------------------------------------------------------------------------------------
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this wave's share of a task: quad group (wave & 3) + 4 * half of the tile's list, row tile 2 * pair + (wave >> 2)
+    struct Ctx { int tile, rt, qy, qx, boff; bool active, valid; };
+    auto task_ctx = [&](int t) {
+        Ctx c;
+        const unsigned wk = p.work[t];
+        c.tile = wk & 0xFFFFF;
+        const int pair = (wk >> 20) & 0x7FF, half = wk >> 31;
+        const int cnt = p.qcnt[c.tile];
+        const int grp = (wave & 3) + 4 * half;
+        c.rt = 2 * pair + (wave >> 2);
+        c.active = grp * 16 < cnt && c.rt < p.nrt;
+        const int qi = grp * 16 + n;
+        c.valid = c.active && qi < cnt;
+        const int q = p.qlist[(long long)c.tile * 128 + (qi < cnt ? qi : (cnt > 0 ? cnt - 1 : 0))];
+        c.qy = q >> 4;
+        c.qx = q & 15;
+        c.boff = kk * PS + (2 * c.qy) * PWP + 2 * c.qx;
+        return c;
+    };
+    Ctx cur = task_ctx(lb);
+    const int aoff = PDW + (wave >> 2) * ADW;               // this wave's A image inside a stage (floats)
+    auto load_raw = [&](unsigned slot, int boff, float (&d)[4][4]) {
+        const float* sp = reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + boff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 lo = *reinterpret_cast<const float2*>(sp + i * PWP), hi = *reinterpret_cast<const float2*>(sp + i * PWP + 2);
+            d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+        }
+    };
+    auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + aoff) + lane; };
+
+#pragma unroll
+    for (int j = 0; j < WA_NST - 1; ++j) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(part);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
+    __syncthreads();
+    float v[16], w[16];
+    f32x4 a0, a1;
+    {
+        float d[4][4];
+        load_raw(lds0, cur.boff, d);
+        wino_in_transform(d, v);
+        const f32x4* ap = a_ptr(lds0);
+        a0 = ap[0];
+        a1 = ap[64];
+    }
+    unsigned rslot = lds0;
+    bool after_epi = false;
+    int boff_next = cur.boff;                                  // patch origin of the lane's quad in the NEXT k-step's task
+    auto kstep = [&](bool act, float (&vc)[16], float (&vx)[16]) {
+        if (after_epi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
+        __syncthreads();
+        after_epi = false;
+        const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
+        const f32x4* ap = a_ptr(rslot);
+        const f32x4* apn = a_ptr(nslot);
+        float dn[4][4], t[4][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 c0 = a0, c1 = a1;
+            if (h < 3) {
+                a0 = ap[(2 * h + 2) * 64];
+                a1 = ap[(2 * h + 3) * 64];
+            } else {
+                a0 = apn[0];
+                a1 = apn[64];
+            }
+            if (h == 0) load_raw(nslot, boff_next, dn);
+            __builtin_amdgcn_sched_barrier(0);
+            if (h == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[0][j] = dn[0][j] - dn[2][j];
+                    t[1][j] = dn[1][j] + dn[2][j];
+                    t[2][j] = dn[2][j] - dn[1][j];
+                    t[3][j] = dn[1][j] - dn[3][j];
+                }
+            }
+            if (h >= 2) {
+#pragma unroll
+                for (int i = 2 * (h - 2); i < 2 * (h - 2) + 2; ++i) {
+                    vx[4 * i + 0] = t[i][0] - t[i][2];
+                    vx[4 * i + 1] = t[i][1] + t[i][2];
+                    vx[4 * i + 2] = t[i][2] - t[i][1];
+                    vx[4 * i + 3] = t[i][1] - t[i][3];
+                }
+            }
+            if (act) {
+                acc[4 * h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, vc[4 * h], acc[4 * h][0], 0, 0, 0);
+                acc[4 * h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, vc[4 * h], acc[4 * h][1], 0, 0, 0);
+                acc[4 * h + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.z, vc[4 * h + 1], acc[4 * h + 1][0], 0, 0, 0);
+                acc[4 * h + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.w, vc[4 * h + 1], acc[4 * h + 1][1], 0, 0, 0);
+                acc[4 * h + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, vc[4 * h + 2], acc[4 * h + 2][0], 0, 0, 0);
+                acc[4 * h + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, vc[4 * h + 2], acc[4 * h + 2][1], 0, 0, 0);
+                acc[4 * h + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.z, vc[4 * h + 3], acc[4 * h + 3][0], 0, 0, 0);
+                acc[4 * h + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.w, vc[4 * h + 3], acc[4 * h + 3][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_part(h);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rslot = nslot;
+    };
+    for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
+        const bool more = k + 1 < mytasks;
+        Ctx nxt = cur;
+        if (more) nxt = task_ctx(ct + G);                       // (its list entry is in flight during this task's k-steps)
+        for (int cs = 0; cs < nk; cs += 2) {                    // nk = 32 or 37: the odd tail is handled below
+            if (cs + 1 == nk) break;
+            kstep(cur.active, v, w);
+            if (cs + 2 == nk) boff_next = nxt.boff;
+            kstep(cur.active, w, v);
+        }
+        if (nk & 1) {                                           // last (odd) k-step: its prefetch belongs to the next task
+            boff_next = nxt.boff;
+            kstep(cur.active, v, w);
+#pragma unroll
+            for (int x = 0; x < 16; ++x) v[x] = w[x];
+        }
+        // ---- ACE epilogue of this wave's (quads, row tile) ------------------------------------------------------------------
+        if (cur.active) {
+            const int tile = cur.tile;
+            const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
+            const int y = ty * TH + 2 * cur.qy, x = tx * TW + 2 * cur.qx;
+            const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
+            const float* nzp = p.noise + (long long)b * p.noise_bstride + (long long)x * p.H + y;      // plane layout [W][H]
+            const float2 nz0 = *reinterpret_cast<const float2*>(nzp), nz1 = *reinterpret_cast<const float2*>(nzp + p.H);
+            // nz0 = (y, x), (y + 1, x);  nz1 = (y, x + 1), (y + 1, x + 1)
+            const int c0 = cur.rt * 16 + 4 * kk;
+            const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + c0), pb = *reinterpret_cast<const float4*>(p.bias_b + c0);
+            const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + c0), pd = *reinterpret_cast<const float4*>(p.bn_d + c0);
+            const float4 pn = *reinterpret_cast<const float4*>(p.nv + c0);
+            const float g_[4] = {pg.x, pg.y, pg.z, pg.w}, b_[4] = {pb.x, pb.y, pb.z, pb.w};
+            const float a_[4] = {pa.x, pa.y, pa.z, pa.w}, d_[4] = {pd.x, pd.y, pd.z, pd.w}, n_[4] = {pn.x, pn.y, pn.z, pn.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + i;
+                float M[16], g00, g01, g10, g11, e00, e01, e10, e11;
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][0][i];
+                wino_out_transform(M, g00, g01, g10, g11);
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][1][i];
+                wino_out_transform(M, e00, e01, e10, e11);
+                if (cur.valid && c < p.C) {
+                    const float* xp = p.x + ((long long)b * p.C + c) * xHW;
+                    float x00, x01, x10, x11;
+                    if (p.x_up) {
+                        x00 = x01 = x10 = x11 = xp[(y >> 1) * xW + (x >> 1)];
+                    } else {
+                        const float2 r0 = *reinterpret_cast<const float2*>(xp + y * xW + x), r1 = *reinterpret_cast<const float2*>(xp + (y + 1) * xW + x);
+                        x00 = r0.x; x01 = r0.y; x10 = r1.x; x11 = r1.y;
+                    }
+                    const float gb = 1.f + g_[i], bb = b_[i];
+                    float o00 = (a_[i] * x00 + n_[i] * nz0.x + d_[i]) * (gb + g00) + (bb + e00);
+                    float o01 = (a_[i] * x01 + n_[i] * nz1.x + d_[i]) * (gb + g01) + (bb + e01);
+                    float o10 = (a_[i] * x10 + n_[i] * nz0.y + d_[i]) * (gb + g10) + (bb + e10);
+                    float o11 = (a_[i] * x11 + n_[i] * nz1.y + d_[i]) * (gb + g11) + (bb + e11);
+                    if (p.act != ACT_NONE) {
+                        o00 = apply_act(o00, p.act); o01 = apply_act(o01, p.act);
+                        o10 = apply_act(o10, p.act); o11 = apply_act(o11, p.act);
+                    }
+                    float* op = p.out + ((long long)b * p.C + c) * HW + y * p.W + x;
+                    *reinterpret_cast<float2*>(op) = make_float2(o00, o01);
+                    *reinterpret_cast<float2*>(op + p.W) = make_float2(o10, o11);
+                }
+            }
+#pragma unroll
+            for (int x2 = 0; x2 < 16; ++x2)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        after_epi = true;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
+}
+
+inline bool wino_supported(int H, int W, int Cin) { return H % wino::TH == 0 && W % wino::TW == 0 && Cin % 8 == 0 && H >= 16; }
+
+inline void wino_fill_launch(WinoParams& p) {
+    p.nrt = (p.Cout + 31) / 32;
+    p.ntx = p.W / wino::TW;
+    p.nty = p.H / wino::TH;
+    p.ntiles = p.B * p.ntx * p.nty;
+    p.ntasks = p.ntiles * p.nrt;
+    p.nks = p.Cin / 4;
+    p.rb = p.nrt >= 4 ? 4 : p.nrt;
+    p.tbk = 32 / p.rb;
+}
+
+hipError_t conv_wino_plain(WinoParams p, hipStream_t s);     // conv_inst_wino.hip
+hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s);
+// wsty[b][rt][s][idx][lane][4] <- Winograd transform of the style LUT lut[(b*19 + j)][tap][gamma|beta][C] (exact-f32 layout)
+hipError_t wino_style_pack(const float* lut, float* wsty, int B, int C, hipStream_t s);
+// boundary quads of every 32 x 16 tile (from the interior map u5 of ace_classify) and the block tasks of conv_wino_ace
+hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int B, int H, int W, hipStream_t s);
+hipError_t wino_ace_worklist(const int* qcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s);
+
+}  // namespace chk

@@ -17,6 +17,7 @@
 #include "conv_ace_sparse.h"
 #include "conv_mfma.h"
 #include "conv_sh16.h"
+#include "conv_wino.h"
 #include "kernels.h"
 #include "sh16.h"
 
@@ -127,6 +128,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 cw.wscale = B.upload(sh16_wscale(*kexp));
             } else {
                 cw.wpk = B.upload(pack_A(r.cout, r.cin, r.ks, r.ks == 3 ? CK_KS3 : CK_KS1, getw));
+                if (wino && r.ks == 3 && r.cin % 8 == 0) cw.wino = B.upload(pack_wino_A(r.cout, r.cin, getw));
             }
             cw.Cout = r.cout;
             cw.Cin = r.cin;
@@ -388,6 +390,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     }
 
     amax_slots = static_cast<unsigned*>(B.dalloc(64 * sizeof(unsigned)));   // 2 per ACE: [output, style projections]
+    zero_page = static_cast<float*>(B.dalloc(256));
+    if (zero_page) (void)hipMemset(zero_page, 0, 256);
     splitk_cap = (long long)16 << 20;     // 64 MiB of split-K slabs (low-resolution layers only)
     splitk_ws = B.falloc((size_t)splitk_cap);
     n_aces = ace_index;
@@ -569,10 +573,12 @@ struct Runner {
     }
     template <class F>
     void timed(int kind, double flops, double bytes, F launch) { timed(kind, flops, bytes, nullptr, 0.0, 0.0, 0.0, 0.0, launch); }
+    double next_flops_exec = -1.0;      // set before a timed() whose matrix cores run fewer FLOPs than the dense count
     template <class F>
     void timed(int kind, double flops, double bytes, const int* sp_stat, double sp_unit, double sp_bytes_px, double sp_bytes_fixed,
                double sp_npix, F launch) {
         if (!m.prof_on) {
+            next_flops_exec = -1.0;
             launch();
             return;
         }
@@ -585,6 +591,8 @@ struct Runner {
         r.sp_bytes_px = sp_bytes_px;
         r.sp_bytes_fixed = sp_bytes_fixed;
         r.sp_npix = sp_npix;
+        r.flops_exec = next_flops_exec;
+        next_flops_exec = -1.0;
         r.e0 = ev();
         r.e1 = ev();
         check(hipEventRecord(r.e0, st), "hipEventRecord");
@@ -913,6 +921,9 @@ struct Runner {
         return !(m.dbg & 32) && w.KS == 3 && r >= 32 &&
                !(((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192);
     }
+    bool use_wino(const ConvW& w, int r) const {
+        return m.wino && !m.use_sh16 && w.wino && w.KS == 3 && wino_supported(r, r, w.Cin);
+    }
     // `prod` / `prod2`: the ACEs that wrote `in` / `in2` (their slots hold the scale in effect)
     void conv(const ConvW& w, const float* in, const AceW& prod, float* out, int r, const float* res, int res_up,
               const ConvW* w2 = nullptr, const float* in2 = nullptr, const AceW* prod2 = nullptr) {
@@ -945,6 +956,28 @@ struct Runner {
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS, cin2 = w2 ? w2->Cin : 0;
+        if (use_wino(w, r) && !w2) {
+            // Winograd F(2x2,3x3) on the exact-f32 matrix cores: 16 MFMA products per quad and channel instead of 36
+            WinoParams q{};
+            q.in = in;
+            q.wpk = w.wino;
+            q.out = out;
+            q.B = B;
+            q.Cin = w.Cin;
+            q.Cout = w.Cout;
+            q.H = r;
+            q.W = r;
+            q.bias = w.bias;
+            q.res = res;
+            q.res_up = res_up;
+            q.act = ACT_NONE;
+            q.zero = m.zero_page;
+            next_flops_exec = 2.0 * w.Cout * w.Cin * 16.0 * npix / 4.0;
+            timed(0, 2.0 * w.Cout * w.Cin * 9.0 * npix,
+                  4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * 16.0),
+                  [&] { check(conv_wino_plain(q, st), "conv (winograd)"); });
+            return;
+        }
         timed(0, 2.0 * w.Cout * (w.Cin * k2 + cin2) * npix,
               4.0 * (npix * (w.Cin + cin2) + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * (w.Cin * k2 + cin2)), [&] {
                   if (m.use_sh16) check(conv_sh16_plain(p, w.KS, st), "conv");
@@ -1022,7 +1055,8 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
                 noff += rr;
                 R.tap_sh16(b.name + ".hs", hs, b.fin, rr, b.ace_s);
                 // the 1x1 shortcut conv is folded into conv_1 (extra K chunks on a second input) unless a test taps its output
-                fuse_s = R.can_fuse_1x1(b.conv_1, r) && !taps.count(b.name + ".xs");
+                // (not on the Winograd path: there the shortcut stays a direct 1x1 GEMM whose output conv_1 adds as its residual)
+                fuse_s = R.can_fuse_1x1(b.conv_1, r) && !taps.count(b.name + ".xs") && !R.use_wino(b.conv_1, r);
                 if (!fuse_s) {
                     R.conv(b.conv_s, hs, b.ace_s, xs, r, nullptr, 0);
                     R.tap_c4(b.name + ".xs", xs, b.fout, rr);

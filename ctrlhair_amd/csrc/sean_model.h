@@ -17,6 +17,7 @@ struct ConvW {
     float* wpk = nullptr;
     float* bias = nullptr;
     float* wscale = nullptr;                    // f16x3 path: per-row 2^-k undoing the weight scaling (sh16.h)
+    float* wino = nullptr;                      // exact-f32 path, 3x3: Winograd F(2x2,3x3) image U = G g G^T (conv_wino.h)
     int Cout = 0, Cin = 0, KS = 0;
 };
 
@@ -51,6 +52,7 @@ struct ProfRec {
     hipEvent_t e0, e1;
     int kind;       // 0 plain conv, 1 ACE conv, 2 LUT gemm, 3 interior pass of a sparse ACE (table build + elementwise kernel)
     double flops, bytes;            // flops: the dense evaluation of the layer (every pixel through the conv)
+    double flops_exec = -1.0;       // FLOPs the matrix cores ran when they differ from `flops` (Winograd convs: 16 / 36); < 0: = flops
     const int* sp_stat = nullptr;   // sparse ACE launch: SparseWork::total of its work list (read back at ch_profile_read)
     double sp_flops_unit = 0.0;     //   executed FLOPs = sp_stat[3] * sp_flops_unit
     double sp_bytes_px = 0.0, sp_bytes_fixed = 0.0, sp_npix = 0.0;   // algorithmic bytes = fixed + per-pixel x (boundary pixels
@@ -100,6 +102,9 @@ struct SeanModel {
     int n_aces = 0;
     // exact SPADE-interior reduction (ace_sparse.h): per resolution level (index = log2(res_div)) the classification buffers
     // and one work list per distinct number of 64-row tiles among the level's ACEs; gtab: [max_batch][19][2][C max]
+    int wino = 1;                              // option "sean.wino": exact-f32 path, 3x3 convs as Winograd F(2x2,3x3) on the f32
+                                               //   matrix cores (conv_wino.h); 0 = direct evaluation (conv_mfma.h)
+    float* zero_page = nullptr;                // 256 bytes of zeros
     int sparse = 1;                            // option "sean.sparse" (0 = every pixel through the conv)
     int sparse_min_r = 64;                     // option "sean.sparse_min": smallest resolution served by the sparse path
     int sh16_compact = 1;                      // option "sean.sh16_compact": f16x3 path, 1 = pixel-level compaction inside the

@@ -1,0 +1,160 @@
+// tools/wino_bench.hip -- stand-alone check + timing of the Winograd F(2x2,3x3) exact-f32 MFMA conv (conv_wino.h) against a
+// naive direct f32 convolution on the GPU, over the ResBlock conv shapes of the ngf = 64 generator at 512^2, B = 16.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino_bench.hip -o tools/wino_bench.bin ; run on the GPU box.
+//   wino_bench.bin            all shapes (check + timing)
+//   wino_bench.bin quick      small shapes only (check)
+#define WINO_ABLATE 1
+#include "../ctrlhair_amd/csrc/conv_inst_wino.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace chk;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+// direct conv, one thread per output, f32 fma chain in (ci, tap) order, double accumulation option off
+__global__ void ref_conv_kernel(const float* in, const float* w, const float* bias, const float* res, int res_up, const float* in2,
+                                const float* w2, int Cin2, float* out, int B, int Cin, int Cout, int H, int W) {
+    const long long n = (long long)B * Cout * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), co = (int)((i / ((long long)W * H)) % Cout), b = (int)(i / ((long long)W * H * Cout));
+        double acc = bias ? bias[co] : 0.f;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    acc += (double)w[((long long)co * Cin + ci) * 9 + t] * in[(((long long)b * Cin + ci) * H + yy) * W + xx];
+            }
+        for (int ci = 0; ci < Cin2; ++ci) acc += (double)w2[(long long)co * Cin2 + ci] * in2[(((long long)b * Cin2 + ci) * H + y) * W + x];
+        if (res) acc += res[(((long long)b * Cout + co) * (H >> res_up) + (y >> res_up)) * (W >> res_up) + (x >> res_up)];
+        out[i] = (float)acc;
+    }
+}
+
+static float frand(unsigned& s) {
+    s = s * 1664525u + 1013904223u;
+    return ((s >> 8) & 0xFFFF) / 32768.f - 1.f;
+}
+
+struct Shape { int B, Cin, Cout, H, Cin2, res; const char* name; };   // res: 0 none, 1 same size, 2 upsampled
+
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const int dbg = argc > 2 && !strcmp(argv[1], "dbg") ? atoi(argv[2]) : 0;      // timing ablations (wrong results)
+    const Shape all[] = {
+        {2, 16, 16, 32, 0, 0, "tiny"}, {3, 32, 48, 64, 0, 1, "tiny res, ragged rows"}, {1, 8, 32, 32, 0, 2, "tiny res_up"},
+        {2, 64, 64, 64, 0, 1, "small res"},
+        {16, 1024, 1024, 32, 0, 0, "G_middle conv_0"}, {16, 1024, 1024, 32, 0, 1, "G_middle conv_1 (+x)"},
+        {16, 1024, 512, 64, 0, 0, "up_0 conv_0"}, {16, 512, 512, 64, 0, 1, "up_0 conv_1 (+xs)"},
+        {16, 512, 256, 128, 0, 0, "up_1 conv_0"}, {16, 256, 256, 128, 0, 1, "up_1 conv_1 (+xs)"},
+        {16, 256, 128, 256, 0, 0, "up_2 conv_0"}, {16, 128, 128, 256, 0, 1, "up_2 conv_1 (+xs)"},
+        {16, 128, 64, 512, 0, 0, "up_3 conv_0"}, {16, 64, 64, 512, 0, 1, "up_3 conv_1 (+xs)"},
+    };
+    float* d_zero;
+    CK(hipMalloc(&d_zero, 256));
+    CK(hipMemset(d_zero, 0, 256));
+    unsigned long long* d_stamps;
+    CK(hipMalloc(&d_stamps, 256 * 8 * 4 * 8));
+    double tot_ms = 0, tot_fl = 0;
+    for (const Shape& c : all) {
+        if (quick && c.B * (long long)c.H * c.H * c.Cout > (1 << 22)) continue;
+        if (dbg && c.B < 16) continue;
+        const int B = c.B, Cin = c.Cin, Cout = c.Cout, H = c.H, W = c.H, Cin2 = c.Cin2;
+        const size_t nin = (size_t)B * Cin * H * W, nout = (size_t)B * Cout * H * W, nin2 = (size_t)B * Cin2 * H * W;
+        const int rh = c.res == 2 ? H / 2 : H;
+        const size_t nres = c.res ? (size_t)B * Cout * rh * rh : 0;
+        unsigned seed = 12345u + Cin * 7 + Cout;
+        std::vector<float> hin(nin), hw((size_t)Cout * Cin * 9), hb(Cout), hin2(nin2), hw2((size_t)Cout * Cin2), hres(nres);
+        const float ws = 1.f / sqrtf((float)Cin * 9.f);
+        for (auto& v : hin) v = frand(seed);
+        for (auto& v : hw) v = frand(seed) * ws;
+        for (auto& v : hb) v = frand(seed) * 0.1f;
+        for (auto& v : hin2) v = frand(seed);
+        for (auto& v : hw2) v = frand(seed) / sqrtf((float)(Cin2 ? Cin2 : 1));
+        for (auto& v : hres) v = frand(seed);
+        const float* wp = hw.data();
+        auto get = [&](int row, int ci, int t) { return wp[((size_t)row * Cin + ci) * 9 + t]; };
+        std::vector<float> pk = pack_wino_A(Cout, Cin, get), pk2;
+        const float* w2p = hw2.data();
+        float *d_in, *d_w, *d_b, *d_pk, *d_out, *d_ref, *d_in2 = nullptr, *d_w2 = nullptr, *d_pk2 = nullptr, *d_res = nullptr;
+        CK(hipMalloc(&d_in, nin * 4 + 256)); CK(hipMalloc(&d_w, hw.size() * 4)); CK(hipMalloc(&d_b, Cout * 4));
+        CK(hipMalloc(&d_pk, pk.size() * 4)); CK(hipMalloc(&d_out, nout * 4)); CK(hipMalloc(&d_ref, nout * 4));
+        CK(hipMemcpy(d_in, hin.data(), nin * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_b, hb.data(), Cout * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_pk, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        if (Cin2) {
+            CK(hipMalloc(&d_in2, nin2 * 4)); CK(hipMalloc(&d_w2, hw2.size() * 4)); CK(hipMalloc(&d_pk2, pk2.size() * 4));
+            CK(hipMemcpy(d_in2, hin2.data(), nin2 * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_w2, hw2.data(), hw2.size() * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_pk2, pk2.data(), pk2.size() * 4, hipMemcpyHostToDevice));
+        }
+        if (nres) {
+            CK(hipMalloc(&d_res, nres * 4));
+            CK(hipMemcpy(d_res, hres.data(), nres * 4, hipMemcpyHostToDevice));
+        }
+        CK(hipMemset(d_out, 0xFF, nout * 4));
+        WinoParams p{};
+        p.in = d_in; p.wpk = d_pk; p.out = d_out; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+        p.bias = d_b; p.res = d_res; p.res_up = c.res == 2 ? 1 : 0; p.act = ACT_NONE;
+        p.zero = d_zero; p.dbg = dbg; p.stamps = d_stamps;
+        CK(conv_wino_plain(p, 0));
+        CK(hipDeviceSynchronize());
+        // reference (subsampled batch for the big shapes: samples 0 and B-1 only)
+        const bool big = (double)nout * Cin * 9 > 4e11;
+        const int Bref = big ? 1 : B;
+        double maxd = 0, maxr = 0;
+        for (int pass = 0; pass < (big ? 2 : 1); ++pass) {
+            const int b0 = pass == 0 ? 0 : B - 1;
+            hipLaunchKernelGGL(ref_conv_kernel, dim3(4096), dim3(256), 0, 0, d_in + (size_t)b0 * Cin * H * W, d_w, d_b,
+                               d_res ? d_res + (size_t)b0 * Cout * rh * rh : nullptr, p.res_up,
+                               d_in2 ? d_in2 + (size_t)b0 * Cin2 * H * W : nullptr, d_w2, Cin2, d_ref, Bref, Cin, Cout, H, W);
+            CK(hipDeviceSynchronize());
+            const size_t nn = (size_t)Bref * Cout * H * W;
+            std::vector<float> ho(nn), hr(nn);
+            CK(hipMemcpy(ho.data(), d_out + (size_t)b0 * Cout * H * W, nn * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hr.data(), d_ref, nn * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nn; ++i) {
+                const double d = fabs((double)ho[i] - hr[i]);
+                if (!(d <= maxd)) maxd = d;      // NaN-propagating
+                if (fabs(hr[i]) > maxr) maxr = fabs(hr[i]);
+            }
+        }
+        const double fl = 2.0 * B * H * W * (double)Cout * (Cin * 9.0 + Cin2);
+        float ms = 0;
+        if (!quick) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            const int it = 5;
+            CK(conv_wino_plain(p, 0));
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < it; ++i) CK(conv_wino_plain(p, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= it;
+            tot_ms += ms * (strstr(c.name, "G_middle") ? 2 : 1);
+            tot_fl += fl * (strstr(c.name, "G_middle") ? 2 : 1);
+        }
+        {
+            std::vector<unsigned long long> hs(256 * 8 * 4);
+            CK(hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+            double a[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 256 * 8; ++i) for (int j = 0; j < 4; ++j) a[j] += (double)hs[i * 4 + j];
+            const double nk = (double)(Cin / 4 + Cin2 / 4) * ((double)B * (H / 16) * (W / 32) * ((Cout + 31) / 32)) * 8;   // wave k-steps
+            if (dbg & 16) printf("   stamps (s_memtime ticks per wave k-step): barrier %.0f  vmcnt wait %.0f  mfma groups %.0f  tail(epilogue incl.) %.0f\n", a[0] / nk, a[3] / nk, a[1] / nk, a[2] / nk);
+        }
+        const double exec = 2.0 * B * (H / 2) * (W / 2) * (double)Cout * (Cin * 16.0 + Cin2 * 4.0);
+        printf("%-28s B%2d %4d->%4d (+%4d) %3d^2  maxdiff %.3e (max|ref| %.2f)  %s  %8.3f ms  dense %6.1f TF/s  executed %6.1f TF/s\n", c.name, B,
+               Cin, Cout, Cin2, H, maxd, maxr, maxd <= 2e-5 * (maxr > 1 ? maxr : 1) ? "OK  " : "FAIL", ms, ms > 0 ? fl / ms * 1e-9 : 0.0,
+               ms > 0 ? exec / ms * 1e-9 : 0.0);
+        fflush(stdout);
+        hipFree(d_in); hipFree(d_w); hipFree(d_b); hipFree(d_pk); hipFree(d_out); hipFree(d_ref);
+        if (d_in2) { hipFree(d_in2); hipFree(d_w2); hipFree(d_pk2); }
+        if (d_res) hipFree(d_res);
+    }
+    if (!quick) printf("sum over the ResBlock convs of one step (G_middle x2): %.2f ms, dense-equivalent %.1f TF/s\n", tot_ms, tot_fl / tot_ms * 1e-9);
+    return 0;
+}
