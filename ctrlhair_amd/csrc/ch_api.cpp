@@ -430,6 +430,7 @@ int ch_profile_read_ex(ch_handle* h, int kind, int* launches, double* total_ms, 
                 h->sean.ev_pool.push_back(r.e1);
             }
             h->sean.prof.clear();
+            h->sean.prof_stats_used = 0;
         }
     }
     if (launches) *launches = n;

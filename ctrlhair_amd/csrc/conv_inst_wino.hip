@@ -40,10 +40,10 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
 
 
 hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s) {
-    if (p.H % wino::TH || p.W % wino::TW || !p.zero || !p.qlist || !p.qcnt || !p.work || !p.total || (p.C & 3)) return hipErrorInvalidValue;
+    if (p.H % WA_TH || p.W % wino::TW || !p.zero || !p.qlist || !p.qcnt || !p.work || !p.total || (p.C & 3)) return hipErrorInvalidValue;
     p.nrt = (p.C + 15) / 16;
     p.ntx = p.W / wino::TW;
-    p.nty = p.H / wino::TH;
+    p.nty = p.H / WA_TH;
     p.K = 128 + (p.wsty ? 20 : 0);
     static bool d0[64] = {};
     hipError_t e = wino_attr(wino_ace_kernel<0>, WA_LDS_BYTES, d0);
@@ -52,43 +52,52 @@ hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---- boundary quads of a tile of 32 x 16 pixels: one block of 128 threads = the tile's 16 x 8 quads, ordered compaction ----------
-__global__ __launch_bounds__(128) void wino_quad_list_kernel(const uint8_t* __restrict__ u5, uint8_t* __restrict__ qlist, int* __restrict__ qcnt,
-                                                             int H, int W, int ntx, int nty) {
-    __shared__ int wc[2];
+// ---- boundary quads of a tile of 32 x 32 pixels: one block of 256 threads = the tile's 16 x 16 quads, ordered compaction ---------
+__global__ __launch_bounds__(256) void wino_quad_list_kernel(const uint8_t* __restrict__ u5, uint8_t* __restrict__ qlist, int* __restrict__ qcnt,
+                                                             int* __restrict__ pcnt, int H, int W, int ntx, int nty) {
+    __shared__ int wc[4], pc[4];
     const int tile = blockIdx.x, tid = threadIdx.x;
     const int b = tile / (ntx * nty), tr = tile % (ntx * nty);
-    const int y = (tr / ntx) * 16 + 2 * (tid >> 4), x = (tr % ntx) * 32 + 2 * (tid & 15);
-    const uint8_t* up = u5 + ((long long)b * H + y) * W + x;
-    const bool bnd = up[0] == 255 || up[1] == 255 || up[W] == 255 || up[W + 1] == 255;
+    const int y = (tr / ntx) * 32 + 2 * (tid >> 4), x = (tr % ntx) * 32 + 2 * (tid & 15);
+    int npx = 4;                                               // boundary pixels of the quad (u5 == nullptr: every pixel is one)
+    if (u5) {
+        const uint8_t* up = u5 + ((long long)b * H + y) * W + x;
+        npx = (up[0] == 255) + (up[1] == 255) + (up[W] == 255) + (up[W + 1] == 255);
+    }
+    const bool bnd = npx > 0;
     const unsigned long long m = __ballot(bnd);
     const int lane = tid & 63, wave = tid >> 6;
-    if (lane == 0) wc[wave] = __popcll(m);
+    int ps = npx;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+    if (lane == 0) { wc[wave] = __popcll(m); pc[wave] = ps; }
     __syncthreads();
-    const int base = wave ? wc[0] : 0;
-    if (bnd) qlist[(long long)tile * 128 + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
-    if (tid == 0) qcnt[tile] = wc[0] + wc[1];
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wc[w];
+    if (bnd) qlist[(long long)tile * 256 + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    if (tid == 0) { qcnt[tile] = wc[0] + wc[1] + wc[2] + wc[3]; pcnt[tile] = pc[0] + pc[1] + pc[2] + pc[3]; }
 }
-hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int B, int H, int W, hipStream_t s) {
-    if (H % 16 || W % 32) return hipErrorInvalidValue;
-    const int ntx = W / 32, nty = H / 16;
-    hipLaunchKernelGGL(wino_quad_list_kernel, dim3(B * ntx * nty), dim3(128), 0, s, u5, qlist, qcnt, H, W, ntx, nty);
+hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int* pcnt, int B, int H, int W, hipStream_t s) {
+    if (H % 32 || W % 32) return hipErrorInvalidValue;
+    const int ntx = W / 32, nty = H / 32;
+    hipLaunchKernelGGL(wino_quad_list_kernel, dim3(B * ntx * nty), dim3(256), 0, s, u5, qlist, qcnt, pcnt, H, W, ntx, nty);
     return hipGetLastError();
 }
 
-// ---- block tasks of conv_wino_ace: per tile ceil(quads / 64) halves x ceil(nrt / 2) row pairs; one block of 1024 threads scans ------
-// total: [0] entries, [1] boundary quads, [2] 16-quad groups, [3] groups x row tiles (wave tasks: x 32 rows x 16 quads of accumulators)
-__global__ __launch_bounds__(1024) void wino_ace_worklist_kernel(const int* __restrict__ qcnt, int ntiles, int nrt, unsigned* __restrict__ work,
-                                                                 int* __restrict__ total) {
+// ---- block tasks of conv_wino_ace: per tile ceil(quads / 64) parts x ceil(nrt / 2) row pairs; one block of 1024 threads scans -------
+// total: [0] entries, [1] boundary quads, [2] 16-quad groups, [3] groups x row tiles (wave tasks: x 32 rows x 16 quads of accumulators),
+// [4..7] the same block with the boundary PIXELS in place of the quads (the layout the profiling records of ace_sparse.h expect)
+__global__ __launch_bounds__(1024) void wino_ace_worklist_kernel(const int* __restrict__ qcnt, const int* __restrict__ pcnt, int ntiles, int nrt,
+                                                                 unsigned* __restrict__ work, int* __restrict__ total) {
     __shared__ int wsum[16];
     __shared__ int carry;
-    __shared__ int stat[3];
+    __shared__ int stat[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npair = (nrt + 1) >> 1;
     if (tid == 0) carry = 0;
-    if (tid < 3) stat[tid] = 0;
+    if (tid < 4) stat[tid] = 0;
     __syncthreads();
-    int s_q = 0, s_g = 0, s_w = 0;
+    int s_q = 0, s_g = 0, s_w = 0, s_p = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 1024) {
         const int tile = t0 + tid;
         int ne = 0, halves = 0;
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(1024) void wino_ace_worklist_kernel(const int* __re
             halves = (c + 63) >> 6;
             ne = halves * npair;
             s_q += c;
+            s_p += pcnt[tile];
             s_g += g;
             s_w += g * nrt;
         }
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(1024) void wino_ace_worklist_kernel(const int* __re
         for (int w = 0; w < wave; ++w) base += wsum[w];
         int o = base + v - ne;
         for (int h = 0; h < halves; ++h)
-            for (int pr = 0; pr < npair; ++pr) work[o++] = (unsigned)tile | ((unsigned)pr << 20) | ((unsigned)h << 31);
+            for (int pr = 0; pr < npair; ++pr) work[o++] = (unsigned)tile | ((unsigned)pr << 20) | ((unsigned)h << 30);
         __syncthreads();
         if (tid == 1023) carry = base + v;
         __syncthreads();
@@ -120,17 +130,19 @@ __global__ __launch_bounds__(1024) void wino_ace_worklist_kernel(const int* __re
     atomicAdd(&stat[0], s_q);
     atomicAdd(&stat[1], s_g);
     atomicAdd(&stat[2], s_w);
+    atomicAdd(&stat[3], s_p);
     __syncthreads();
     if (tid == 0) {
-        total[0] = carry;
+        total[0] = total[4] = carry;
         total[1] = stat[0];
-        total[2] = stat[1];
-        total[3] = stat[2];
+        total[5] = stat[3];
+        total[2] = total[6] = stat[1];
+        total[3] = total[7] = stat[2];
     }
 }
-hipError_t wino_ace_worklist(const int* qcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s) {
-    if (ntiles >= (1 << 20) || nrt >= (1 << 11)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(wino_ace_worklist_kernel, dim3(1), dim3(1024), 0, s, qcnt, ntiles, nrt, work, total);
+hipError_t wino_ace_worklist(const int* qcnt, const int* pcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s) {
+    if (ntiles >= (1 << 20) || nrt >= (1 << 11)) return hipErrorInvalidValue;      // (pairs < 2^10, parts < 4)
+    hipLaunchKernelGGL(wino_ace_worklist_kernel, dim3(1), dim3(1024), 0, s, qcnt, pcnt, ntiles, nrt, work, total);
     return hipGetLastError();
 }
 

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             const int y = y0 + py, x = x0 + px;
             const bool ok = k4 < 4 && rem < PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
+            if (WINO_DBG(p, 64) && (py % 5) >= 2) voff[i] = 0x80000000u;       // (ablation: 60 % of the patch rows not fetched)
         }
         d_in = wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
         d_a = wino_rsrc(p.wpk + (long long)irt * p.nks * 2048, (unsigned)p.nks * 8192u);
@@ -449,9 +450,11 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
 //     the style term  sum_t P[(sample, label(p + t)), t]  is the 3x3 conv of the one-hot map with per-SAMPLE weights P (the
 //     style LUT), so it runs on the matrix cores as 5 more k-steps whose A images come from a per-sample buffer (wino_style_pack,
 //     Winograd-transformed LUT) -- the 18 gathers per (pixel, 4-channel run) of the direct kernel's epilogue are gone.
-//   * A block task = one spatial tile of 32 x 16 pixels x a PAIR of row tiles x up to 64 of its boundary quads: waves 0-3 / 4-7
+//   * A block task = one spatial tile of 32 x 32 pixels x a PAIR of row tiles x up to 64 of its boundary quads: waves 0-3 / 4-7
 //     take the two row tiles, wave (w & 3) the w-th group of 16 listed quads (B-fragment addresses are per lane anyway);
-//     waves without quads only take part in the staging.  A tile with more than 64 boundary quads gets a second task.
+//     waves without quads only take part in the staging.  A tile with more than 64 boundary quads gets up to four tasks.
+//     (Tiles of 32 x 16 left half of the waves idle on sparse levels -- about 30 boundary quads per tile at 512^2 on the
+//     benchmark labels -- and a k-step costs nearly the same with four busy waves as with eight: 5.4 -> ms per C = 128 ACE.)
 struct WinoAceParams {
     const float* actv;      // [B][K][H][W]: K = 128 (+ 20 one-hot planes when wsty is set)
     const float* wpk;       // pack_wino_A image of the (gamma | beta) rows over the 128 hidden channels
@@ -463,15 +466,18 @@ struct WinoAceParams {
     const float *bias_g, *bias_b, *bn_a, *bn_d, *nv;
     const float* noise;     // plane base of this ACE, sample stride noise_bstride, layout [W][H]
     long long noise_bstride;
-    const uint8_t* qlist;   // [ntiles][128] boundary quads of each tile (qy * 16 + qx), raster order
+    const uint8_t* qlist;   // [ntiles][256] boundary quads of each tile of 32 x 32 pixels (qy * 16 + qx), raster order
     const int* qcnt;        // [ntiles]
-    const unsigned* work;   // tile | row pair << 20 | half << 31
+    const unsigned* work;   // tile | row pair << 20 | part << 30 (part = which 64 of the tile's listed quads)
     const int* total;       // [0] = entries of `work`
     const float* zero;
     int nrt, ntx, nty, K;   // set by the launcher
 };
-constexpr int WA_NST = 5, WA_ADW = 2 * wino::ADW, WA_SDW = wino::PDW + WA_ADW, WA_NLD = wino::NPD + 2;
-constexpr int WA_LDS_BYTES = WA_NST * WA_SDW * 4;            // 140 KB
+// tiles of 32 x 32 pixels (16 x 16 quads) here: a sparse tile must hold enough boundary quads to fill the block's waves
+constexpr int WA_TH = 32, WA_PROWS = WA_TH + 2, WA_PS = 1248;      // plane stride 1248 = 19 * 64 + 32 floats (34 * 36 = 1224 used)
+constexpr int WA_NPD = 10, WA_PDW = WA_NPD * 512;                   // 10 patch DMA instructions per thread per k-step
+constexpr int WA_NST = 4, WA_ADW = 2 * wino::ADW, WA_SDW = WA_PDW + WA_ADW, WA_NLD = WA_NPD + 2;
+constexpr int WA_LDS_BYTES = WA_NST * WA_SDW * 4;            // 144 KB
 
 template <int DUMMY>
 __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p) {
@@ -491,23 +497,23 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
 
     // ---- issue side ------------------------------------------------------------------------------------------------------------
-    unsigned voff[NPD];
+    unsigned voff[WA_NPD];
     const unsigned va = (unsigned)tid * 16u;
     int it = lb, is = 0;
     wino_u32x4 d_in, d_a0, d_a1, d_s0, d_s1;
     unsigned so_in = 0, so_a = 0;
     auto issue_task = [&]() {
         const unsigned wk = p.work[it];
-        const int tile = wk & 0xFFFFF, pair = (wk >> 20) & 0x7FF;
+        const int tile = wk & 0xFFFFF, pair = (wk >> 20) & 0x3FF;
         const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, ib = tile / (p.ntx * p.nty);
-        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        const int y0 = ty * WA_TH - 1, x0 = tx * TW - 1;
 #pragma unroll
-        for (int i = 0; i < NPD; ++i) {
+        for (int i = 0; i < WA_NPD; ++i) {
             const int e = i * 512 + tid;
-            const int k4 = e / PS, rem = e - k4 * PS;
+            const int k4 = e / WA_PS, rem = e - k4 * WA_PS;
             const int py = rem / PWP, px = rem - py * PWP;
             const int y = y0 + py, x = x0 + px;
-            const bool ok = k4 < 4 && rem < PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const bool ok = k4 < 4 && rem < WA_PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
         }
         const int r0 = 2 * pair, r1 = 2 * pair + 1 < p.nrt ? 2 * pair + 1 : 2 * pair;      // (odd row-tile count: the last pair repeats)
@@ -526,12 +532,12 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     auto issue_part = [&](int part) {
         const bool hid = is < nks;
         const unsigned wb = islot + (unsigned)wave * 256u;
-        if (part < 3) {
+        if (part < 3) {                                     // 3 + 3 + 4 patch DMAs
 #pragma unroll
-            for (int i = 2 * part; i < 2 * part + 2; ++i) wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
+            for (int i = 3 * part; i < (part == 2 ? WA_NPD : 3 * part + 3); ++i) wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
             return;
         }
-        const unsigned wa = islot + PDW * 4u + (unsigned)wave * 1024u;
+        const unsigned wa = islot + WA_PDW * 4u + (unsigned)wave * 1024u;
         if (hid) {
             wino_dma16(va, d_a0, so_a, wa);
             wino_dma16(va, d_a1, so_a, wa + ADW * 4u);
@@ -570,21 +576,21 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
         Ctx c;
         const unsigned wk = p.work[t];
         c.tile = wk & 0xFFFFF;
-        const int pair = (wk >> 20) & 0x7FF, half = wk >> 31;
+        const int pair = (wk >> 20) & 0x3FF, part = wk >> 30;
         const int cnt = p.qcnt[c.tile];
-        const int grp = (wave & 3) + 4 * half;
+        const int grp = (wave & 3) + 4 * part;
         c.rt = 2 * pair + (wave >> 2);
         c.active = grp * 16 < cnt && c.rt < p.nrt;
         const int qi = grp * 16 + n;
         c.valid = c.active && qi < cnt;
-        const int q = p.qlist[(long long)c.tile * 128 + (qi < cnt ? qi : (cnt > 0 ? cnt - 1 : 0))];
+        const int q = p.qlist[(long long)c.tile * 256 + (qi < cnt ? qi : (cnt > 0 ? cnt - 1 : 0))];
         c.qy = q >> 4;
         c.qx = q & 15;
-        c.boff = kk * PS + (2 * c.qy) * PWP + 2 * c.qx;
+        c.boff = kk * WA_PS + (2 * c.qy) * PWP + 2 * c.qx;
         return c;
     };
     Ctx cur = task_ctx(lb);
-    const int aoff = PDW + (wave >> 2) * ADW;               // this wave's A image inside a stage (floats)
+    const int aoff = WA_PDW + (wave >> 2) * ADW;               // this wave's A image inside a stage (floats)
     auto load_raw = [&](unsigned slot, int boff, float (&d)[4][4]) {
         const float* sp = reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + boff;
 #pragma unroll
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     unsigned rslot = lds0;
     bool after_epi = false;
     int boff_next = cur.boff;                                  // patch origin of the lane's quad in the NEXT k-step's task
-    auto kstep = [&](bool act, float (&vc)[16], float (&vx)[16]) {
+    auto kstep = [&](bool act, bool rd, float (&vc)[16], float (&vx)[16]) {
         if (after_epi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
         __syncthreads();
@@ -627,14 +633,16 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const f32x4 c0 = a0, c1 = a1;
-            if (h < 3) {
-                a0 = ap[(2 * h + 2) * 64];
-                a1 = ap[(2 * h + 3) * 64];
-            } else {
-                a0 = apn[0];
-                a1 = apn[64];
+            if (rd) {                                           // (a wave without quads in this task and the next skips its operand reads)
+                if (h < 3) {
+                    a0 = ap[(2 * h + 2) * 64];
+                    a1 = ap[(2 * h + 3) * 64];
+                } else {
+                    a0 = apn[0];
+                    a1 = apn[64];
+                }
+                if (h == 0) load_raw(nslot, boff_next, dn);
             }
-            if (h == 0) load_raw(nslot, boff_next, dn);
             __builtin_amdgcn_sched_barrier(0);
             if (h == 1) {
 #pragma unroll
@@ -674,15 +682,16 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
         const bool more = k + 1 < mytasks;
         Ctx nxt = cur;
         if (more) nxt = task_ctx(ct + G);                       // (its list entry is in flight during this task's k-steps)
+        const bool rd = cur.active || nxt.active;
         for (int cs = 0; cs < nk; cs += 2) {                    // nk = 32 or 37: the odd tail is handled below
             if (cs + 1 == nk) break;
-            kstep(cur.active, v, w);
+            kstep(cur.active, rd, v, w);
             if (cs + 2 == nk) boff_next = nxt.boff;
-            kstep(cur.active, w, v);
+            kstep(cur.active, rd, w, v);
         }
         if (nk & 1) {                                           // last (odd) k-step: its prefetch belongs to the next task
             boff_next = nxt.boff;
-            kstep(cur.active, v, w);
+            kstep(cur.active, rd, v, w);
 #pragma unroll
             for (int x = 0; x < 16; ++x) v[x] = w[x];
         }
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
         if (cur.active) {
             const int tile = cur.tile;
             const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
-            const int y = ty * TH + 2 * cur.qy, x = tx * TW + 2 * cur.qx;
+            const int y = ty * WA_TH + 2 * cur.qy, x = tx * TW + 2 * cur.qx;
             const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
             const float* nzp = p.noise + (long long)b * p.noise_bstride + (long long)x * p.H + y;      // plane layout [W][H]
             const float2 nz0 = *reinterpret_cast<const float2*>(nzp), nz1 = *reinterpret_cast<const float2*>(nzp + p.H);
@@ -762,8 +771,9 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s);     // conv_inst_wino.h
 hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s);
 // wsty[b][rt][s][idx][lane][4] <- Winograd transform of the style LUT lut[(b*19 + j)][tap][gamma|beta][C] (exact-f32 layout)
 hipError_t wino_style_pack(const float* lut, float* wsty, int B, int C, hipStream_t s);
-// boundary quads of every 32 x 16 tile (from the interior map u5 of ace_classify) and the block tasks of conv_wino_ace
-hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int B, int H, int W, hipStream_t s);
-hipError_t wino_ace_worklist(const int* qcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s);
+// boundary quads of every 32 x 32 tile (from the interior map u5 of ace_classify) and the block tasks of conv_wino_ace
+// (u5 == nullptr: every quad is a boundary quad -- levels without the interior reduction); pcnt: boundary pixels per tile; total: 8 ints
+hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int* pcnt, int B, int H, int W, hipStream_t s);
+hipError_t wino_ace_worklist(const int* qcnt, const int* pcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s);
 
 }  // namespace chk

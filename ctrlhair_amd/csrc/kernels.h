@@ -7,7 +7,11 @@ namespace chk {
 hipError_t label_downsample(const uint8_t* in, uint8_t* out, int B, int S, int r, hipStream_t s);
 // need (optional, [B][H][W]): pixels with need == 0 are not written (ace_sparse.h: nothing reads them)
 hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* bias, float* out, int B, int H, int W,
-                          int K, int relu, hipStream_t s, int c4 = 0, const uint8_t* need = nullptr);
+                          int K, int relu, hipStream_t s, int c4 = 0, const uint8_t* need = nullptr, int kout = 0);
+// kout > K (NCHW output only): the output tensor has kout channel planes per sample; the table channels fill the first K.
+// label_onehot_planes writes planes k0 .. k0 + 19 of such a tensor: plane k0 + j = (label == j), plane k0 + 19 = 0 (the Winograd ACE
+// kernel's style k-steps, conv_wino.h)
+hipError_t label_onehot_planes(const uint8_t* lab, float* out, int B, int H, int W, int kout, int k0, hipStream_t s);
 // `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
                                int K, int relu, float scale, hipStream_t s, int bf16 = 0, const uint8_t* need = nullptr,

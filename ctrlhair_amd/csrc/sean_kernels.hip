@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
                                                              const float* __restrict__ table,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int B, int H, int W, int K, int relu, int c4,
-                                                             const uint8_t* __restrict__ need) {
+                                                             const uint8_t* __restrict__ need, int kout) {
     // Table slice in LDS with a padded row pitch (36 floats: lanes that hold different labels start 4 banks apart) and one
     // all-zero row that taps outside the image (and labels >= 19) point at: every lane issues the same 9 ds_read_b128 per 4
     // channels, no predication (as 288 ds_read_b32 per pixel the kernel was bound by its LDS reads, not by its stores).
@@ -95,17 +95,36 @@ __global__ __launch_bounds__(256) void onehot_conv3x3_kernel(const uint8_t* __re
             for (int e = 0; e < 4; ++e) {
                 if (k + e >= K) break;
                 if (c4) out[(((long long)b * (K >> 2) + ((k + e) >> 2)) * HW + p) * 4 + ((k + e) & 3)] = v[e];
-                else out[((long long)b * K + k + e) * HW + p] = v[e];
+                else out[((long long)b * kout + k + e) * HW + p] = v[e];
             }
         }
     }
 }
 
 hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* bias, float* out, int B, int H, int W,
-                          int K, int relu, hipStream_t s, int c4, const uint8_t* need) {
+                          int K, int relu, hipStream_t s, int c4, const uint8_t* need, int kout) {
     const long long npix = (long long)B * H * W;
+    if (kout && (kout < K || c4)) return hipErrorInvalidValue;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((K + OH_KC - 1) / OH_KC));
-    hipLaunchKernelGGL(onehot_conv3x3_kernel, grid, dim3(256), 0, s, lab, table, bias, out, B, H, W, K, relu, c4, need);
+    hipLaunchKernelGGL(onehot_conv3x3_kernel, grid, dim3(256), 0, s, lab, table, bias, out, B, H, W, K, relu, c4, need, kout ? kout : K);
+    return hipGetLastError();
+}
+
+// planes k0 .. k0 + 19 of an NCHW tensor with kout planes per sample: the one-hot label map (labels >= 19: all zero) + a zero plane
+__global__ __launch_bounds__(256) void label_onehot_planes_kernel(const uint8_t* __restrict__ lab, float* __restrict__ out, long long HW,
+                                                                  long long npix, int kout, int k0) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= npix) return;
+    const long long b = i / HW, p = i - b * HW;
+    const int j = lab[i];
+    float* o = out + (b * kout + k0) * HW + p;
+#pragma unroll
+    for (int q = 0; q < 20; ++q) o[q * HW] = q == j ? 1.f : 0.f;
+}
+hipError_t label_onehot_planes(const uint8_t* lab, float* out, int B, int H, int W, int kout, int k0, hipStream_t s) {
+    const long long HW = (long long)H * W, npix = B * HW;
+    if (k0 + 20 > kout) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(label_onehot_planes_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, lab, out, HW, npix, kout, k0);
     return hipGetLastError();
 }
 

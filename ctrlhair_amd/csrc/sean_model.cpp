@@ -276,6 +276,15 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 a.spade_wscale = B.upload(sh16_wscale(kexp));
             } else {
                 a.spade_wpk = B.upload(pack_A(tiles * 64, HID, 3, CK_KS3, getsp));
+                if (wino) {      // Winograd path: row tiles of 16 channels, rows 0-15 = gamma, 16-31 = beta (conv_wino.h)
+                    auto getw = [&](int row, int ci, int t) {
+                        const int c = (row / 32) * 16 + (row & 15);
+                        if (c >= C) return 0.f;
+                        const bool beta = (row & 16) != 0;
+                        return (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t] * (beta ? sb : sg);
+                    };
+                    a.spade_wino = B.upload(pack_wino_A(((C + 15) / 16) * 32, HID, getw));
+                }
             }
             if (a.styled) {
                 auto cg = B.get(p + ".conv_gamma.weight", (size_t)C * STYLE * 9);
@@ -417,7 +426,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a) continue;
                 const size_t r = (size_t)ms / a->res_div;
-                if (ahead_full) actv_ahead[a->index] = B.falloc((size_t)mb * r * r * HID);
+                if (ahead_full) actv_ahead[a->index] = B.falloc((size_t)mb * r * r * (HID + 20));
                 if (a->styled) lut_ahead[a->index] = B.falloc(npad_b * 18 * a->C);
             }
         splitk_side = B.falloc((size_t)splitk_cap);
@@ -464,7 +473,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         midmax = std::max(midmax, MB * S * S * (use_sh16 ? 64 : 16));
     }
     lut = static_cast<float*>(B.dalloc(lutmax * 4));
-    actv = static_cast<float*>(B.dalloc(MB * S * S * HID * 4));
+    actv = static_cast<float*>(B.dalloc(MB * S * S * (HID + 20) * 4));      // (+ 20 one-hot planes: Winograd ACE path, <= S/2)
     h0 = static_cast<float*>(B.dalloc(h0max * 4));
     hs = static_cast<float*>(B.dalloc(h0max * 4));
     dx = static_cast<float*>(B.dalloc(midmax * 4));
@@ -472,6 +481,42 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     xs = static_cast<float*>(B.dalloc(outmax * 4));
     xa = static_cast<float*>(B.dalloc(outmax * 4));
     xb = static_cast<float*>(B.dalloc(outmax * 4));
+    // ---- Winograd ACE path: boundary-quad lists per level, task lists per (level, row tiles), per-sample style images ------
+    for (int k = 0; k < 6; ++k) wq_level[k] = WinoLevel();
+    wsty = nullptr;
+    if (wino && !use_sh16) {
+        size_t wsty_max = 0;
+        for (const auto& b : blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
+                if (!a || !a->spade_wino) continue;
+                int k = 0;
+                while ((1 << k) < a->res_div) ++k;
+                const int r = ms >> k;
+                if (r < 32 || r % 32) continue;
+                WinoLevel& L = wq_level[k];
+                if (!L.qlist) {
+                    L.cap_tiles = mb * (r / 32) * (r / 32);
+                    L.qlist = static_cast<uint8_t*>(B.dalloc((size_t)L.cap_tiles * 256));
+                    L.qcnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
+                    L.pcnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
+                }
+                const int nrt = (a->C + 15) / 16;
+                bool have = false;
+                for (const auto& w : L.works) have = have || w.nrt == nrt;
+                if (!have) {
+                    WinoWork w;
+                    w.nrt = nrt;
+                    w.work = static_cast<unsigned*>(B.dalloc((size_t)L.cap_tiles * 4 * ((nrt + 1) / 2) * sizeof(unsigned)));
+                    w.total = static_cast<int*>(B.dalloc(8 * sizeof(int)));
+                    L.works.push_back(w);
+                }
+                if (a->styled) wsty_max = std::max(wsty_max, (size_t)mb * nrt * 5 * 2048);
+            }
+        if (wsty_max) wsty = B.falloc(wsty_max);
+    }
+    prof_stats_cap = 16384;
+    prof_stats_used = 0;
+    prof_stats = static_cast<int*>(B.dalloc((size_t)prof_stats_cap * 4 * sizeof(int)));
     // ---- exact SPADE-interior reduction: classification buffers per level, work lists per (level, row tiles) ------------
     for (int k = 0; k < 6; ++k) {
         sp_level[k][0] = sp_level[k][1] = SparseLevel();
@@ -587,6 +632,12 @@ struct Runner {
         r.flops = flops;
         r.bytes = bytes;
         r.sp_stat = sp_stat;
+        if (sp_stat && m.prof_stats && m.prof_stats_used < m.prof_stats_cap) {
+            // snapshot of the work list's statistics on the stream: a later chunk / step rebuilds the list
+            int* slot = m.prof_stats + 4 * (size_t)m.prof_stats_used++;
+            check(hipMemcpyAsync(slot, sp_stat, 4 * sizeof(int), hipMemcpyDeviceToDevice, st), "profile statistics snapshot");
+            r.sp_stat = slot;
+        }
         r.sp_flops_unit = sp_unit;
         r.sp_bytes_px = sp_bytes_px;
         r.sp_bytes_fixed = sp_bytes_fixed;
@@ -647,6 +698,45 @@ struct Runner {
             }
         return nullptr;
     }
+    // Winograd ACE path: classification of the level (when the interior reduction serves it), boundary-quad lists, task list
+    struct WinoPrep { const SeanModel::WinoLevel* L = nullptr; const SeanModel::WinoWork* W = nullptr; const SparseLevel* S = nullptr; };
+    bool wq_done[6] = {};
+    std::vector<int> wwork_done[6];
+    WinoPrep wino_prepare(const AceW& a, const uint8_t* lab, int r) {
+        WinoPrep o;
+        int k = 0;
+        while ((1 << k) < a.res_div) ++k;
+        const SeanModel::WinoLevel& L = m.wq_level[k];
+        if (!L.qlist) return o;
+        const int nrt = (a.C + 15) / 16;
+        for (const auto& w : L.works)
+            if (w.nrt == nrt) o.W = &w;
+        if (!o.W) return o;
+        o.L = &L;
+        if (m.sparse && r >= m.sparse_min_r) {
+            for (int ti = 1; ti >= 0 && !o.S; --ti)
+                if (m.sp_level[k][ti].u5) {
+                    const SparseLevel& S = m.sp_level[k][ti];
+                    if (!lvl_done[k][ti]) {
+                        check(ace_classify(lab, S.u5, S.need, S.list, S.cnt, B, r, r, S.TH, st), "ace_classify");
+                        lvl_done[k][ti] = true;
+                    }
+                    o.S = &S;
+                }
+        }
+        const int ntiles = B * (r / 32) * (r / 32);
+        if (!wq_done[k]) {
+            check(wino_quad_lists(o.S ? o.S->u5 : nullptr, L.qlist, L.qcnt, L.pcnt, B, r, r, st), "wino_quad_lists");
+            wq_done[k] = true;
+        }
+        bool done = false;
+        for (int d : wwork_done[k]) done = done || d == nrt;
+        if (!done) {
+            check(wino_ace_worklist(L.qcnt, L.pcnt, ntiles, nrt, o.W->work, o.W->total, st), "wino_ace_worklist");
+            wwork_done[k].push_back(nrt);
+        }
+        return o;
+    }
     const uint8_t* labels_at(const uint8_t* full, int res_div) {
         if (res_div == 1) return full;
         int k = 0;
@@ -662,6 +752,7 @@ struct Runner {
         int lut_rs = 1, lut_ns = 0, lut_bs = LABEL_NC;
     };
     // what: bit 0 = style LUT, bit 1 = SPADE hidden activations
+    bool use_wino_ace(const AceW& a, int r) const { return m.wino && !m.use_sh16 && a.spade_wino && r >= 32 && r % 32 == 0; }
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
                         float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr) {
         const int r = S / a.res_div;
@@ -738,7 +829,11 @@ struct Runner {
         if (m.use_sh16)
             check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2, need, tile_cnt,
                                       (m.dbg & 33554432) ? 1 : 0), "mlp_shared");
-        else
+        else if (use_wino_ace(a, r) && a.styled) {
+            // Winograd ACE path: the one-hot label planes behind the hidden channels feed the style k-steps (conv_wino.h)
+            check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, nullptr, HID + 20), "mlp_shared");
+            check(label_onehot_planes(lab, actv_buf, B, r, r, HID + 20, HID, s), "one-hot planes");
+        } else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, need), "mlp_shared");
         return q;
     }
@@ -771,7 +866,10 @@ struct Runner {
         const double npix = (double)B * r * r;
         // exact SPADE-interior reduction (ace_sparse.h): classification of the level + work list of this layer's row tiles.
         // f16x3 path: tile-skip mode, honoured by the wave-specialised kernel only (conv_sh16.h)
-        const SparseWork* sw = sparse_prepare(a, lab, r);
+        const bool wino_ace = use_wino_ace(a, r);
+        WinoPrep wp;
+        if (wino_ace) wp = wino_prepare(a, lab, r);
+        const SparseWork* sw = (wino_ace && wp.L) ? nullptr : sparse_prepare(a, lab, r);
         if (sw && m.use_sh16) {
             ConvParams t{};
             t.C = a.C;
@@ -806,6 +904,67 @@ struct Runner {
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else {
             q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true, 3, need, tile_cnt);
+        }
+        if (wino_ace && wp.L) {
+            const double xpp = 4.0 * a.C / (x_up ? 4.0 : 1.0), opp = 4.0 * a.C;
+            const int ktot = HID + (a.styled ? 20 : 0);
+            if (wp.S) {          // interior pixels: elementwise with the per-(sample, label) gamma/beta rows (ace_sparse.h)
+                AceInteriorParams ip{};
+                ip.x = x;
+                ip.out = hout;
+                ip.u5 = wp.S->u5;
+                ip.cnt = wp.S->cnt;
+                ip.gtab = m.gtab;
+                ip.bn_a = a.bn_a;
+                ip.bn_d = a.bn_d;
+                ip.nv = a.nv;
+                ip.noise = noise + noff;
+                ip.noise_bstride = (long long)nf;
+                ip.B = B;
+                ip.C = a.C;
+                ip.H = r;
+                ip.W = r;
+                ip.x_up = x_up;
+                ip.act = act;
+                ip.variant = 0;
+                ip.impl = 0;
+                ip.fill_min = x_up ? 257 : 128;
+                timed(3, 0.0, 0.0, wp.W->total + 4, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
+                    check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
+                    check(ace_interior_f32(ip, st), "ace interior");
+                });
+            }
+            WinoAceParams w{};
+            w.actv = q.actv;
+            w.wpk = a.spade_wino;
+            w.wsty = (a.styled && q.lut) ? m.wsty : nullptr;
+            w.out = hout;
+            w.x = x;
+            w.x_up = x_up;
+            w.act = act;
+            w.B = B;
+            w.C = a.C;
+            w.H = r;
+            w.W = r;
+            w.bias_g = a.bias_g;
+            w.bias_b = a.bias_b;
+            w.bn_a = a.bn_a;
+            w.bn_d = a.bn_d;
+            w.nv = a.nv;
+            w.noise = noise + noff;
+            w.noise_bstride = (long long)nf;
+            w.qlist = wp.L->qlist;
+            w.qcnt = wp.L->qcnt;
+            w.work = wp.W->work;
+            w.total = wp.W->total;
+            w.zero = m.zero_page;
+            // executed FLOPs = wave tasks x (32 rows x 16 quads x 16 positions x K) x 2; dense = the direct conv over every pixel
+            timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 0.0, wp.W->total + 4, 2.0 * 32 * 16 * 16 * ktot, 4.0 * ktot + xpp + opp,
+                  4.0 * 2.0 * a.C * ktot * 16, npix, [&] {
+                      if (w.wsty) check(wino_style_pack(q.lut, m.wsty, B, a.C, st), "wino_style_pack");
+                      check(conv_wino_ace(w, st), "spade conv (winograd, boundary quads)");
+                  });
+            return;
         }
         ConvParams p{};
         p.in = q.actv;

@@ -36,6 +36,7 @@ struct AceW {
     float out_scale = 8.f;                      // f16x3 path: first-pass SH16 scale of this ACE's output (SH16_ACT_SCALE; the
                                                 //   shortcut's ace_s carries the 2^D aligning conv_s with conv_1, sean_model.cpp)
     float actv_scale = 1.f;                     // f16x3 path: SH16 scale of the SPADE hidden activations (from a table bound)
+    float* spade_wino = nullptr;                // exact-f32 Winograd path: pack_wino_A image of the (gamma | beta) rows, 16-channel row tiles
     float* gconst = nullptr;                    // [19][gamma|beta][C]: SPADE gamma/beta of a pixel whose 5x5 label neighbourhood
                                                 //   is uniformly j (blend factor folded in, biases not) -- ace_sparse.h
 };
@@ -53,7 +54,7 @@ struct ProfRec {
     int kind;       // 0 plain conv, 1 ACE conv, 2 LUT gemm, 3 interior pass of a sparse ACE (table build + elementwise kernel)
     double flops, bytes;            // flops: the dense evaluation of the layer (every pixel through the conv)
     double flops_exec = -1.0;       // FLOPs the matrix cores ran when they differ from `flops` (Winograd convs: 16 / 36); < 0: = flops
-    const int* sp_stat = nullptr;   // sparse ACE launch: SparseWork::total of its work list (read back at ch_profile_read)
+    const int* sp_stat = nullptr;   // sparse ACE launch: snapshot of the statistics of its work list (read back at ch_profile_read)
     double sp_flops_unit = 0.0;     //   executed FLOPs = sp_stat[3] * sp_flops_unit
     double sp_bytes_px = 0.0, sp_bytes_fixed = 0.0, sp_npix = 0.0;   // algorithmic bytes = fixed + per-pixel x (boundary pixels
                                     //   sp_stat[1] for kind 1, interior pixels sp_npix - sp_stat[1] for kind 3)
@@ -105,6 +106,14 @@ struct SeanModel {
     int wino = 1;                              // option "sean.wino": exact-f32 path, 3x3 convs as Winograd F(2x2,3x3) on the f32
                                                //   matrix cores (conv_wino.h); 0 = direct evaluation (conv_mfma.h)
     float* zero_page = nullptr;                // 256 bytes of zeros
+    // Winograd ACE path (conv_wino.h wino_ace_kernel): per resolution level the boundary quads of every 32 x 16 tile and one task
+    // list per distinct row-tile count; per-sample style images of the ACE being run
+    struct WinoWork { int nrt = 0; unsigned* work = nullptr; int* total = nullptr; };
+    struct WinoLevel { uint8_t* qlist = nullptr; int* qcnt = nullptr; int* pcnt = nullptr; int cap_tiles = 0; std::vector<WinoWork> works; };
+    WinoLevel wq_level[6];
+    float* wsty = nullptr;
+    int* prof_stats = nullptr;                 // profiling: snapshots of the work-list statistics of sparse launches (16 B each)
+    int prof_stats_cap = 0, prof_stats_used = 0;
     int sparse = 1;                            // option "sean.sparse" (0 = every pixel through the conv)
     int sparse_min_r = 64;                     // option "sean.sparse_min": smallest resolution served by the sparse path
     int sh16_compact = 1;                      // option "sean.sh16_compact": f16x3 path, 1 = pixel-level compaction inside the
