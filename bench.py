@@ -54,7 +54,8 @@ DENSE_REFERENCE_FLOP_PER_IMAGE = 2.5696e12    # the reference's 
 PATH_OPTION = {'f32': 0, 'f16x3': 1, 'f16': 2, 'bf16': 3}
 
 DTYPE = {
-    'f32': 'f32 (exact-f32 MFMA, v_mfma_f32_32x32x2_f32)',
+    'f32': 'f32 (every product and sum an IEEE f32 operation on the f32 matrix cores, v_mfma_f32_16x16x4_f32 / 32x32x2_f32; 3x3 convs '
+           'as Winograd F(2x2,3x3) unless --wino 0)',
     'f16x3': 'f32 storage + f32 accumulate; conv products as 3-term f16 split on MFMA with power-of-two operand scaling '
              '(2^-22 per product: f32-class, not the fp32 number of record; csrc/sh16.h)',
     'f16': 'f16 operands on MFMA, f32 accumulate, f32 normalisation/modulation (reduced precision: tolerance 5e-2)',
@@ -67,15 +68,18 @@ def csrc_sha():
     a mismatch means the committed traffic figure is stale and is not reported."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'ctrlhair_amd', 'csrc')
-    for f in ('conv_mfma.h', 'conv_ace_sparse.h', 'ace_sparse.h', 'conv_sh16.h', 'conv_sh16_ws2.h', 'sh16.h'):
+    for f in ('conv_mfma.h', 'conv_wino.h', 'conv_ace_sparse.h', 'ace_sparse.h', 'conv_sh16.h', 'sh16.h'):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(ngf, S, sd_np, budget_s=40.0):
-    """The oracle (torch fp32 CPU restatement of the reference path) timed on this host's cores on a bounded sample of
-    the same workload: one 128x128 warm-up, then up to 3 single-image forwards at the benchmark size (median)."""
+def cpu_baseline(ngf, S, sd_np, budget_s=45.0, weights=None):
+    """The oracle (torch fp32 CPU restatement of the reference path) timed on this host's cores on a bounded sample of the same
+    workload (SURVEY.md 8d asks for Config 2 at B=1 and B=16 and for Config 1; B=16 of the dense reference graph takes minutes
+    here, so the sample is: one 128x128 warm-up, single-image forwards at the benchmark size while the budget lasts (median), and
+    -- when the full weight set is at hand -- ONE Config-1 edit (256x256 portrait through Backend.set_input_img / sliders /
+    output on the CPU restatement of every network))."""
     import numpy as np
     import torch
     from ctrlhair_amd import procedural as P
@@ -91,12 +95,33 @@ def cpu_baseline(ngf, S, sd_np, budget_s=40.0):
         t = time.time()
         O.generator_forward(sd, lab, cd, nz, ngf, weights_cache=wc)
         times.append(time.time() - t)
-        if time.time() - t0 > budget_s:
+        if time.time() - t0 + times[-1] > budget_s:
             break
     med = float(np.median(times))
-    return {'value': round(1.0 / med, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{len(times)} single-image {S}x{S} generator forwards (median; the dense reference graph, batch 16 would '
-                      f'take minutes), torch {torch.__version__} CPU, after a 128x128 warm-up'}
+    out = {'value': round(1.0 / med, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': f'{len(times)} single-image {S}x{S} generator forwards (median; the dense reference graph), torch '
+                     f'{torch.__version__} CPU, after a 128x128 warm-up',
+           'b1_seconds': [round(t, 2) for t in times],
+           'b16': {'run': False, 'estimate_seconds_per_batch': round(16 * med, 1),
+                   'why': 'no cross-sample op in the graph: a batch of 16 is 16 of these forwards; not run inside the bench budget'}}
+    if weights is not None:
+        try:
+            from ctrlhair_amd.ui.backend import Backend
+            from tests.oracle_models import OracleModels      # CPU provider of every network (test infrastructure)
+            be = Backend(2.5, blending=False, models=OracleModels(weights, ngf))
+            img = np.ascontiguousarray(P.synthetic_images(1, 256, seed=11)[0].transpose(1, 2, 0))
+            img = np.clip((img * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
+            t = time.time()
+            be.set_input_img(img_rgb=img)
+            be.change_curliness(1.0)
+            be.change_texture(1.5, 0)
+            be.change_shape(-1.0, 0)
+            be.output()
+            out['config1_edit'] = {'seconds': round(time.time() - t, 2), 'what': 'one 256x256 portrait: set_input_img (parse, shape / '
+                                   'style / colour encoders) + three slider moves + output(), every network on the CPU oracle'}
+        except Exception as e:          # never lose the run over the baseline
+            out['config1_edit'] = {'error': f'{type(e).__name__}: {e}'}
+    return out
 
 
 def make_labels(kind, B, S, first):
@@ -274,8 +299,9 @@ def roofline_block(path, prof, value, B, sustained):
         kname = 'conv_sh16_ws_kernel / conv_sh16_kernel <KS=3,...,EPI_ACE> (SPADE gamma/beta conv, f16x3 split operands, fused ACE epilogue)'
     else:
         executed, peak, pk = useful, PEAK_F32_MFMA_TFLOPS, 'f32'
-        kname = ('conv_ace_sparse_kernel<TH> (SPADE gamma/beta conv over the compacted boundary pixels, exact-f32 MFMA, fused ACE '
-                 'epilogue) + conv_mfma_kernel<KS=3,...,EPI_ACE> for the low-resolution ACEs')
+        kname = ('wino_ace_kernel<TH> (SPADE gamma/beta conv + style convs as Winograd F(2x2,3x3) on the exact-f32 matrix cores over the '
+                 'boundary quads, fused ACE epilogue; --wino 0: conv_ace_sparse_kernel) + conv_mfma_kernel<KS=3,...,EPI_ACE> for '
+                 'the ACEs below 32 pixels')
     traffic = traffic_raw = detail = note = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
@@ -312,7 +338,8 @@ def roofline_block(path, prof, value, B, sustained):
         'executed_over_dense': round(ace['flops_executed'] / max(ace['flops'], 1.0), 4),
         'dense_equivalent_f32_tflops': round(dense, 2),
         'note': 'executed = FLOPs the matrix cores ran (exact SPADE-interior reduction: pixels with a uniform 5x5 label '
-                'neighbourhood take per-label constants, csrc/ace_sparse.h); utilisation is priced on executed FLOPs only',
+                'neighbourhood take per-label constants, csrc/ace_sparse.h; Winograd F(2x2,3x3): 16 products per quad and channel '
+                'instead of 36, csrc/conv_wino.h); utilisation is priced on executed FLOPs only',
         'all_mfma_convs': {
             'executed_tflops': round(allk['flops_executed'] / max(allk['ms'], 1e-9) / 1e9, 2),
             'ms_per_step': round(allk['ms'] / steps, 3),
@@ -356,7 +383,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=0, help='per GPU; default 16 (generator; 32 with --gpus 8 = configs[3]) / 8 (pipeline)')
+    ap.add_argument('--batch', type=int, default=0, help='per GPU; default 16 for every --gpus N (generator) / 8 (pipeline); the 32-per-GPU '
+                    'shape of configs[3] rides along as the block configs3_b32_per_gpu at N = 1 and N = 8')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ngf', type=int, default=64)
     ap.add_argument('--workload', choices=('all', 'generator', 'pipeline'), default='all')
@@ -381,7 +409,8 @@ def main():
         args.only_headline = True
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         respawn_under_torchrun(args.gpus)
-    gen_batch = args.batch if args.batch > 0 else (32 if args.gpus == 8 else 16)
+    # ONE per-GPU batch for every N of a scaling curve (N = 1 must be the workload of N = 8)
+    gen_batch = args.batch if args.batch > 0 else 16
     pipe_batch = args.batch if args.batch > 0 else 8
 
     import torch
@@ -411,6 +440,7 @@ def main():
     res = {}
     sustained = None
     sd = None
+    all_weights = None
 
     if do_gen:
         from ctrlhair_amd import procedural as P
@@ -442,10 +472,34 @@ def main():
             del job
             torch.cuda.empty_cache()
         head = blocks[args.path]
+        # side legs of the exact-f32 number of record (shorter runs, same protocol): the per-GPU shape of configs[3] (32 images
+        # per GPU), and at N = 1 the same job without the Winograd convs and without the SPADE-interior reduction (worst case)
+        side = {}
+        if args.path == 'f32' and (extras or world == 8) and args.batch == 0:
+            variants = [('configs3_b32_per_gpu', {'batch': 32})]
+            if extras:
+                variants += [('direct_convs_no_winograd', {'wino': 0}), ('dense_worst_case_no_interior_reduction', {'sparse': 0})]
+            for name, over in variants:
+                a2 = argparse.Namespace(**vars(args))
+                for k, v in over.items():
+                    setattr(a2, k, v)
+                try:
+                    job = GeneratorJob(a2, 'f32', dev, rank, sd, labels=args.labels)
+                    r2, p2 = run_leg(job, a2, dist, dev, world, steps=max(5, args.steps // 3), warmup=max(2, args.warmup // 3))
+                    rb = roofline_block('f32', p2, r2['value'] / world, a2.batch, sustained)
+                    side[name] = {'value': r2['value'], 'unit': 'images/s', 'ms_per_step': r2['ms_per_step'], 'steps': r2['steps'],
+                                  'batch_per_gpu': a2.batch, 'global_batch': world * a2.batch,
+                                  'all_mfma_convs': rb['all_mfma_convs'], 'dominant_kernel_tflops': rb['achieved'],
+                                  'executed_over_dense_spade': rb['executed_over_dense']}
+                    job.close()
+                    del job
+                except Exception as e:           # e.g. not enough memory for the 32-image handle next to another process
+                    side[name] = {'error': f'{type(e).__name__}: {e}'}
+                torch.cuda.empty_cache()
         par = f'batch-sharded x{world}'
         if dist is not None:
             par += ' + RCCL all-gather of outputs' + ('' if args.sync_gather else ' overlapped with the next step')
-        cfgn = 'configs[3]: B=256 on 8 GPUs' if (world == 8 and gen_batch == 32) else 'configs[1]'
+        cfgn = 'configs[1] per GPU' if gen_batch == 16 else f'{gen_batch} per GPU'
         res = {
             'metric': '512x512 edited images/sec (SEAN generator forward), whole job', 'value': head['value'], 'unit': 'images/s',
             'n_gpus': world, 'steps': head['steps'], 'warmup': head['warmup'], 'ms_per_step': head['ms_per_step'],
@@ -454,9 +508,10 @@ def main():
                     'no checkpoint ships with the reference)',
             'config': {'workload': f'SEAN generator forward only, batch {gen_batch}/GPU, {S}x{S}, ngf={ngf} (BASELINE.json {cfgn})',
                        'global_batch': world * gen_batch, 'conv_path': args.path, 'parallelism': par, 'labels': args.labels,
-                       'spade_interior_reduction': bool(args.sparse)},
+                       'spade_interior_reduction': bool(args.sparse), 'winograd_f2x2_3x3': bool(args.wino) and args.path == 'f32'},
             'roofline': head['roofline'], 'sustained_peaks': sustained,
         }
+        res.update(side)
         if 'f16x3' in blocks and args.path != 'f16x3':
             b = blocks['f16x3']
             res['f32_class_f16x3'] = {k: b[k] for k in ('value', 'ms_per_step', 'step_ms', 'steps', 'warmup', 'dtype', 'roofline')}
@@ -473,6 +528,7 @@ def main():
         from ctrlhair_amd.hair_editor import procedural_weights
         args.batch = pipe_batch
         weights = procedural_weights(0, ngf)
+        all_weights = weights
         if sd is None:
             sd = weights['sean']
         if args.workload == 'all':
@@ -509,7 +565,7 @@ def main():
                 res['pipeline'][path] = r
 
     if rank == 0 and do_gen and not args.no_cpu_baseline and world == 1:
-        res['cpu_baseline'] = cpu_baseline(ngf, S, sd)
+        res['cpu_baseline'] = cpu_baseline(ngf, S, sd, weights=all_weights)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -196,6 +196,7 @@ hipError_t ace_gtable(const float* bias_g, const float* bias_b, const float* gco
 // different labels hit different banks).
 //      out = act((bn_a x + nv nz + bn_d) (1 + gamma) + beta)          (normalization.py:111-112,182; architecture.py:95)
 constexpr int IN_CG = 32;
+#ifdef CH_ABLATE      // the row-shaped first versions (A/B builds only)
 __global__ __launch_bounds__(256) void ace_interior_f32_kernel(const AceInteriorParams q) {
     constexpr int RS = 2 * IN_CG + 1;
     __shared__ float gt[19 * RS];
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(256) void ace_interior_f32_scalar_kernel(const AceI
         op[(long long)c * HW] = o;
     }
 }
+#endif   // CH_ABLATE
 
 // Blocks of 32 x 8 pixels (the default; tools/interior_bench.hip measures it against the row kernel above): whole 32-byte
 // sectors of the [W][H] noise plane instead of 4 bytes out of each of 256 lines, and a block that is mostly interior writes ALL
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
 
 // Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
 // values of a thread share their 32-byte sectors with the seven other rows of the block.
+#ifdef CH_ABLATE      // four pixels per thread (A/B builds only)
 __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {
     constexpr int RS = 2 * IN_CG + 1;
     __shared__ float gt[19 * RS];
@@ -431,20 +434,28 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
     }
 }
 
+#endif   // CH_ABLATE
+
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU) return hipErrorInvalidValue;
     if (q.W % 4 != 0) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
+#ifdef CH_ABLATE
     if (q.impl == 2 && q.W >= 128) {
         dim3 gridt((unsigned)(q.B * ((q.W + 127) / 128) * ((q.H + 7) / 8)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_tile4_kernel, gridt, dim3(256), 0, s, q);
         return hipGetLastError();
     }
+#endif
     if (q.impl == 0 || q.impl == 2) {
         dim3 gridt((unsigned)(q.B * ((q.W + 31) / 32) * ((q.H + 7) / 8)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_tile_kernel, gridt, dim3(256), 0, s, q);
         return hipGetLastError();
     }
+#ifndef CH_ABLATE
+    (void)HW;
+    return hipErrorInvalidValue;
+#else
     if (q.variant != 1) {       // default (0) and the full-sector experiment (2): one pixel per thread
         dim3 grid1((unsigned)(q.B * ((HW + 255) / 256)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_scalar_kernel, grid1, dim3(256), 0, s, q);
@@ -453,6 +464,7 @@ hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     dim3 grid((unsigned)(q.B * ((HW + 1023) / 1024)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
     hipLaunchKernelGGL(ace_interior_f32_kernel, grid, dim3(256), 0, s, q);
     return hipGetLastError();
+#endif
 }
 
 // ---- interior pass, f16x3 path (tile-skip mode): C4 in, SH16 out --------------------------------------------------------
@@ -461,6 +473,7 @@ hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
 //      o = act((bn_a x + nv nz + bn_d) (1 + gamma) + beta) * out_scale [* extra];  hi = f16(o), lo = f16(o - hi)
 constexpr int IS_GPB = 4;
 typedef _Float16 is_h8 __attribute__((ext_vector_type(8)));
+#ifdef CH_ABLATE      // the row-shaped first version (A/B builds only)
 __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInteriorParams q) {
     constexpr int CB = IS_GPB * 8, RS = 2 * CB + 4;          // row pitch: 16-byte aligned, labels spread over the banks
     __shared__ __attribute__((aligned(16))) float gt[19 * RS];
@@ -553,6 +566,7 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInterio
     // pass 0: the tensor's maximum at the first-pass scale (uniform: every thread of every block gets here)
     if (q.pass == 0 && q.out_amax) sh16_block_slot_max(q.out_amax, amax);
 }
+#endif   // CH_ABLATE
 
 // Same arithmetic, blocks of 32 x 8 pixels (tools/interior_bench.hip measures both):
 //  * the noise plane is stored [W][H]: a block of 256 consecutive pixels of a row touched 256 different 64-byte lines of it for
@@ -671,9 +685,14 @@ hipError_t ace_interior_sh16(const AceInteriorParams& q, hipStream_t s) {
         hipLaunchKernelGGL(ace_interior_sh16_tile_kernel, dim3((unsigned)(ntile < 2048 ? ntile : 2048)), dim3(256), 0, s, q);
         return hipGetLastError();
     }
+#ifdef CH_ABLATE
     const int nblk = q.B * ((HW + 255) / 256);
     hipLaunchKernelGGL(ace_interior_sh16_kernel, dim3((unsigned)(nblk < 2048 ? nblk : 2048)), dim3(256), 0, s, q);
     return hipGetLastError();
+#else
+    (void)HW;
+    return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace chk

@@ -348,6 +348,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.wino = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.wino_th") == 0) {    // tile height 16 / 32 of the Winograd ACE kernel (0 = chosen per level)
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino_th) must precede ch_finalize");
+        h->sean.wino_th = value;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.sparse") == 0) {     // exact SPADE-interior reduction (ace_sparse.h); buffers are sized at ch_finalize
         h->sean.sparse = value != 0;
         return CH_OK;
@@ -372,6 +377,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         return CH_OK;
     }
     if (std::strcmp(key, "sean.dbg") == 0) {
+#ifndef CH_ABLATE
+        if (value & CH_ABLATE_DBG_MASK)
+            return fail(h, CH_ERR_ARG, "ch_set_option(sean.dbg): timing-ablation / superseded-kernel bits need a library built with -DCH_ABLATE "
+                                       "(make -C ctrlhair_amd/csrc ABLATE=1)");
+#endif
         h->sean.dbg = value;
         return CH_OK;
     }

@@ -39,26 +39,33 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
 }
 
 
-hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s) {
-    if (p.H % WA_TH || p.W % wino::TW || !p.zero || !p.qlist || !p.qcnt || !p.work || !p.total || (p.C & 3)) return hipErrorInvalidValue;
-    p.nrt = (p.C + 15) / 16;
-    p.ntx = p.W / wino::TW;
-    p.nty = p.H / WA_TH;
-    p.K = 128 + (p.wsty ? 20 : 0);
+template <int TH>
+static hipError_t launch_wino_ace(const WinoAceParams& p, hipStream_t s) {
     static bool d0[64] = {};
-    hipError_t e = wino_attr(wino_ace_kernel<0>, WA_LDS_BYTES, d0);
+    hipError_t e = wino_attr(wino_ace_kernel<TH>, WaCfg<TH>::LDS_BYTES, d0);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wino_ace_kernel<0>, dim3(wino_num_cus()), dim3(512), WA_LDS_BYTES, s, p);
+    hipLaunchKernelGGL(wino_ace_kernel<TH>, dim3(wino_num_cus()), dim3(512), WaCfg<TH>::LDS_BYTES, s, p);
     return hipGetLastError();
 }
+hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s) {
+    if ((p.TH != 16 && p.TH != 32) || p.H % p.TH || p.W % wino::TW || !p.zero || !p.qlist || !p.qcnt || !p.work || !p.total || (p.C & 3))
+        return hipErrorInvalidValue;
+    p.nrt = (p.C + 15) / 16;
+    p.ntx = p.W / wino::TW;
+    p.nty = p.H / p.TH;
+    p.K = 128 + (p.wsty ? 20 : 0);
+    return p.TH == 32 ? launch_wino_ace<32>(p, s) : launch_wino_ace<16>(p, s);
+}
 
-// ---- boundary quads of a tile of 32 x 32 pixels: one block of 256 threads = the tile's 16 x 16 quads, ordered compaction ---------
-__global__ __launch_bounds__(256) void wino_quad_list_kernel(const uint8_t* __restrict__ u5, uint8_t* __restrict__ qlist, int* __restrict__ qcnt,
-                                                             int* __restrict__ pcnt, int H, int W, int ntx, int nty) {
-    __shared__ int wc[4], pc[4];
+// ---- boundary quads of a tile of 32 x TH pixels: one block of 8 TH threads = the tile's 16 x TH / 2 quads, ordered compaction -----
+template <int TH>
+__global__ __launch_bounds__(8 * TH) void wino_quad_list_kernel(const uint8_t* __restrict__ u5, uint8_t* __restrict__ qlist, int* __restrict__ qcnt,
+                                                                int* __restrict__ pcnt, int H, int W, int ntx, int nty) {
+    constexpr int NW = TH / 8;
+    __shared__ int wc[NW], pc[NW];
     const int tile = blockIdx.x, tid = threadIdx.x;
     const int b = tile / (ntx * nty), tr = tile % (ntx * nty);
-    const int y = (tr / ntx) * 32 + 2 * (tid >> 4), x = (tr % ntx) * 32 + 2 * (tid & 15);
+    const int y = (tr / ntx) * TH + 2 * (tid >> 4), x = (tr % ntx) * 32 + 2 * (tid & 15);
     int npx = 4;                                               // boundary pixels of the quad (u5 == nullptr: every pixel is one)
     if (u5) {
         const uint8_t* up = u5 + ((long long)b * H + y) * W + x;
@@ -72,15 +79,21 @@ __global__ __launch_bounds__(256) void wino_quad_list_kernel(const uint8_t* __re
     for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
     if (lane == 0) { wc[wave] = __popcll(m); pc[wave] = ps; }
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wc[w];
-    if (bnd) qlist[(long long)tile * 256 + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
-    if (tid == 0) { qcnt[tile] = wc[0] + wc[1] + wc[2] + wc[3]; pcnt[tile] = pc[0] + pc[1] + pc[2] + pc[3]; }
+    int base = 0, tq = 0, tp = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (w < wave) base += wc[w];
+        tq += wc[w];
+        tp += pc[w];
+    }
+    if (bnd) qlist[(long long)tile * (8 * TH) + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    if (tid == 0) { qcnt[tile] = tq; pcnt[tile] = tp; }
 }
-hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int* pcnt, int B, int H, int W, hipStream_t s) {
-    if (H % 32 || W % 32) return hipErrorInvalidValue;
-    const int ntx = W / 32, nty = H / 32;
-    hipLaunchKernelGGL(wino_quad_list_kernel, dim3(B * ntx * nty), dim3(256), 0, s, u5, qlist, qcnt, pcnt, H, W, ntx, nty);
+hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int* pcnt, int B, int H, int W, int TH, hipStream_t s) {
+    if ((TH != 16 && TH != 32) || H % TH || W % 32) return hipErrorInvalidValue;
+    const int ntx = W / 32, nty = H / TH;
+    if (TH == 32) hipLaunchKernelGGL(wino_quad_list_kernel<32>, dim3(B * ntx * nty), dim3(256), 0, s, u5, qlist, qcnt, pcnt, H, W, ntx, nty);
+    else hipLaunchKernelGGL(wino_quad_list_kernel<16>, dim3(B * ntx * nty), dim3(128), 0, s, u5, qlist, qcnt, pcnt, H, W, ntx, nty);
     return hipGetLastError();
 }
 

@@ -24,6 +24,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing ablations (skipped loads / epilogues / gathers: WRONG RESULTS) and superseded kernel versions kept for A/B measurements
+// exist only in builds with -DCH_ABLATE (make ABLATE=1); the default library contains none of them and ch_set_option rejects
+// their sean.dbg bits.
+#ifdef CH_ABLATE
+#define CH_ABL(x) (x)
+#else
+#define CH_ABL(x) 0
+#endif
+// sean.dbg bits that need a CH_ABLATE build: 1 / 2 / 4 / 8 skip loads, the MFMA loop, epilogues; 2048 conv_sh16_ws2_kernel;
+// 65536 / 1048576 / 2097152 / 16777216 earlier interior-pass kernels; 4194304 no style-LUT gathers
+constexpr int CH_ABLATE_DBG_MASK = 1 | 2 | 4 | 8 | 2048 | 65536 | 1048576 | 2097152 | 16777216 | 4194304;
+
 namespace chk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -140,7 +152,7 @@ __device__ __forceinline__ void ace_epilogue_f32(const ConvParams& p, f32x16 (&a
     const uint8_t* lb = p.lab + (long long)b * HW;
     const float* xb = p.x + (long long)b * C * xHW;
     float* ob = p.out + (long long)b * C * HW;
-    const float* Lb = (p.lut && !(p.dbg & 4194304)) ? p.lut + (long long)b * 19 * 9 * 2 * C : nullptr;   // (bit: timing ablation)
+    const float* Lb = (p.lut && !CH_ABL(p.dbg & 4194304)) ? p.lut + (long long)b * 19 * 9 * 2 * C : nullptr;   // (bit: timing ablation)
     // Pixel (n) outer: the nine (label, tap) row offsets of the pixel's style-LUT gathers are computed once and shared by its
     // four channel runs (as 32-bit element offsets from the sample's LUT: <= 19*9*2*C floats); the five parameter float4 of a
     // run are re-read per pixel from L1 instead (per-tap 64-bit address arithmetic was the larger cost).

@@ -629,16 +629,16 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         }
     };
 
-    if (!(p.dbg & 8)) stage(c_lo, 0);
+    if (!CH_ABL(p.dbg & 8)) stage(c_lo, 0);
     __syncthreads();
 
     for (int ch = c_lo; ch < c_hi; ++ch) {
-        if (ch + 1 < c_hi && !(p.dbg & 1)) stage(ch + 1, (ch + 1 - c_lo) & 1);
+        if (ch + 1 < c_hi && !CH_ABL(p.dbg & 1)) stage(ch + 1, (ch + 1 - c_lo) & 1);
         if constexpr (FUSE) {
             if (ch + 1 == c_hi) stage2(0, (ch + 1 - c_lo) & 1);
         }
         const uint4* sb = smem_u + ((ch - c_lo) & 1) * UNITS;
-        if (p.dbg & 2) { __syncthreads(); continue; }
+        if (CH_ABL(p.dbg & 2)) { __syncthreads(); continue; }
         const uint4* Ac = Ap + (long long)ch * (NT * 4 * 64);
         uint4 a_cur[4];
 #pragma unroll
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void conv_sh16_kernel(const ConvParams p) {
         }
     }
 
-    if (p.dbg & 4) return;
+    if (CH_ABL(p.dbg & 4)) return;
     sh16_epilogue<TW, TH, TB, EPI, TERMS == 2, D2S>(p, acc, mtile64, wn, lane, x0, y0, b0, ks, ROT);
 }
 
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(512, 2) void conv_sh16_ws_kernel(const ConvParams p
         // after the last chunk's barrier the consumers no longer touch LDS: the loaders go on staging the next tile
         // while the epilogue runs
         if (stamp && k < 64) stamps[k * 3 + 1] = __builtin_amdgcn_s_memtime();
-        if (p.dbg & 4) continue;
+        if (CH_ABL(p.dbg & 4)) continue;
         if constexpr (!pre) {
             sh16_epilogue<TW, TH, TB, EPI, TERMS == 2>(p, acc, mtile64, wn, lane, x0, y0, b0);
         } else {
@@ -1616,7 +1616,7 @@ hipError_t launch_sh16_ws2(ConvParams p, int rows, hipStream_t stream);     // c
 inline bool sh16_ace_uses_ws(const ConvParams& p) {
     const int rows = ((p.C + 31) / 32) * 64;
     const long long ntiles = (long long)(rows / 64) * ((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
-    if ((p.dbg & 2048) && p.Cin == 128 && p.W >= 32) return false;
+    if (CH_ABL(p.dbg & 2048) && p.Cin == 128 && p.W >= 32) return false;
     const bool ws_ok = p.W >= 32 && p.Cin >= 48;
     return ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512));
 }
@@ -1630,7 +1630,9 @@ hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
     const long long ntiles = (long long)(rows / 64) * ((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
     // dbg bit 2048: the experimental kernel of conv_sh16_ws2.h (epilogue pipelined into the next tile's k-loop; correct,
     // but its half-size tiles double the A-fragment traffic and the loaders cannot deliver it: DESIGN.md section 7)
+#ifdef CH_ABLATE
     if ((p.dbg & 2048) && p.Cin == 128 && p.W >= 32) return launch_sh16_ws2<TERMS>(p, rows, s);
+#endif
     const bool ws_ok = p.W >= 32 && p.Cin >= 48;
     if (ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512))) {
         if constexpr (TERMS == 3) {        // pixel-level compaction when the caller passes the per-tile lists (sean_model.cpp)

@@ -466,22 +466,34 @@ struct WinoAceParams {
     const float *bias_g, *bias_b, *bn_a, *bn_d, *nv;
     const float* noise;     // plane base of this ACE, sample stride noise_bstride, layout [W][H]
     long long noise_bstride;
-    const uint8_t* qlist;   // [ntiles][256] boundary quads of each tile of 32 x 32 pixels (qy * 16 + qx), raster order
+    const uint8_t* qlist;   // [ntiles][8 TH] boundary quads of each tile of 32 x TH pixels (qy * 16 + qx), raster order
+    int TH;                 // tile height 16 / 32 the lists were built with
     const int* qcnt;        // [ntiles]
     const unsigned* work;   // tile | row pair << 20 | part << 30 (part = which 64 of the tile's listed quads)
     const int* total;       // [0] = entries of `work`
     const float* zero;
     int nrt, ntx, nty, K;   // set by the launcher
 };
-// tiles of 32 x 32 pixels (16 x 16 quads) here: a sparse tile must hold enough boundary quads to fill the block's waves
-constexpr int WA_TH = 32, WA_PROWS = WA_TH + 2, WA_PS = 1248;      // plane stride 1248 = 19 * 64 + 32 floats (34 * 36 = 1224 used)
-constexpr int WA_NPD = 10, WA_PDW = WA_NPD * 512;                   // 10 patch DMA instructions per thread per k-step
-constexpr int WA_NST = 4, WA_ADW = 2 * wino::ADW, WA_SDW = WA_PDW + WA_ADW, WA_NLD = WA_NPD + 2;
-constexpr int WA_LDS_BYTES = WA_NST * WA_SDW * 4;            // 144 KB
+// Tile height 32 (16 x 16 quads) or 16 (16 x 8 quads), chosen per resolution level by the caller: a sparse tile must hold enough
+// boundary quads to fill the block's waves (512^2 on the benchmark labels: about 30 boundary quads per 32 x 16 tile, half of the
+// waves idle, and a k-step costs nearly the same with four busy waves as with eight: 13.8 -> 9.6 ms for the level's three ACEs
+// with the taller tile), but the taller patch costs 20 instead of 12 KB of DMA per k-step and one ring stage (256^2: 8.1 vs 9.6).
+template <int TH_>
+struct WaCfg {
+    static constexpr int TH = TH_, PROWS = TH + 2, NQ = 8 * TH;              // quads per tile
+    static constexpr int PS = TH == 32 ? 1248 : wino::PS;                     // plane stride (floats), = 32 mod 64
+    static constexpr int NPD = TH == 32 ? 10 : 6, PDW = NPD * 512;            // patch DMA instructions per thread per k-step
+    static constexpr int NST = TH == 32 ? 4 : 5;                              // ring depth
+    static constexpr int ADW = 2 * wino::ADW, SDW = PDW + ADW, NLD = NPD + 2;
+    static constexpr int LDS_BYTES = NST * SDW * 4;                           // 144 KB / 140 KB
+};
 
-template <int DUMMY>
+template <int TH_>
 __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p) {
     using namespace wino;
+    using Cfg = WaCfg<TH_>;
+    constexpr int WA_TH = Cfg::TH, WA_PROWS = Cfg::PROWS, WA_PS = Cfg::PS, WA_NPD = Cfg::NPD, WA_PDW = Cfg::PDW, WA_NST = Cfg::NST;
+    constexpr int WA_SDW = Cfg::SDW, WA_NLD = Cfg::NLD, WA_NQ = Cfg::NQ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -532,9 +544,9 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     auto issue_part = [&](int part) {
         const bool hid = is < nks;
         const unsigned wb = islot + (unsigned)wave * 256u;
-        if (part < 3) {                                     // 3 + 3 + 4 patch DMAs
+        if (part < 3) {                                     // 3 + 3 + 4 (2 + 2 + 2) patch DMAs
 #pragma unroll
-            for (int i = 3 * part; i < (part == 2 ? WA_NPD : 3 * part + 3); ++i) wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
+            for (int i = (WA_NPD / 3) * part; i < (part == 2 ? WA_NPD : (WA_NPD / 3) * (part + 1)); ++i) wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
             return;
         }
         const unsigned wa = islot + WA_PDW * 4u + (unsigned)wave * 1024u;
@@ -583,7 +595,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
         c.active = grp * 16 < cnt && c.rt < p.nrt;
         const int qi = grp * 16 + n;
         c.valid = c.active && qi < cnt;
-        const int q = p.qlist[(long long)c.tile * 256 + (qi < cnt ? qi : (cnt > 0 ? cnt - 1 : 0))];
+        const int q = p.qlist[(long long)c.tile * WA_NQ + (qi < cnt ? qi : (cnt > 0 ? cnt - 1 : 0))];
         c.qy = q >> 4;
         c.qx = q & 15;
         c.boff = kk * WA_PS + (2 * c.qy) * PWP + 2 * c.qx;
@@ -771,9 +783,9 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s);     // conv_inst_wino.h
 hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s);
 // wsty[b][rt][s][idx][lane][4] <- Winograd transform of the style LUT lut[(b*19 + j)][tap][gamma|beta][C] (exact-f32 layout)
 hipError_t wino_style_pack(const float* lut, float* wsty, int B, int C, hipStream_t s);
-// boundary quads of every 32 x 32 tile (from the interior map u5 of ace_classify) and the block tasks of conv_wino_ace
+// boundary quads of every 32 x TH tile (from the interior map u5 of ace_classify) and the block tasks of conv_wino_ace
 // (u5 == nullptr: every quad is a boundary quad -- levels without the interior reduction); pcnt: boundary pixels per tile; total: 8 ints
-hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int* pcnt, int B, int H, int W, hipStream_t s);
+hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int* pcnt, int B, int H, int W, int TH, hipStream_t s);
 hipError_t wino_ace_worklist(const int* qcnt, const int* pcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s);
 
 }  // namespace chk

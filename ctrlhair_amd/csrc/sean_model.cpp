@@ -495,8 +495,9 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 if (r < 32 || r % 32) continue;
                 WinoLevel& L = wq_level[k];
                 if (!L.qlist) {
-                    L.cap_tiles = mb * (r / 32) * (r / 32);
-                    L.qlist = static_cast<uint8_t*>(B.dalloc((size_t)L.cap_tiles * 256));
+                    L.TH = wino_tile_h(r);
+                    L.cap_tiles = mb * (r / 32) * (r / L.TH);
+                    L.qlist = static_cast<uint8_t*>(B.dalloc((size_t)L.cap_tiles * 8 * L.TH));
                     L.qcnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
                     L.pcnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
                 }
@@ -724,9 +725,9 @@ struct Runner {
                     o.S = &S;
                 }
         }
-        const int ntiles = B * (r / 32) * (r / 32);
+        const int ntiles = B * (r / 32) * (r / L.TH);
         if (!wq_done[k]) {
-            check(wino_quad_lists(o.S ? o.S->u5 : nullptr, L.qlist, L.qcnt, L.pcnt, B, r, r, st), "wino_quad_lists");
+            check(wino_quad_lists(o.S ? o.S->u5 : nullptr, L.qlist, L.qcnt, L.pcnt, B, r, r, L.TH, st), "wino_quad_lists");
             wq_done[k] = true;
         }
         bool done = false;
@@ -954,6 +955,7 @@ struct Runner {
             w.noise = noise + noff;
             w.noise_bstride = (long long)nf;
             w.qlist = wp.L->qlist;
+            w.TH = wp.L->TH;
             w.qcnt = wp.L->qcnt;
             w.work = wp.W->work;
             w.total = wp.W->total;
@@ -1026,15 +1028,15 @@ struct Runner {
             ip.out_scale = a.out_scale;
             ip.out_amax = m.amax_slots + 2 * a.index;
             ip.bf16 = m.terms == 2;
-            ip.variant = m.use_sh16 ? (compact ? 1 : 0) : ((m.dbg & 65536) ? 1 : ((m.dbg & 1048576) ? 2 : 0));
+            ip.variant = m.use_sh16 ? (compact ? 1 : 0) : (CH_ABL(m.dbg & 65536) ? 1 : (CH_ABL(m.dbg & 1048576) ? 2 : 0));
             // blocks of 32 x 8 pixels; mostly-interior blocks write every pixel (the conv below overwrites the boundary pixels).
             // Exact-f32 pass: filling pays only where x is read at full size (measured, tools/interior_bench.hip).
             // dbg bit 2097152: the row-shaped kernels of the first version (A/B)
-            ip.impl = (m.dbg & 2097152) ? 1 : 0;
+            ip.impl = CH_ABL(m.dbg & 2097152) ? 1 : 0;
             ip.fill_min = m.use_sh16 ? 128 : (x_up ? 257 : 128);
             // (impl 2, four pixels per thread: 10 % ahead at 512^2 in tools/interior_bench.hip, no difference in the generator
             // step -- 159.7 vs 159.9 images/s -- so the one-pixel kernel stays; dbg bit 16777216 selects it)
-            if (!m.use_sh16 && (m.dbg & 16777216) && r >= 128) {
+            if (!m.use_sh16 && CH_ABL(m.dbg & 16777216) && r >= 128) {
                 ip.impl = 2;
                 ip.fill_min = 128;
             }

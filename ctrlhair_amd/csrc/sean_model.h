@@ -109,7 +109,11 @@ struct SeanModel {
     // Winograd ACE path (conv_wino.h wino_ace_kernel): per resolution level the boundary quads of every 32 x 16 tile and one task
     // list per distinct row-tile count; per-sample style images of the ACE being run
     struct WinoWork { int nrt = 0; unsigned* work = nullptr; int* total = nullptr; };
-    struct WinoLevel { uint8_t* qlist = nullptr; int* qcnt = nullptr; int* pcnt = nullptr; int cap_tiles = 0; std::vector<WinoWork> works; };
+    struct WinoLevel { uint8_t* qlist = nullptr; int* qcnt = nullptr; int* pcnt = nullptr; int cap_tiles = 0, TH = 16; std::vector<WinoWork> works; };
+    int wino_th = 0;                           // option "sean.wino_th": tile height 16 / 32 of the Winograd ACE kernel (0 = by level)
+    // measured per level at B = 16, 512^2 on the benchmark labels (ms for the level's three ACEs, tiles of 32 x 16 / 32 x 32):
+    // 512^2 13.8 / 9.6, 256^2 8.1 / 9.6, 128^2 7.9 / 7.1, 64^2 4.1 / 4.8
+    int wino_tile_h(int r) const { return (wino_th == 16 || wino_th == 32) ? (r % wino_th ? 16 : wino_th) : ((r >= 512 || r == 128) ? 32 : 16); }
     WinoLevel wq_level[6];
     float* wsty = nullptr;
     int* prof_stats = nullptr;                 // profiling: snapshots of the work-list statistics of sparse launches (16 B each)

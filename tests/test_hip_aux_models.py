@@ -12,6 +12,17 @@ from tests.golden_util import GOLDEN
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
 _c = {}
+MAX_TIE_FRACTION = 5e-4      # label pixels allowed to differ from the reference's argmax (all of them inside its low-margin set)
+
+
+def _tie_account(what, bad, low_margin):
+    """Integer outputs are an argmax over fp32 logits that legitimately differ at the 1e-6 level: a pixel may flip only where the
+    REFERENCE's own top-2 margin is tiny, and the number of flips is measured and bounded -- 'identical up to ties' as a
+    statement with a count."""
+    nbad, nlow, n = int(bad.sum()), int(low_margin.sum()), bad.size
+    print(f'{what}: {nbad} of {n} pixels differ ({nbad / n:.2e}); low-margin pixels of the reference: {nlow} ({nlow / n:.2e})')
+    assert not (bad & ~low_margin).any(), f'{what}: {int((bad & ~low_margin).sum())} differences outside the low-margin set'
+    assert nbad <= MAX_TIE_FRACTION * n, f'{what}: {nbad} tie flips exceed {MAX_TIE_FRACTION:.0e} of {n} pixels'
 
 
 def env():
@@ -74,7 +85,7 @@ def test_shape_branch_golden(hip_lib):
     assert np.abs(fl.cpu().numpy()[:, :, ::4, ::4] - z['face_logit_sub4']).max() <= TOL
     assert np.abs(fl.cpu().numpy()[:, :, 96:160, 96:160] - z['face_logit_crop']).max() <= TOL
     bad = out.cpu().numpy() != z['out_labels']
-    assert not (bad & (z['margin'].astype(np.float32) > 1e-3)).any(), int(bad.sum())
+    _tie_account('shape decoder labels', bad, z['margin'].astype(np.float32) <= 1e-3)
     assert torch.equal(mask_one_hot_to_label(probs).to(torch.uint8), out)
     assert torch.equal(mask_one_hot_to_label(sg.forward_decoder(hl, fl)).to(torch.uint8), out)
     assert float((probs.sum(1) - 1).abs().max()) < 1e-4
@@ -109,7 +120,7 @@ def test_bisenet_golden(hip_lib, name):
     assert np.abs(lg[:, :, ::8, ::8] - z['logits_sub8']).max() <= TOL
     assert np.abs(lg[:, :, 100:164, 60:124] - z['logits_crop']).max() <= TOL
     bad = lab.cpu().numpy() != z['labels']
-    assert not (bad & (z['margin'].astype(np.float32) > 1e-3)).any(), int(bad.sum())
+    _tie_account(f'BiSeNet labels {name}', bad, z['margin'].astype(np.float32) <= 1e-3)
     lab2, _ = e['bise'].parse_tensor(img)
     assert torch.equal(lab, lab2)
 

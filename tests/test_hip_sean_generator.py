@@ -13,8 +13,8 @@ TOL = 1e-3
 # exact-f32 MFMA kernel | 3-term split-operand f16 MFMA kernels (conv_sh16.h), default dispatch | the same with every
 # eligible layer forced onto the wave-specialised persistent kernel | ... SPADE convs on the experimental kernel of
 # conv_sh16_ws2.h (epilogue pipelined into the next tile's k-loop) | ... onto the 2-blocks-per-CU kernel
-PATHS = ['f32', 'f16x3', 'f16x3ws', 'f16x3ws2', 'f16x3nows']
-DBG = {'f16x3ws': 64, 'f16x3ws2': 64 | 2048, 'f16x3nows': 128}
+PATHS = ['f32', 'f16x3', 'f16x3ws', 'f16x3nows']
+DBG = {'f16x3ws': 64, 'f16x3nows': 128}
 PATH_TOL = {'f16': 5e-2, 'bf16': 5e-2}      # single-term f16 / bf16 operands: the reduced-precision configuration (BASELINE.json
 #                                            configs[4]: 'bf16 MFMA conv path, tolerance 5e-2 vs fp32 reference')
 
@@ -228,26 +228,29 @@ def test_reduced_precision_paths_against_exact(hip_lib):
     assert err['f16'][1] < err['bf16'][1]          # 11 vs 8 significand bits
 
 
-@pytest.mark.parametrize('path', ['f32', 'f16x3'])
-def test_golden_batch16_full_size(hip_lib, path):
-    """BASELINE.json configs[1] as benchmarked: ngf=64, 512x512, max_batch=16, B=16 in ONE call.  Samples 0-2 are the inputs
-    of the reference-made fixtures ngf64_S512_ui (1) and ngf64_S512_B2 (2) and must reproduce them; samples 3-15 are
-    seeded synthetic inputs and must equal the same sample rendered alone (no cross-sample op)."""
+@pytest.mark.parametrize('path,B', [('f32', 16), ('f16x3', 16), ('f32', 32), ('bf16', 32)])
+def test_golden_batch16_full_size(hip_lib, path, B):
+    """BASELINE.json configs[1] as benchmarked (ngf=64, 512x512, max_batch=16, B=16 in ONE call), the per-GPU shape of configs[3]
+    (B=256 on 8 GPUs = max_batch 32 per rank, fp32) and of configs[4] (bf16 operands, 32 per GPU, tolerance 5e-2).  Samples 0-2
+    are the inputs of the reference-made fixtures ngf64_S512_ui (1) and ngf64_S512_B2 (2) and must reproduce them; the other
+    samples are seeded synthetic inputs and must equal the same sample rendered alone (no cross-sample op)."""
     from ctrlhair_amd import procedural as P
     ui, b2 = Case('ngf64_S512_ui'), Case('ngf64_S512_B2')
-    ngf, S, B = 64, 512, 16
+    ngf, S = 64, 512
     assert ui.wseed == b2.wseed == 0
-    gen = _gen(_sds.setdefault((ngf, 0), P.sean_state_dict(0, ngf)), 16, S, f16x3={'f32': 0}.get(path, 1))
-    labels = np.concatenate([ui.labels, b2.labels, P.blocky_labels(13, S, seed=900)])
-    codes = np.concatenate([ui.codes, b2.codes, P.style_codes(13, seed=901)])
-    noise = np.concatenate([ui.noise, b2.noise, P.noise_planes(13, S, ngf, seed=902)])
+    gen = _gen(_sds.setdefault((ngf, 0), P.sean_state_dict(0, ngf)), B, S, f16x3={'f32': 0, 'bf16': 3}.get(path, 1))
+    labels = np.concatenate([ui.labels, b2.labels, P.blocky_labels(B - 3, S, seed=900)])
+    codes = np.concatenate([ui.codes, b2.codes, P.style_codes(B - 3, seed=901)])
+    noise = np.concatenate([ui.noise, b2.noise, P.noise_planes(B - 3, S, ngf, seed=902)])
     img = _run(gen, labels, codes, noise)
     assert np.isfinite(img).all()
     d_ui, d_b2 = ui.diff_samples(img[0:1], [0]), b2.diff_samples(img[1:3], [0, 1])
-    print(f'{path}: B=16 batch vs reference fixtures: {d_ui:.3e} (ui), {d_b2:.3e} (B2)')
-    assert d_ui <= TOL and d_b2 <= TOL
-    for i in (3, 9, 15):
+    print(f'{path}: B={B} batch vs reference fixtures: {d_ui:.3e} (ui), {d_b2:.3e} (B2)')
+    tol = PATH_TOL.get(path, TOL)
+    assert d_ui <= tol and d_b2 <= tol
+    for i in (3, 9, B - 1):
         one = _run(gen, labels[i:i + 1], codes[i:i + 1], noise[i:i + 1])
         # the same f32 sums in another association (split-K follows the grid size, i.e. the batch): measured 0.6e-5 ... 1.1e-5
-        assert np.abs(one[0] - img[i]).max() <= 2e-5
+        # (bf16 operands: the scale protocol may pick another power of two for another batch)
+        assert np.abs(one[0] - img[i]).max() <= (2e-5 if path != 'bf16' else 2e-2)
     gen.handle.close()

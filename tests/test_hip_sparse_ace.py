@@ -135,7 +135,13 @@ def test_interior_and_label_table_kernels_match_their_first_versions(hip_lib, pa
     codes, noise = P.style_codes(B), P.noise_planes(B, S, ngf)
     new = _gen(sd, B, S, path, 1)
     old = _gen(sd, B, S, path, 1)
-    old.handle.set_option('sean.dbg', (64 if path == 'f16x3' else 0) | 2097152 | 33554432)
+    try:
+        old.handle.set_option('sean.dbg', (64 if path == 'f16x3' else 0) | 2097152 | 33554432)
+    except RuntimeError as e:        # the superseded kernels only exist in A/B builds (make -C ctrlhair_amd/csrc ABLATE=1)
+        new.handle.close()
+        old.handle.close()
+        assert 'CH_ABLATE' in str(e)
+        pytest.skip('library built without -DCH_ABLATE: the first-version kernels are not in it')
     sets = _label_sets(B, S)
     for name in ('face', 'blocky', 'noclass', 'stripes5'):
         a, b = _run(new, sets[name], codes, noise), _run(old, sets[name], codes, noise)

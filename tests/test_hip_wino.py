@@ -1,0 +1,100 @@
+"""GPU tests of the Winograd F(2x2,3x3) kernels of the exact-f32 path (ctrlhair_amd/csrc/conv_wino.h): the ResBlock 3x3 convs
+(/root/reference/sean_codes/models/networks/architecture.py:82-91) and the SPADE gamma/beta conv + style convs over the boundary
+quads (normalization.py:117-153,172-173,249-257).
+
+The golden / oracle tests of test_hip_sean_generator.py already run with them on (option sean.wino = 1 is the default of the
+exact-f32 path); here the library is compared with ITSELF on the direct evaluation (sean.wino = 0) at a tolerance far inside the
+parity bound, on the shapes that exercise the kernels' edge cases: a single 16-channel row tile (ngf = 16: the second row tile
+of a pair does not exist), levels below 32 pixels (direct kernels), S < max_size, ragged batches, labels >= 19 at tile borders,
+label maps with no interior pixel, both tile heights of the ACE kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(sd, mb, ms, wino, extra=None):
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    opts = {'sean.wino': wino}
+    opts.update(extra or {})
+    return SeanGenerator(0, f16x3=0, options=opts).load_state_dict(sd, max_batch=mb, max_size=ms)
+
+
+def _run(gen, labels, codes, noise):
+    dev = gen.device
+    out = gen.generate(torch.from_numpy(labels).to(dev), torch.from_numpy(codes).to(dev), torch.from_numpy(noise).to(dev))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _label_sets(B, S):
+    from ctrlhair_amd import procedural as P
+    sets = {'blocky': P.blocky_labels(B, S, grid=8), 'face': np.stack([P.face_like_labels(S, 40 + b) for b in range(B)])}
+    diag = (np.add.outer(np.arange(S), np.arange(S)) % 19).astype(np.uint8)          # no interior pixel at any resolution
+    sets['diag'] = np.repeat(diag[None], B, 0)
+    edge = P.blocky_labels(B, S, grid=4, seed=5).copy()                              # 'no class' labels across tile borders
+    edge[:, 30:34, :] = 255
+    edge[:, :, 62:66] = 19
+    edge[:, S // 2:, : S // 2] = 200
+    sets['noclass_at_tile_borders'] = edge
+    sets['one_region'] = np.full((B, S, S), 13, np.uint8)                            # interior everywhere but the image frame
+    return sets
+
+
+@pytest.mark.parametrize('S,th', [(64, 0), (128, 16), (128, 32)])
+def test_winograd_equals_direct_tiny(hip_lib, S, th):
+    """ngf = 16, max_size 128: one row tile per ACE at the last level, levels of 2 ... 16 pixels on the direct kernels."""
+    from ctrlhair_amd import procedural as P
+    ngf, B = 16, 3
+    sd = P.sean_state_dict(0, ngf)
+    direct = _gen(sd, B, 128, 0)
+    wino = _gen(sd, B, 128, 1, {'sean.wino_th': th} if th else None)
+    codes, noise = P.style_codes(B, seed=3), P.noise_planes(B, S, ngf, seed=4)
+    for name, lab in _label_sets(B, S).items():
+        a, b = _run(direct, lab, codes, noise), _run(wino, lab, codes, noise)
+        assert np.isfinite(b).all()
+        d = float(np.abs(a - b).max())
+        print(f'ngf16 S={S} th={th} {name}: max |winograd - direct| = {d:.3e}')
+        assert d <= 2e-5, name
+        assert np.array_equal(b, _run(wino, lab, codes, noise)), 'repeated call differs'
+    one = _run(wino, _label_sets(B, S)['face'][1:2], codes[1:2], noise[1:2])          # ragged batch: one sample of three
+    assert np.abs(one[0] - _run(wino, _label_sets(B, S)['face'], codes, noise)[1]).max() <= 2e-5
+    direct.handle.close()
+    wino.handle.close()
+
+
+def test_winograd_equals_direct_ngf64(hip_lib):
+    """ngf = 64 at 256^2 (all four Winograd levels 32 ... 256, styled and unstyled ACEs, 64 row tiles at C = 1024) and against
+    the oracle."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    ngf, S, B = 64, 256, 2
+    sd = P.sean_state_dict(0, ngf)
+    direct, wino = _gen(sd, B, S, 0), _gen(sd, B, S, 1)
+    codes, noise = P.style_codes(B, seed=8), P.noise_planes(B, S, ngf, seed=9)
+    sets = _label_sets(B, S)
+    for name in ('face', 'blocky', 'noclass_at_tile_borders', 'diag'):
+        a, b = _run(direct, sets[name], codes, noise), _run(wino, sets[name], codes, noise)
+        d = float(np.abs(a - b).max())
+        print(f'ngf64 {name}: max |winograd - direct| = {d:.3e}')
+        assert d <= 2e-5, name
+    ref = O.generator_forward(O.to_torch(sd), sets['face'][:1], codes[:1], noise[:1], ngf).numpy()
+    assert np.abs(_run(wino, sets['face'][:1], codes[:1], noise[:1]) - ref).max() <= 1e-3
+    # executed-FLOP accounting of the plain convs: 16 / 36 of the dense count on the Winograd levels
+    wino.handle.profile_enable(True)
+    _run(wino, sets['face'], codes, noise)
+    wino.handle.profile_enable(False)
+    plain = wino.handle.profile_read(0)
+    wino.handle.profile_read(-1)
+    assert 16 / 36 - 1e-9 <= plain['flops_executed'] / plain['flops'] <= 0.62       # (+ the direct 1x1 shortcuts and 8 / 16-pixel levels)
+    direct.handle.close()
+    wino.handle.close()
+
+
+def test_option_must_precede_finalize(hip_lib):
+    from ctrlhair_amd import procedural as P
+    g = _gen(P.sean_state_dict(0, 16), 1, 64, 1)
+    with pytest.raises(RuntimeError):
+        g.handle.set_option('sean.wino', 0)
+    g.handle.close()

@@ -51,8 +51,9 @@ def test_stages_against_reference_fixture(pipe):
     lab = pipe.parse(img).cpu().numpy()
     low = np.unpackbits(z['labels_low_margin'])[:lab.size].reshape(lab.shape).astype(bool)
     diff = lab != z['labels']
-    print(f'parse: {int(diff.sum())} label differences, {int(low.sum())} low-margin pixels')
+    print(f'parse: {int(diff.sum())} of {diff.size} label pixels differ, {int(low.sum())} low-margin pixels')
     assert not (diff & ~low).any()
+    assert diff.sum() <= 5e-4 * diff.size      # 'identical up to ties' with a measured bound
     labels = torch.from_numpy(z['labels']).to(dev)
     # analyse on the reference's label map
     lat = pipe.analyse(img, labels)
@@ -77,8 +78,9 @@ def test_stages_against_reference_fixture(pipe):
     mask = mask.cpu().numpy()
     lowm = np.unpackbits(z['mask_low_margin'])[:mask.size].reshape(mask.shape).astype(bool)
     dm = mask != z['mask']
-    print(f'shape decoder: {int(dm.sum())} label differences, {int(lowm.sum())} low-margin pixels')
+    print(f'shape decoder: {int(dm.sum())} of {dm.size} label pixels differ, {int(lowm.sum())} low-margin pixels')
     assert not (dm & ~lowm).any()
+    assert dm.sum() <= 5e-4 * dm.size
     # generator on the reference's mask (steps over possible ties of the decoder)
     image, _ = pipe.render(ed, noise=noise, mask=torch.from_numpy(z['mask']).to(dev))
     torch.cuda.synchronize()
