@@ -411,6 +411,7 @@ def main():
         respawn_under_torchrun(args.gpus)
     # ONE per-GPU batch for every N of a scaling curve (N = 1 must be the workload of N = 8)
     gen_batch = args.batch if args.batch > 0 else 16
+    user_batch = args.batch
     pipe_batch = args.batch if args.batch > 0 else 8
 
     import torch
@@ -475,7 +476,7 @@ def main():
         # side legs of the exact-f32 number of record (shorter runs, same protocol): the per-GPU shape of configs[3] (32 images
         # per GPU), and at N = 1 the same job without the Winograd convs and without the SPADE-interior reduction (worst case)
         side = {}
-        if args.path == 'f32' and (extras or world == 8) and args.batch == 0:
+        if args.path == 'f32' and (extras or world == 8) and user_batch == 0:
             variants = [('configs3_b32_per_gpu', {'batch': 32})]
             if extras:
                 variants += [('direct_convs_no_winograd', {'wino': 0}), ('dense_worst_case_no_interior_reduction', {'sparse': 0})]

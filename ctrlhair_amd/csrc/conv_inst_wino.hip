@@ -1,4 +1,5 @@
 // conv_inst_wino.hip -- instantiations + launchers of the Winograd F(2x2,3x3) exact-f32 MFMA kernels (conv_wino.h)
+#include "conv_pw.h"
 #include "conv_wino.h"
 
 namespace chk {
@@ -38,6 +39,26 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+template <int RT>
+static hipError_t launch_pw(PwParams p, hipStream_t s) {
+    using Cfg = PwCfg<RT>;
+    static bool d0[64] = {};
+    hipError_t e = wino_attr(pw_conv_kernel<RT>, Cfg::LDS_BYTES, d0);
+    if (e != hipSuccess) return e;
+    const int nrt = (p.Cout + 31) / 32;
+    p.nrg = (nrt + RT - 1) / RT;
+    p.npt = p.HW / Cfg::PXB;
+    p.ntasks = p.B * p.npt * p.nrg;
+    p.nst = p.Cin / 16;
+    const int grid = p.ntasks < wino_num_cus() ? p.ntasks : wino_num_cus();
+    hipLaunchKernelGGL(pw_conv_kernel<RT>, dim3(grid), dim3(512), Cfg::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+hipError_t conv_pw(PwParams p, hipStream_t s) {
+    if (!pw_supported(p.Cin, p.Cout, p.HW)) return hipErrorInvalidValue;
+    return (p.Cout + 31) / 32 >= 4 ? launch_pw<4>(p, s) : launch_pw<2>(p, s);
+}
 
 template <int TH>
 static hipError_t launch_wino_ace(const WinoAceParams& p, hipStream_t s) {

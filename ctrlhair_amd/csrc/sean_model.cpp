@@ -17,6 +17,7 @@
 #include "conv_ace_sparse.h"
 #include "conv_mfma.h"
 #include "conv_sh16.h"
+#include "conv_pw.h"
 #include "conv_wino.h"
 #include "kernels.h"
 #include "sh16.h"
@@ -129,6 +130,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             } else {
                 cw.wpk = B.upload(pack_A(r.cout, r.cin, r.ks, r.ks == 3 ? CK_KS3 : CK_KS1, getw));
                 if (wino && r.ks == 3 && r.cin % 8 == 0) cw.wino = B.upload(pack_wino_A(r.cout, r.cin, getw));
+                if (wino && r.ks == 1 && r.cin % 16 == 0) cw.pw = B.upload(pack_pw_A(r.cout, r.cin, [&](int row, int ci) { return getw(row, ci, 0); }));
             }
             cw.Cout = r.cout;
             cw.Cin = r.cin;
@@ -1137,6 +1139,19 @@ struct Runner {
             timed(0, 2.0 * w.Cout * w.Cin * 9.0 * npix,
                   4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * 16.0),
                   [&] { check(conv_wino_plain(q, st), "conv (winograd)"); });
+            return;
+        }
+        if (m.wino && !m.use_sh16 && w.pw && w.KS == 1 && !w2 && !res && !w.bias && pw_supported(w.Cin, w.Cout, r * r)) {
+            PwParams q{};         // the learned shortcut conv_s: dedicated 1x1 kernel (conv_pw.h)
+            q.in = in;
+            q.wpk = w.pw;
+            q.out = out;
+            q.B = B;
+            q.Cin = w.Cin;
+            q.Cout = w.Cout;
+            q.HW = r * r;
+            timed(0, 2.0 * w.Cout * w.Cin * npix, 4.0 * (npix * w.Cin + npix * w.Cout + (double)w.Cout * w.Cin),
+                  [&] { check(conv_pw(q, st), "conv 1x1"); });
             return;
         }
         timed(0, 2.0 * w.Cout * (w.Cin * k2 + cin2) * npix,

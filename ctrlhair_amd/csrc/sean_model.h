@@ -18,6 +18,7 @@ struct ConvW {
     float* bias = nullptr;
     float* wscale = nullptr;                    // f16x3 path: per-row 2^-k undoing the weight scaling (sh16.h)
     float* wino = nullptr;                      // exact-f32 path, 3x3: Winograd F(2x2,3x3) image U = G g G^T (conv_wino.h)
+    float* pw = nullptr;                        // exact-f32 path, 1x1: pack_pw_A image (conv_pw.h)
     int Cout = 0, Cin = 0, KS = 0;
 };
 

@@ -14,6 +14,11 @@ using namespace chk;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
+static float frand(unsigned& s) {
+    s = s * 1664525u + 1013904223u;
+    return ((s >> 8) & 0xFFFF) / 32768.f - 1.f;
+}
+
 // direct conv, one thread per output, f32 fma chain in (ci, tap) order, double accumulation option off
 __global__ void ref_conv_kernel(const float* in, const float* w, const float* bias, const float* res, int res_up, const float* in2,
                                 const float* w2, int Cin2, float* out, int B, int Cin, int Cout, int H, int W) {
@@ -33,14 +38,67 @@ __global__ void ref_conv_kernel(const float* in, const float* w, const float* bi
     }
 }
 
-static float frand(unsigned& s) {
-    s = s * 1664525u + 1013904223u;
-    return ((s >> 8) & 0xFFFF) / 32768.f - 1.f;
-}
-
 struct Shape { int B, Cin, Cout, H, Cin2, res; const char* name; };   // res: 0 none, 1 same size, 2 upsampled
 
+__global__ void ref_pw_kernel(const float* in, const float* w, float* out, int B, int Cin, int Cout, int HW) {
+    const long long n = (long long)B * Cout * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % HW), co = (int)((i / HW) % Cout), b = (int)(i / ((long long)HW * Cout));
+        double acc = 0;
+        for (int ci = 0; ci < Cin; ++ci) acc += (double)w[(long long)co * Cin + ci] * in[((long long)b * Cin + ci) * HW + px];
+        out[i] = (float)acc;
+    }
+}
+
+static int run_pw() {      // the four learned shortcuts of the ngf = 64 generator at 512^2, B = 16 (+ two small shapes)
+    struct S1 { int B, Cin, Cout, H; };
+    const S1 all[] = {{2, 32, 48, 32}, {1, 64, 32, 16}, {16, 1024, 512, 64}, {16, 512, 256, 128}, {16, 256, 128, 256}, {16, 128, 64, 512}};
+    double tot = 0;
+    for (const S1& c : all) {
+        const int HW = c.H * c.H;
+        const size_t nin = (size_t)c.B * c.Cin * HW, nout = (size_t)c.B * c.Cout * HW;
+        unsigned seed = 777u + c.Cin;
+        std::vector<float> hin(nin), hw((size_t)c.Cout * c.Cin);
+        for (auto& v : hin) v = frand(seed);
+        for (auto& v : hw) v = frand(seed) / sqrtf((float)c.Cin);
+        const float* wp = hw.data();
+        const int Cin = c.Cin;
+        std::vector<float> pk = pack_pw_A(c.Cout, c.Cin, [&](int row, int ci) { return wp[(size_t)row * Cin + ci]; });
+        float *d_in, *d_w, *d_pk, *d_out, *d_ref;
+        CK(hipMalloc(&d_in, nin * 4)); CK(hipMalloc(&d_w, hw.size() * 4)); CK(hipMalloc(&d_pk, pk.size() * 4 + 64));
+        CK(hipMalloc(&d_out, nout * 4)); CK(hipMalloc(&d_ref, nout * 4));
+        CK(hipMemcpy(d_in, hin.data(), nin * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_pk, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(d_out, 0xFF, nout * 4));
+        PwParams p{};
+        p.in = d_in; p.wpk = d_pk; p.out = d_out; p.B = c.B; p.Cin = c.Cin; p.Cout = c.Cout; p.HW = HW;
+        CK(conv_pw(p, 0));
+        hipLaunchKernelGGL(ref_pw_kernel, dim3(4096), dim3(256), 0, 0, d_in, d_w, d_ref, c.B, c.Cin, c.Cout, HW);
+        CK(hipDeviceSynchronize());
+        std::vector<float> ho(nout), hr(nout);
+        CK(hipMemcpy(ho.data(), d_out, nout * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hr.data(), d_ref, nout * 4, hipMemcpyDeviceToHost));
+        double maxd = 0;
+        for (size_t i = 0; i < nout; ++i) { const double d = fabs((double)ho[i] - hr[i]); if (!(d <= maxd)) maxd = d; }
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; ++i) CK(conv_pw(p, 0));
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+        const double fl = 2.0 * c.B * HW * (double)c.Cout * c.Cin;
+        printf("1x1  B%2d %4d->%4d %3d^2  maxdiff %.3e %s  %8.3f ms  %6.1f TF/s\n", c.B, c.Cin, c.Cout, c.H, maxd, maxd <= 2e-5 ? "OK  " : "FAIL", ms, fl / ms * 1e-9);
+        if (c.B == 16) tot += ms;
+        hipFree(d_in); hipFree(d_w); hipFree(d_pk); hipFree(d_out); hipFree(d_ref);
+    }
+    printf("sum over the four shortcut convs of one step: %.2f ms\n", tot);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "pw")) return run_pw();
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
     const int dbg = argc > 2 && !strcmp(argv[1], "dbg") ? atoi(argv[2]) : 0;      // timing ablations (wrong results)
     const Shape all[] = {
