@@ -80,7 +80,8 @@ def _load_dirs(d: str) -> List[np.ndarray]:
 
 
 def reference_checkpoints(root: str = '.') -> Dict[str, object]:
-    """-> {'sean','shape','color_gen','color_dis','color_rgb','bisenet': state dicts; 'texture_dirs','shape_dirs': lists}."""
+    """-> {'sean','shape','color_gen','color_dis','color_rgb','bisenet': state dicts; 'texture_dirs','shape_dirs': lists;
+    '_origin': 'reference' -- HairEditor / EditPipeline default to the exact-f32 path for a dict that carries this tag}."""
     import torch
     ct = load_checkpoint(os.path.join(experiment_dir(root, 'color_texture'), 'checkpoints'))
     sh = load_checkpoint(os.path.join(experiment_dir(root, 'shape'), 'checkpoints'))
@@ -90,7 +91,8 @@ def reference_checkpoints(root: str = '.') -> Dict[str, object]:
             'color_dis': strip_module(ct['Model_D']), 'color_rgb': strip_module(rgb['Predictor']),
             'bisenet': torch.load(os.path.join(root, BISENET_FILE), map_location='cpu'),
             'texture_dirs': _load_dirs(os.path.join(experiment_dir(root, 'color_texture'), 'texture_dir_used')),
-            'shape_dirs': _load_dirs(os.path.join(experiment_dir(root, 'shape'), 'shape_dir_used'))}
+            'shape_dirs': _load_dirs(os.path.join(experiment_dir(root, 'shape'), 'shape_dir_used')),
+            '_origin': 'reference'}
 
 
 def write_reference_layout(root: str, weights: Dict[str, dict], texture_dirs=(), shape_dirs=(), ddp_prefix: bool = True,
@@ -142,15 +144,18 @@ def expected(ngf: int = 64) -> Dict[str, Dict[str, Tuple[int, ...]]]:
     from .hair_editor import procedural_weights
     # Only the shapes are wanted: the random-tensor makers of ctrlhair_amd.procedural are swapped for zero-stride views for
     # the duration of the call (no hundreds of MB of Gaussians, no power iterations); calibration tables are not applied.
-    saved = (P._normal, P._xavier, P.power_iterate, P.load_calibration)
     view = lambda shape: np.broadcast_to(np.float32(0), tuple(int(d) for d in shape))
-    try:
+    # P.MAKER_LOCK: the weight builders take the same (re-entrant) lock, so a concurrent procedural_weights() / sean_state_dict()
+    # call in another thread can never see the patched makers
+    with P.MAKER_LOCK:
+      saved = (P._normal, P._xavier, P.power_iterate, P.load_calibration)
+      try:
         P._normal = lambda seed, name, shape, std: view(shape)
         P._xavier = lambda seed, name, shape: view(shape)
         P.power_iterate = lambda w, seed, name, iters=60: (view((w.shape[0],)), view((int(np.prod(w.shape[1:])),)))
         P.load_calibration = lambda seed, ngf: {}              # (an empty table: nothing to apply, shapes unchanged)
         w = procedural_weights(0, ngf)
-    finally:
+      finally:
         P._normal, P._xavier, P.power_iterate, P.load_calibration = saved
     return {m: {k: _shape(v) for k, v in w[m].items()} for m in MODELS}
 

@@ -354,6 +354,10 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         return CH_OK;
     }
     if (std::strcmp(key, "sean.sparse") == 0) {     // exact SPADE-interior reduction (ace_sparse.h); buffers are sized at ch_finalize
+        // after ch_finalize the reduction can be switched OFF (and back on); a handle finalised without it has no classification
+        // buffers, and turning it on would silently do nothing
+        if (h->sean_ready && value != 0 && !h->sean.gtab)
+            return fail(h, CH_ERR_STATE, "ch_set_option(sean.sparse = 1): the handle was finalised with sean.sparse = 0 (no buffers); set it before ch_finalize");
         h->sean.sparse = value != 0;
         return CH_OK;
     }

@@ -41,7 +41,7 @@ from .checkpoints import reference_checkpoints      # noqa: E402,F401  (referenc
 class HipModels:
     """Builds every network of the path on one ch_handle (one GPU)."""
 
-    def __init__(self, weights: Dict[str, dict], device: int = 0, img_size: int = 256, max_batch: int = 1, f16x3=True,
+    def __init__(self, weights: Dict[str, dict], device: int = 0, img_size: int = 256, max_batch: int = 1, f16x3=None,
                  options: Optional[Dict[str, int]] = None):
         """f16x3: arithmetic of the SEAN generator / Zencoder convs (see SeanGenerator): True = split-operand f16 MFMA,
         f32-class results (default); False = exact-f32 MFMA; 2 = single-term f16 (reduced precision).
@@ -49,6 +49,8 @@ class HipModels:
         from .models import ColorTextureModels, FaceParsing, ShapeGenerator
         from .sean.generator import SeanGenerator
         from .sean.pix2pix_model import Pix2PixModel
+        if f16x3 is None:            # by the weights: exact f32 for a released checkpoint, f16x3 otherwise (is_released_checkpoint)
+            f16x3 = not is_released_checkpoint(weights)
         self.generator = SeanGenerator(device, f16x3=f16x3, options=options).load_state_dict(weights['sean'], max_batch=max_batch,
                                                                                            max_size=img_size)
         h, dev = self.generator.handle, self.generator.device
@@ -64,6 +66,14 @@ class HipModels:
         self.blender = PoissonBlender(h, dev)       # blending step after the generator (Backend(blending=True))
 
 
+def is_released_checkpoint(weights) -> bool:
+    """True for 'reference', a checkpoint directory, or a dict made by checkpoints.reference_checkpoints() (tagged '_origin'):
+    such weights default to the exact-f32 path everywhere (HairEditor, EditPipeline); procedural / untagged dicts to f16x3."""
+    if isinstance(weights, str):
+        return weights != 'procedural'
+    return isinstance(weights, dict) and weights.get('_origin') == 'reference'
+
+
 class HairEditor:
     """This is the basic module (hair_editor.py:40-43); ctrlhair_amd.ui.backend.Backend succeeds this class."""
 
@@ -75,7 +85,7 @@ class HairEditor:
         (tests/test_hip_robust_weights.py) but has never seen the real checkpoints, which cannot be fetched here.  Pass
         True / False to choose explicitly."""
         if f16x3 is None:
-            f16x3 = not (weights == 'reference' or (isinstance(weights, str) and weights != 'procedural'))
+            f16x3 = not is_released_checkpoint(weights)
         if models is None:
             if weights == 'procedural':
                 weights = procedural_weights()

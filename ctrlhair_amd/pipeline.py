@@ -69,8 +69,12 @@ def hsv_to_rgb_u8(hsv: torch.Tensor) -> torch.Tensor:
 
 class EditPipeline:
     def __init__(self, weights: Optional[Dict[str, dict]] = None, device: int = 0, img_size: int = 512, max_batch: int = 8,
-                 f16x3=1, models=None, texture_dirs=None, shape_dirs=None, hsv_table=None, options=None):
-        from .hair_editor import HipModels, procedural_weights
+                 f16x3=None, models=None, texture_dirs=None, shape_dirs=None, hsv_table=None, options=None):
+        """f16x3: None = by the weights, like HairEditor: 0 (exact f32) for a released checkpoint (a dict made by
+        checkpoints.reference_checkpoints), 1 (split-operand f16 MFMA, f32-class) for procedural / untagged weights."""
+        from .hair_editor import HipModels, is_released_checkpoint, procedural_weights
+        if f16x3 is None:
+            f16x3 = 0 if is_released_checkpoint(weights) else 1
         if models is None:
             models = HipModels(weights if weights is not None else procedural_weights(), device=device, img_size=img_size,
                                max_batch=max_batch, f16x3=f16x3, options=options)

@@ -13,7 +13,9 @@ Key families follow SURVEY.md Appendix A / the reference modules:
   normalization.py:71-106,191-247 and torch.nn.utils.spectral_norm
   (weight_orig / weight_u / weight_v buffers).
 """
+import functools
 import os
+import threading
 import zlib
 from typing import Dict, Optional
 
@@ -23,6 +25,19 @@ from .sean import arch
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
 CALIB_PATH = os.path.join(_DATA, 'sean_calib.npz')
+
+
+# Held by every state-dict builder below and by ctrlhair_amd.checkpoints.expected(), which swaps the tensor makers for shape-only
+# stand-ins while it runs: a builder in another thread must never see the swapped makers (re-entrant: builders call each other).
+MAKER_LOCK = threading.RLock()
+
+
+def _locked(fn):
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        with MAKER_LOCK:
+            return fn(*a, **k)
+    return wrapper
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:
@@ -101,6 +116,7 @@ def load_calibration(seed: int, ngf: int) -> Optional[Dict[str, np.ndarray]]:
     return out or None
 
 
+@_locked
 def sean_state_dict(seed: int = 0, ngf: int = 64, calibrated: bool = True,
                     with_zencoder: bool = True) -> Dict[str, np.ndarray]:
     """Full SPADEGenerator state dict (982 entries at any ngf) as numpy arrays."""
@@ -223,6 +239,7 @@ def _bn(sd, seed, p, C):
     sd[p + '.num_batches_tracked'] = np.zeros((), np.int64)
 
 
+@_locked
 def shape_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
     """shape_branch/model.py Generator(cfg 054): hair/face MaskEncoder (7 x conv4x4 s2 + custom LayerNorm) and
     MaskDecoder (Linear -> 7 x [up, conv3x3, LayerNorm] -> conv3x3).  241.0 M parameters."""
@@ -264,6 +281,7 @@ def shape_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
     return sd
 
 
+@_locked
 def color_state_dicts(seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:
     """color_texture_branch cfg 045: {'gen': EigenGenerator, 'dis': Discriminator (encoder), 'rgb': Predictor p004}."""
     gen: Dict[str, np.ndarray] = {}
@@ -295,6 +313,7 @@ def color_state_dicts(seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:
     return {'gen': gen, 'dis': dis, 'rgb': rgb}
 
 
+@_locked
 def bisenet_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
     """external_code/face_parsing/model.py BiSeNet(19) (+ resnet.py Resnet18): 13.3 M parameters, convs without bias,
     BatchNorm with random affine/running statistics so that BN folding is exercised."""

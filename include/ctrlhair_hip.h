@@ -54,7 +54,9 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
                     const int64_t* shape, int ndim);
 
 /* Options, set before ch_finalize.  "sean.f16x3" (default 0) selects the arithmetic of the SEAN generator's MFMA convs:
- *   0  exact f32 (v_mfma_f32_32x32x2_f32);
+ *   0  f32 throughout on the f32 matrix cores (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: every product and every sum an IEEE f32
+ *      operation); with "sean.wino" = 1 (default) the 3x3 convs are evaluated as Winograd F(2x2,3x3)
+ *      (ctrlhair_amd/csrc/conv_wino.h), with 0 directly (conv_mfma.h) -- two associations of the same f32 arithmetic;
  *   1  f16 matrix cores with the 3-term split-operand scheme of ctrlhair_amd/csrc/conv_sh16.h: f32-class accuracy, f32
  *      accumulation, activations between ACE and conv stored as f16 hi/lo pairs;
  *   2  f16 matrix cores, single term: operands rounded to f16, f32 accumulation and f32 normalisation / modulation
@@ -71,7 +73,15 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   inputs are bounded, so their scales are static; 0 = every conv on the exact-f32 kernels.
  * "bisenet.f16x3" (default 1): BiSeNet's convs on the f16x3 kernels; its f32 activations stay in the C4 layout and are split
  *   into f16 pairs while staged, with the scale derived from the maximum the producing kernel recorded; 0 = exact-f32 kernels.
- *   (The Zencoder follows "sean.f16x3".) */
+ *   (The Zencoder follows "sean.f16x3".)
+ * "sean.wino" (default 1; "sean.f16x3" = 0 only): the ResBlock 3x3 convs, the SPADE gamma/beta convs and the style convs as
+ *   Winograd F(2x2,3x3) on the f32 matrix cores, the learned 1x1 shortcuts on the pointwise kernel of conv_pw.h.
+ * "sean.wino_th": tile height 16 / 32 of the Winograd ACE kernel (0 = chosen per resolution level).
+ * "sean.sparse" (default 1): the exact SPADE-interior reduction (csrc/ace_sparse.h).  May be switched off (and back on) after
+ *   ch_finalize; a handle finalised with 0 has no classification buffers and rejects 1 afterwards (CH_ERR_STATE).
+ * "sean.sparse_min", "sean.sparse_th", "sean.sh16_compact": tuning knobs of that reduction (before ch_finalize).
+ * "sean.dbg": profiling switches.  The bits that skip work (wrong results) or select superseded kernel versions exist only in
+ *   libraries built with -DCH_ABLATE (make -C ctrlhair_amd/csrc ABLATE=1); the default build rejects them (CH_ERR_ARG). */
 int  ch_set_option(ch_handle* h, const char* key, int value);
 
 /* Fold + pack + upload the loaded tensors: spectral-norm sigma (torch spectral_norm eval semantics,

@@ -85,6 +85,13 @@ def test_editor_from_checkpoint_tree_equals_in_memory_weights(hip_lib, tree):
     # (a released checkpoint tree defaults to the exact-f32 path, in-memory / procedural weights to the split-operand path)
     d = HairEditor(True, True, weights=root, device=0)
     assert d.models.generator.f16x3 is False and b.models.generator.f16x3 is True
+    # ... and so does the same tree read into memory first (reference_checkpoints tags its dict)
+    from ctrlhair_amd import checkpoints as C
+    from ctrlhair_amd.hair_editor import is_released_checkpoint
+    mem = C.reference_checkpoints(root)
+    assert is_released_checkpoint(mem) and is_released_checkpoint(root) and not is_released_checkpoint(w)
+    e = HairEditor(True, True, weights=mem, device=0)
+    assert e.models.generator.f16x3 is False
     assert all(torch.equal(x, y) for x, y in zip(a.texture_dirs, b.texture_dirs))
     assert all(torch.equal(x, y) for x, y in zip(a.shape_dirs, b.shape_dirs))
     labels, codes = P.blocky_labels(1, 256, seed=3), P.style_codes(1, seed=4)
