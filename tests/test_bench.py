@@ -34,7 +34,7 @@ def test_force_dist_runs_the_rccl_path_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and 'RCCL all-gather' in line['config']['parallelism']
-    assert line['dtype'].startswith('f32 (exact-f32') and line['step_ms']['n'] == 3
+    assert line['dtype'].startswith('f32 (every product and sum an IEEE f32') and line['step_ms']['n'] == 3
     rf = line['roofline']
     assert rf['bound'] == 'mfma' and 0 < rf['frac'] < 1 and rf['flops_executed_per_launch_avg'] <= rf['flops_dense_per_launch_avg'] * 1.001
 
