@@ -70,17 +70,7 @@ struct WinoParams {
     const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image patch elements)
     // set by the launcher
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
-#ifdef WINO_ABLATE
-    unsigned long long* stamps;   // tools/wino_bench.hip only: per wave [wait + barrier, MFMA groups, tail] cycle sums
-    int dbg;                // tools/wino_bench.hip only (timing ablations, wrong results): 1 no MFMA, 2 no patch DMA, 4 no A DMA,
-                            //   8 no fragment reads
-#endif
 };
-#ifdef WINO_ABLATE
-#define WINO_DBG(p, bit) ((p).dbg & (bit))
-#else
-#define WINO_DBG(p, bit) 0
-#endif
 
 // ---- host: weight transform + packing -------------------------------------------------------------------------------------
 // image of (row tile rt, k-step s): [idx 0..7][lane][4 floats]; float e of idx holds fragment a = 4 idx + e = (xi = a >> 1,
@@ -182,6 +172,12 @@ __device__ __forceinline__ void wino_dma16(unsigned voff, const wino_u32x4& d, u
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(d), "s"(soff), "s"(lds) : "memory");
 }
 
+#ifndef WINO_NG
+#define WINO_NG 8      // MFMA groups per k-step between scheduling fences: 8 (of four MFMAs) or 4 (of eight)
+#endif
+template <int N>
+struct WInt { static constexpr int value = N; };
+
 template <int DUMMY>
 __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) {
     using namespace wino;
@@ -217,7 +213,6 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             const int y = y0 + py, x = x0 + px;
             const bool ok = k4 < 4 && rem < PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
-            if (WINO_DBG(p, 64) && (py % 5) >= 2) voff[i] = 0x80000000u;       // (ablation: 60 % of the patch rows not fetched)
         }
         d_in = wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
         d_a = wino_rsrc(p.wpk + (long long)irt * p.nks * 2048, (unsigned)p.nks * 8192u);
@@ -233,15 +228,11 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
         if (part < 3) {
 #pragma unroll
             for (int i = 2 * part; i < 2 * part + 2; ++i) {
-                if (WINO_DBG(p, 2)) continue;
                 wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
             }
             return;
         }
-        if (!WINO_DBG(p, 4)) {
-            const unsigned wa = islot + PDW * 4u + (unsigned)wave * 1024u;
-            wino_dma16(va, d_a, so_a, wa);
-        }
+        wino_dma16(va, d_a, so_a, islot + PDW * 4u + (unsigned)wave * 1024u);
         islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
         so_in += 16u * (unsigned)HW;
         so_a += 8192u;
@@ -296,27 +287,12 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
 
     unsigned rslot = lds0;
     bool after_epi = false;
-#ifdef WINO_ABLATE
-    unsigned long long st_wait = 0, st_mf = 0, st_tail = 0, st_vm = 0, tl = 0;
-#endif
     float w[16];                                                   // the other half of the (v, w) ping-pong of B fragments
     // one k-step: MFMAs on the B fragments `vc` (ready) while the next k-step's patch is read and transformed into `vx`
     auto kstep = [&](float (&vc)[16], float (&vx)[16]) {
-#ifdef WINO_ABLATE
-        const unsigned long long T0 = __builtin_amdgcn_s_memtime();
-        if (p.stamps && tl != 0) st_tail += T0 - tl;
-#endif
         if (after_epi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 3)) : "memory");
-#ifdef WINO_ABLATE
-        const unsigned long long T0b = __builtin_amdgcn_s_memtime();
-        st_vm += T0b - T0;
-#endif
-        if (!WINO_DBG(p, 32)) __syncthreads();
-#ifdef WINO_ABLATE
-        const unsigned long long T1 = __builtin_amdgcn_s_memtime();
-        st_wait += T1 - T0b;
-#endif
+        __syncthreads();
         after_epi = false;
         const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
         const f32x4* ap = a_ptr(rslot);
@@ -326,16 +302,14 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const f32x4 c0 = a0, c1 = a1;
-                if (!WINO_DBG(p, 8)) {
-                    if (h < 3) {
-                        a0 = ap[(2 * h + 2) * 64];
-                        a1 = ap[(2 * h + 3) * 64];
-                    } else {
-                        a0 = apn[0];
-                        a1 = apn[64];
-                    }
-                    if (h == 0) load_raw(nslot, dn);               // k-step q + 1 was verified by the barrier above
+                if (h < 3) {
+                    a0 = ap[(2 * h + 2) * 64];
+                    a1 = ap[(2 * h + 3) * 64];
+                } else {
+                    a0 = apn[0];
+                    a1 = apn[64];
                 }
+                if (h == 0) load_raw(nslot, dn);                   // k-step q + 1 was verified by the barrier above
                 __builtin_amdgcn_sched_barrier(0);                 // the LDS reads of the NEXT group first: this group's MFMA time
                                                                    //   is their latency
                 // the next k-step's input transform, spread over the MFMA groups (B^T d, then (.) B two rows at a time)
@@ -357,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
                         vx[4 * i + 3] = t[i][1] - t[i][3];
                     }
                 }
-                if (!WINO_DBG(p, 1)) {
+                {
                     acc[4 * h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, vc[4 * h], acc[4 * h][0], 0, 0, 0);
                     acc[4 * h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, vc[4 * h], acc[4 * h][1], 0, 0, 0);
                     acc[4 * h + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.z, vc[4 * h + 1], acc[4 * h + 1][0], 0, 0, 0);
@@ -373,23 +347,40 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             }
         }
         rslot = nslot;
-#ifdef WINO_ABLATE
-        tl = __builtin_amdgcn_s_memtime();
-        st_mf += tl - T1;
-#endif
     };
     for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
         for (int cs = 0; cs < nk; cs += 2) {
             kstep(v, w);          // (nks is even: wino_supported)
             kstep(w, v);
         }
-        // ---- epilogue of task ct ---------------------------------------------------------------------------------------------
+        // ---- epilogue of task ct: every load first (rows clamped, so no load sits behind a branch: the per-row load -> use chains
+        //      of the first version cost four memory round trips per task), then the output transforms, then the stores -----------
         {
             int crt, tile;
             wino_task(p, ct, crt, tile);
             const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
             const int y = ty * TH + 2 * wave, x = tx * TW + 2 * n;
             const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
+            float bs[2][4];
+            float2 r0[2][4], r1[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = crt * 32 + m * 16 + 4 * kk + i, rc = row < p.Cout ? row : p.Cout - 1;
+                    bs[m][i] = p.bias ? p.bias[rc] : 0.f;
+                    r0[m][i] = r1[m][i] = make_float2(0.f, 0.f);
+                    if (p.res) {
+                        const float* rp = p.res + ((long long)b * p.Cout + rc) * rHW;
+                        if (p.res_up) {
+                            const float r = rp[(y >> 1) * rW + (x >> 1)];
+                            r0[m][i] = r1[m][i] = make_float2(r, r);
+                        } else {
+                            r0[m][i] = *reinterpret_cast<const float2*>(rp + y * rW + x);
+                            r1[m][i] = *reinterpret_cast<const float2*>(rp + (y + 1) * rW + x);
+                        }
+                    }
+                }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -400,24 +391,13 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
                     for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][m][i];
                     float y00, y01, y10, y11;
                     wino_out_transform(M, y00, y01, y10, y11);
+                    y00 += bs[m][i] + r0[m][i].x; y01 += bs[m][i] + r0[m][i].y;
+                    y10 += bs[m][i] + r1[m][i].x; y11 += bs[m][i] + r1[m][i].y;
+                    if (p.act != ACT_NONE) {
+                        y00 = apply_act(y00, p.act); y01 = apply_act(y01, p.act);
+                        y10 = apply_act(y10, p.act); y11 = apply_act(y11, p.act);
+                    }
                     if (row < p.Cout) {
-                        const float bs = p.bias ? p.bias[row] : 0.f;
-                        y00 += bs; y01 += bs; y10 += bs; y11 += bs;
-                        if (p.res) {
-                            const float* rp = p.res + ((long long)b * p.Cout + row) * rHW;
-                            if (p.res_up) {
-                                const float r = rp[(y >> 1) * rW + (x >> 1)];
-                                y00 += r; y01 += r; y10 += r; y11 += r;
-                            } else {
-                                const float2 r0 = *reinterpret_cast<const float2*>(rp + y * rW + x);
-                                const float2 r1 = *reinterpret_cast<const float2*>(rp + (y + 1) * rW + x);
-                                y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
-                            }
-                        }
-                        if (p.act != ACT_NONE) {
-                            y00 = apply_act(y00, p.act); y01 = apply_act(y01, p.act);
-                            y10 = apply_act(y10, p.act); y11 = apply_act(y11, p.act);
-                        }
                         float* op = p.out + ((long long)b * p.Cout + row) * HW + y * p.W + x;
                         *reinterpret_cast<float2*>(op) = make_float2(y00, y01);
                         *reinterpret_cast<float2*>(op + p.W) = make_float2(y10, y11);
@@ -430,12 +410,6 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             after_epi = true;
         }
     }
-#ifdef WINO_ABLATE
-    if (p.stamps && lane == 0) {
-        unsigned long long* o = p.stamps + ((long long)blockIdx.x * 8 + wave) * 4;
-        o[0] = st_wait; o[1] = st_mf; o[2] = st_tail; o[3] = st_vm;
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
 }
 
@@ -494,13 +468,14 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     using Cfg = WaCfg<TH_>;
     constexpr int WA_TH = Cfg::TH, WA_PROWS = Cfg::PROWS, WA_PS = Cfg::PS, WA_NPD = Cfg::NPD, WA_PDW = Cfg::PDW, WA_NST = Cfg::NST;
     constexpr int WA_SDW = Cfg::SDW, WA_NLD = Cfg::NLD, WA_NQ = Cfg::NQ;
+    constexpr int AHEAD = WA_NST - 1;                          // k-steps the issue side runs ahead of the consumers
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kk = lane >> 4;
     const int G = gridDim.x;
     const int ntasks = p.total[0];
-    const int lb = blockIdx.x;
+    const int lb = xcd_remap(blockIdx.x, G);      // the tasks of a tile (row pairs x parts: consecutive entries) run on ONE XCD at the same time
     if (lb >= ntasks) return;
     const int mytasks = (ntasks - lb + G - 1) / G;
     const int nks = 32, nk = nks + (p.wsty ? 5 : 0);
@@ -509,13 +484,15 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
 
     // ---- issue side ------------------------------------------------------------------------------------------------------------
+    // The k-step is BRANCH-FREE (measured: every conditional inside it -- around an MFMA group, an operand read, the choice of the A
+    // source -- cost far more than its instruction count: tools/wino_ace_bench.hip): the transitions of the issue side (hidden ->
+    // style A images -> next task) happen BETWEEN straight runs of k-steps, see the task loop.
     unsigned voff[WA_NPD];
     const unsigned va = (unsigned)tid * 16u;
-    int it = lb, is = 0;
-    wino_u32x4 d_in, d_a0, d_a1, d_s0, d_s1;
+    wino_u32x4 d_in, d_h0, d_h1, d_s0, d_s1, dA0, dA1;
     unsigned so_in = 0, so_a = 0;
-    auto issue_task = [&]() {
-        const unsigned wk = p.work[it];
+    auto issue_task = [&](int t) {
+        const unsigned wk = p.work[t];
         const int tile = wk & 0xFFFFF, pair = (wk >> 20) & 0x3FF;
         const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, ib = tile / (p.ntx * p.nty);
         const int y0 = ty * WA_TH - 1, x0 = tx * TW - 1;
@@ -530,48 +507,33 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
         }
         const int r0 = 2 * pair, r1 = 2 * pair + 1 < p.nrt ? 2 * pair + 1 : 2 * pair;      // (odd row-tile count: the last pair repeats)
         d_in = wino_rsrc(p.actv + (long long)ib * p.K * HW, (unsigned)p.K * HW * 4u);
-        d_a0 = wino_rsrc(p.wpk + (long long)r0 * nks * 2048, (unsigned)nks * 8192u);
-        d_a1 = wino_rsrc(p.wpk + (long long)r1 * nks * 2048, (unsigned)nks * 8192u);
+        d_h0 = wino_rsrc(p.wpk + (long long)r0 * nks * 2048, (unsigned)nks * 8192u);
+        d_h1 = wino_rsrc(p.wpk + (long long)r1 * nks * 2048, (unsigned)nks * 8192u);
         if (p.wsty) {
             d_s0 = wino_rsrc(p.wsty + ((long long)ib * p.nrt + r0) * 5 * 2048, 5u * 8192u);
             d_s1 = wino_rsrc(p.wsty + ((long long)ib * p.nrt + r1) * 5 * 2048, 5u * 8192u);
         }
+        dA0 = d_h0;
+        dA1 = d_h1;
         so_in = 0;
         so_a = 0;
     };
-    issue_task();
-    unsigned islot = lds0;
-    auto issue_part = [&](int part) {
-        const bool hid = is < nks;
-        const unsigned wb = islot + (unsigned)wave * 256u;
-        if (part < 3) {                                     // 3 + 3 + 4 (2 + 2 + 2) patch DMAs
+    unsigned islot = lds0;                                     // ring slot the next issue fills
+    // the LDS-DMA instructions of a k-step, spread over the eight MFMA groups so that they issue in the shadow of the matrix pipe
+    auto issue_group = [&](auto gt) {
+        constexpr int g = decltype(gt)::value;
+        if constexpr (g < 6) {
+            constexpr int lo = g * WA_NPD / 6, hi = (g + 1) * WA_NPD / 6;
+            const unsigned wb = islot + (unsigned)wave * 256u;
 #pragma unroll
-            for (int i = (WA_NPD / 3) * part; i < (part == 2 ? WA_NPD : (WA_NPD / 3) * (part + 1)); ++i) wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
-            return;
-        }
-        const unsigned wa = islot + WA_PDW * 4u + (unsigned)wave * 1024u;
-        if (hid) {
-            wino_dma16(va, d_a0, so_a, wa);
-            wino_dma16(va, d_a1, so_a, wa + ADW * 4u);
+            for (int i = lo; i < hi; ++i) wino_dma4(voff[i], d_in, so_in, wb + (unsigned)i * 2048u);
+        } else if constexpr (g == 6) {
+            wino_dma16(va, dA0, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u);
         } else {
-            wino_dma16(va, d_s0, so_a, wa);
-            wino_dma16(va, d_s1, so_a, wa + ADW * 4u);
-        }
-        islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
-        so_in += 16u * (unsigned)HW;
-        so_a += 8192u;
-        if (++is == nk) {
-            if (it + G < ntasks) {
-                it += G;
-                is = 0;
-                issue_task();
-            } else {
-                is = nk - 1;
-                so_in -= 16u * (unsigned)HW;
-                so_a -= 8192u;
-            }
-        } else if (is == nks) {
-            so_a = 0;
+            wino_dma16(va, dA1, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u + ADW * 4u);
+            islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
+            so_in += 16u * (unsigned)HW;
+            so_a += 8192u;
         }
     };
 
@@ -582,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // this wave's share of a task: quad group (wave & 3) + 4 * half of the tile's list, row tile 2 * pair + (wave >> 2)
+    // this wave's share of a task: quad group (wave & 3) + 4 * part of the tile's list, row tile 2 * pair + (wave >> 2)
     struct Ctx { int tile, rt, qy, qx, boff; bool active, valid; };
     auto task_ctx = [&](int t) {
         Ctx c;
@@ -613,50 +575,63 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     };
     auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + aoff) + lane; };
 
+    issue_task(lb);
 #pragma unroll
-    for (int j = 0; j < WA_NST - 1; ++j) {
-#pragma unroll
-        for (int part = 0; part < 4; ++part) issue_part(part);
+    for (int j = 0; j < AHEAD; ++j) {
+        issue_group(WInt<0>{}); issue_group(WInt<1>{}); issue_group(WInt<2>{}); issue_group(WInt<3>{});
+        issue_group(WInt<4>{}); issue_group(WInt<5>{}); issue_group(WInt<6>{}); issue_group(WInt<7>{});
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
     __syncthreads();
-    float v[16], w[16];
-    f32x4 a0, a1;
+    // B fragments of the current k-step (transformed patch of this lane's (quad, channel)); overwritten IN PLACE by the next k-step's
+    // as the MFMA groups release them.  F: A fragments, group g reads F[g & 3], the read for group g + 2 is issued at group g.
+    float v[16], t3[4];
+    f32x4 F[4];
     {
         float d[4][4];
         load_raw(lds0, cur.boff, d);
-        wino_in_transform(d, v);
+        wino_in_transform(d, v);                               // (v[12..15] are written again, from t3, by the first k-step)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t3[j] = d[1][j] - d[3][j];
         const f32x4* ap = a_ptr(lds0);
-        a0 = ap[0];
-        a1 = ap[64];
+        F[0] = ap[0];
+        F[1] = ap[64];
+        F[2] = F[3] = F[0];
     }
     unsigned rslot = lds0;
-    bool after_epi = false;
-    int boff_next = cur.boff;                                  // patch origin of the lane's quad in the NEXT k-step's task
-    auto kstep = [&](bool act, bool rd, float (&vc)[16], float (&vx)[16]) {
-        if (after_epi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
+    // One k-step (4 input channels; eight groups of four MFMAs) + the fetch and input transform of the next k-step's operands
+    // (boff_pre = the lane's patch origin in THAT k-step's task).  Every wave runs it, with or without quads in the task (a wave
+    // without quads sits on a SIMD of its own with its row-tile twin -- waves w and w + 4 share the quad group -- so its MFMAs on
+    // clamped operands delay nobody, and one code path keeps the accumulators out of scratch); the epilogue is what is predicated.
+    auto kstep = [&](int boff_pre) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
         __syncthreads();
-        after_epi = false;
         const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
         const f32x4* ap = a_ptr(rslot);
-        const f32x4* apn = a_ptr(nslot);
+        const f32x4* apn = a_ptr(nslot);                       // (k-step q + 1 was verified by the barrier above)
         float dn[4][4], t[4][4];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const f32x4 c0 = a0, c1 = a1;
-            if (rd) {                                           // (a wave without quads in this task and the next skips its operand reads)
-                if (h < 3) {
-                    a0 = ap[(2 * h + 2) * 64];
-                    a1 = ap[(2 * h + 3) * 64];
-                } else {
-                    a0 = apn[0];
-                    a1 = apn[64];
-                }
-                if (h == 0) load_raw(nslot, boff_next, dn);
+        // eighth e of the k-step: the A-fragment read for eighth e + 2 (F is a ring of four), four MFMAs, a piece of the next k-step's
+        // input transform behind the MFMAs that read the old values, a piece of the k-step's LDS-DMA issue
+        auto g_loads = [&](auto gt) {
+            constexpr int g = decltype(gt)::value;
+            if constexpr (g < 6) F[(g + 2) & 3] = ap[(g + 2) * 64];
+            else F[(g + 2) & 3] = apn[(g - 6) * 64];
+            if constexpr (g == 0) load_raw(nslot, boff_pre, dn);
+        };
+        auto g_math = [&](auto gt) {
+            constexpr int g = decltype(gt)::value;
+            const f32x4 c = F[g & 3];
+            acc[2 * g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, v[2 * g], acc[2 * g][0], 0, 0, 0);
+            acc[2 * g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, v[2 * g], acc[2 * g][1], 0, 0, 0);
+            acc[2 * g + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, v[2 * g + 1], acc[2 * g + 1][0], 0, 0, 0);
+            acc[2 * g + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, v[2 * g + 1], acc[2 * g + 1][1], 0, 0, 0);
+            if constexpr (g == 0) {                            // row 3 of the transform the previous k-step computed: its old values were
+                v[12] = t3[0] - t3[2];                         //   read by that k-step's last two eighths (a write behind them would have
+                v[13] = t3[1] + t3[2];                         //   waited for their MFMAs to start)
+                v[14] = t3[2] - t3[1];
+                v[15] = t3[1] - t3[3];
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (h == 1) {
+            if constexpr (g == 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     t[0][j] = dn[0][j] - dn[2][j];
@@ -665,49 +640,60 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
                     t[3][j] = dn[1][j] - dn[3][j];
                 }
             }
-            if (h >= 2) {
+            if constexpr (g >= 4 && g < 7) {
+                constexpr int i = g - 4;                       // v[4 i ..]: read by the eighths 2 i, 2 i + 1 < g of this k-step
+                v[4 * i + 0] = t[i][0] - t[i][2];
+                v[4 * i + 1] = t[i][1] + t[i][2];
+                v[4 * i + 2] = t[i][2] - t[i][1];
+                v[4 * i + 3] = t[i][1] - t[i][3];
+            }
+            if constexpr (g == 7) {
 #pragma unroll
-                for (int i = 2 * (h - 2); i < 2 * (h - 2) + 2; ++i) {
-                    vx[4 * i + 0] = t[i][0] - t[i][2];
-                    vx[4 * i + 1] = t[i][1] + t[i][2];
-                    vx[4 * i + 2] = t[i][2] - t[i][1];
-                    vx[4 * i + 3] = t[i][1] - t[i][3];
-                }
+                for (int j = 0; j < 4; ++j) t3[j] = t[3][j];
             }
-            if (act) {
-                acc[4 * h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, vc[4 * h], acc[4 * h][0], 0, 0, 0);
-                acc[4 * h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, vc[4 * h], acc[4 * h][1], 0, 0, 0);
-                acc[4 * h + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.z, vc[4 * h + 1], acc[4 * h + 1][0], 0, 0, 0);
-                acc[4 * h + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.w, vc[4 * h + 1], acc[4 * h + 1][1], 0, 0, 0);
-                acc[4 * h + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, vc[4 * h + 2], acc[4 * h + 2][0], 0, 0, 0);
-                acc[4 * h + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, vc[4 * h + 2], acc[4 * h + 2][1], 0, 0, 0);
-                acc[4 * h + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.z, vc[4 * h + 3], acc[4 * h + 3][0], 0, 0, 0);
-                acc[4 * h + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.w, vc[4 * h + 3], acc[4 * h + 3][1], 0, 0, 0);
-            }
+        };
+#if WINO_NG == 8
+        auto group = [&](auto gt) {
+            g_loads(gt);
+            __builtin_amdgcn_sched_barrier(0);                 // the LDS reads of the group after next first: two groups of MFMA time are their latency
+            g_math(gt);
             __builtin_amdgcn_sched_barrier(0);
-            issue_part(h);
+            issue_group(gt);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        group(WInt<0>{}); group(WInt<1>{}); group(WInt<2>{}); group(WInt<3>{});
+        group(WInt<4>{}); group(WInt<5>{}); group(WInt<6>{}); group(WInt<7>{});
+#else
+        auto group = [&](auto g0, auto g1) {                   // four groups of eight MFMAs
+            g_loads(g0); g_loads(g1);
+            __builtin_amdgcn_sched_barrier(0);                 // the LDS reads of the next group first: this group's MFMA time is their latency
+            g_math(g0); g_math(g1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_group(g0); issue_group(g1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(WInt<0>{}, WInt<1>{}); group(WInt<2>{}, WInt<3>{}); group(WInt<4>{}, WInt<5>{}); group(WInt<6>{}, WInt<7>{});
+#endif
         rslot = nslot;
     };
     for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
         const bool more = k + 1 < mytasks;
         Ctx nxt = cur;
         if (more) nxt = task_ctx(ct + G);                       // (its list entry is in flight during this task's k-steps)
-        const bool rd = cur.active || nxt.active;
-        for (int cs = 0; cs < nk; cs += 2) {                    // nk = 32 or 37: the odd tail is handled below
-            if (cs + 1 == nk) break;
-            kstep(cur.active, rd, v, w);
-            if (cs + 2 == nk) boff_next = nxt.boff;
-            kstep(cur.active, rd, w, v);
+        const int tnext = more ? ct + G : ct;                   // (past the end: this task again -- never read; keeps the vmcnt counting uniform)
+        // consumer k-step c issues k-step c + AHEAD: hidden channels while c + AHEAD < 32, then the style images, then the next task
+        for (int c = 0; c < nks - AHEAD; ++c) kstep(cur.boff);
+        if (nk > nks) {
+            dA0 = d_s0;
+            dA1 = d_s1;
+            so_a = 0;
+            for (int c = nks - AHEAD; c < nk - AHEAD; ++c) kstep(cur.boff);
         }
-        if (nk & 1) {                                           // last (odd) k-step: its prefetch belongs to the next task
-            boff_next = nxt.boff;
-            kstep(cur.active, rd, v, w);
-#pragma unroll
-            for (int x = 0; x < 16; ++x) v[x] = w[x];
-        }
-        // ---- ACE epilogue of this wave's (quads, row tile) ------------------------------------------------------------------
+        issue_task(tnext);
+        for (int c = nk - AHEAD; c < nk; ++c) kstep(c == nk - 1 ? nxt.boff : cur.boff);      // the last k-step's prefetch belongs to the next task
+        // ---- ACE epilogue of this wave's (quads, row tile): every load first (channels clamped, so no load sits behind a branch: the
+        //      per-channel load -> use chains of the first version cost four memory round trips per task), then the output transforms
+        //      and the modulation, then the stores ------------------------------------------------------------------------------
         if (cur.active) {
             const int tile = cur.tile;
             const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
@@ -716,10 +702,25 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
             const float* nzp = p.noise + (long long)b * p.noise_bstride + (long long)x * p.H + y;      // plane layout [W][H]
             const float2 nz0 = *reinterpret_cast<const float2*>(nzp), nz1 = *reinterpret_cast<const float2*>(nzp + p.H);
             // nz0 = (y, x), (y + 1, x);  nz1 = (y, x + 1), (y + 1, x + 1)
-            const int c0 = cur.rt * 16 + 4 * kk;
-            const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + c0), pb = *reinterpret_cast<const float4*>(p.bias_b + c0);
-            const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + c0), pd = *reinterpret_cast<const float4*>(p.bn_d + c0);
-            const float4 pn = *reinterpret_cast<const float4*>(p.nv + c0);
+            const int c0 = cur.rt * 16 + 4 * kk, c0c = c0 < p.C ? c0 : p.C - 4;                          // (C % 4 == 0: conv_wino_ace)
+            const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + c0c), pb = *reinterpret_cast<const float4*>(p.bias_b + c0c);
+            const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + c0c), pd = *reinterpret_cast<const float4*>(p.bn_d + c0c);
+            const float4 pn = *reinterpret_cast<const float4*>(p.nv + c0c);
+            float2 xr0[4], xr1[4];
+            const float* xp0 = p.x + ((long long)b * p.C + c0c) * xHW;
+            if (p.x_up) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xv = xp0[(long long)i * xHW + (y >> 1) * xW + (x >> 1)];
+                    xr0[i] = xr1[i] = make_float2(xv, xv);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xr0[i] = *reinterpret_cast<const float2*>(xp0 + (long long)i * xHW + y * xW + x);
+                    xr1[i] = *reinterpret_cast<const float2*>(xp0 + (long long)i * xHW + (y + 1) * xW + x);
+                }
+            }
             const float g_[4] = {pg.x, pg.y, pg.z, pg.w}, b_[4] = {pb.x, pb.y, pb.z, pb.w};
             const float a_[4] = {pa.x, pa.y, pa.z, pa.w}, d_[4] = {pd.x, pd.y, pd.z, pd.w}, n_[4] = {pn.x, pn.y, pn.z, pn.w};
 #pragma unroll
@@ -732,35 +733,27 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][1][i];
                 wino_out_transform(M, e00, e01, e10, e11);
+                const float gb = 1.f + g_[i], bb = b_[i];
+                float o00 = (a_[i] * xr0[i].x + n_[i] * nz0.x + d_[i]) * (gb + g00) + (bb + e00);
+                float o01 = (a_[i] * xr0[i].y + n_[i] * nz1.x + d_[i]) * (gb + g01) + (bb + e01);
+                float o10 = (a_[i] * xr1[i].x + n_[i] * nz0.y + d_[i]) * (gb + g10) + (bb + e10);
+                float o11 = (a_[i] * xr1[i].y + n_[i] * nz1.y + d_[i]) * (gb + g11) + (bb + e11);
+                if (p.act != ACT_NONE) {
+                    o00 = apply_act(o00, p.act); o01 = apply_act(o01, p.act);
+                    o10 = apply_act(o10, p.act); o11 = apply_act(o11, p.act);
+                }
                 if (cur.valid && c < p.C) {
-                    const float* xp = p.x + ((long long)b * p.C + c) * xHW;
-                    float x00, x01, x10, x11;
-                    if (p.x_up) {
-                        x00 = x01 = x10 = x11 = xp[(y >> 1) * xW + (x >> 1)];
-                    } else {
-                        const float2 r0 = *reinterpret_cast<const float2*>(xp + y * xW + x), r1 = *reinterpret_cast<const float2*>(xp + (y + 1) * xW + x);
-                        x00 = r0.x; x01 = r0.y; x10 = r1.x; x11 = r1.y;
-                    }
-                    const float gb = 1.f + g_[i], bb = b_[i];
-                    float o00 = (a_[i] * x00 + n_[i] * nz0.x + d_[i]) * (gb + g00) + (bb + e00);
-                    float o01 = (a_[i] * x01 + n_[i] * nz1.x + d_[i]) * (gb + g01) + (bb + e01);
-                    float o10 = (a_[i] * x10 + n_[i] * nz0.y + d_[i]) * (gb + g10) + (bb + e10);
-                    float o11 = (a_[i] * x11 + n_[i] * nz1.y + d_[i]) * (gb + g11) + (bb + e11);
-                    if (p.act != ACT_NONE) {
-                        o00 = apply_act(o00, p.act); o01 = apply_act(o01, p.act);
-                        o10 = apply_act(o10, p.act); o11 = apply_act(o11, p.act);
-                    }
                     float* op = p.out + ((long long)b * p.C + c) * HW + y * p.W + x;
                     *reinterpret_cast<float2*>(op) = make_float2(o00, o01);
                     *reinterpret_cast<float2*>(op + p.W) = make_float2(o10, o11);
                 }
             }
-#pragma unroll
-            for (int x2 = 0; x2 < 16; ++x2)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        after_epi = true;
+#pragma unroll
+        for (int x2 = 0; x2 < 16; ++x2)                         // (waves without quads in the task accumulated products of clamped operands)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's loads / stores share the counter with the ring: drain once per task
         cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
