@@ -363,7 +363,6 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
 
 // Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
 // values of a thread share their 32-byte sectors with the seven other rows of the block.
-#ifdef CH_ABLATE      // four pixels per thread (A/B builds only)
 __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {
     constexpr int RS = 2 * IN_CG + 1;
     __shared__ float gt[19 * RS];
@@ -434,19 +433,16 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
     }
 }
 
-#endif   // CH_ABLATE
 
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU) return hipErrorInvalidValue;
     if (q.W % 4 != 0) return hipErrorInvalidValue;
     const int HW = q.H * q.W;
-#ifdef CH_ABLATE
     if (q.impl == 2 && q.W >= 128) {
         dim3 gridt((unsigned)(q.B * ((q.W + 127) / 128) * ((q.H + 7) / 8)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_tile4_kernel, gridt, dim3(256), 0, s, q);
         return hipGetLastError();
     }
-#endif
     if (q.impl == 0 || q.impl == 2) {
         dim3 gridt((unsigned)(q.B * ((q.W + 31) / 32) * ((q.H + 7) / 8)), (unsigned)((q.C + IN_CG - 1) / IN_CG));
         hipLaunchKernelGGL(ace_interior_f32_tile_kernel, gridt, dim3(256), 0, s, q);

@@ -930,8 +930,10 @@ struct Runner {
                 ip.x_up = x_up;
                 ip.act = act;
                 ip.variant = 0;
-                ip.impl = 0;
-                ip.fill_min = x_up ? 257 : 128;
+                // four pixels per thread (16-byte stores) from 128 pixels of width: 530 -> 420 us on the up-sampled 512^2 launches
+                // (tools/interior_bench.hip); level in the 100 ms step of round 3, measurable in this one
+                ip.impl = r >= 128 ? 2 : 0;
+                ip.fill_min = (x_up && r < 128) ? 257 : 128;
                 timed(3, 0.0, 0.0, wp.W->total + 4, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
                     check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
                     check(ace_interior_f32(ip, st), "ace interior");
