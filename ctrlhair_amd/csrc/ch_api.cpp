@@ -348,6 +348,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.wino = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.wino_gather") == 0) {    // 1 = gather mode of the Winograd ACE kernel (default), 0 = tile mode
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino_gather) must precede ch_finalize");
+        h->sean.wino_gather = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.wino_th") == 0) {    // tile height 16 / 32 of the Winograd ACE kernel (0 = chosen per level)
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino_th) must precede ch_finalize");
         h->sean.wino_th = value;

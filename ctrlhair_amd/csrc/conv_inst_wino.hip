@@ -69,6 +69,17 @@ static hipError_t launch_wino_ace(const WinoAceParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s) {
+    if (p.gq) {            // gather mode
+        if (!p.gq_n || p.gq_cap <= 0 || p.B > 32 || !p.work || !p.total || (p.C & 3) || (p.W & 1) || (p.H & 1)) return hipErrorInvalidValue;
+        p.nrt = (p.C + 15) / 16;
+        if (p.nrt > 2 * 65535) return hipErrorInvalidValue;
+        p.K = 128 + (p.wsty ? 20 : 0);
+        static bool d0[64] = {};
+        hipError_t e = wino_attr(wino_ace_gather_kernel<0>, winog::LDS_BYTES, d0);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino_ace_gather_kernel<0>, dim3(wino_num_cus()), dim3(512), winog::LDS_BYTES, s, p);
+        return hipGetLastError();
+    }
     if ((p.TH != 16 && p.TH != 32) || p.H % p.TH || p.W % wino::TW || !p.zero || !p.qlist || !p.qcnt || !p.work || !p.total || (p.C & 3))
         return hipErrorInvalidValue;
     p.nrt = (p.C + 15) / 16;
@@ -76,6 +87,92 @@ hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s) {
     p.nty = p.H / p.TH;
     p.K = 128 + (p.wsty ? 20 : 0);
     return p.TH == 32 ? launch_wino_ace<32>(p, s) : launch_wino_ace<16>(p, s);
+}
+
+// ---- gather mode: per-tile lists (tiles of 32 x 16) -> one list of boundary quads per sample, tasks of 64 consecutive entries --------
+__global__ __launch_bounds__(1024) void wino_gather_scan_kernel(const int* __restrict__ qcnt, int* __restrict__ qoff, int* __restrict__ gq_n, int tps) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < tps; t0 += 1024) {
+        const int t = t0 + tid;
+        const int c = t < tps ? qcnt[b * tps + t] : 0;
+        int v = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(v, off, 64);
+            if (lane >= off) v += u;
+        }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (t < tps) qoff[b * tps + t] = base + v - c;
+        __syncthreads();
+        if (tid == 1023) carry = base + v;
+        __syncthreads();
+    }
+    if (tid == 0) gq_n[b] = carry;
+}
+__global__ __launch_bounds__(128) void wino_gather_fill_kernel(const uint8_t* __restrict__ qlist, const int* __restrict__ qcnt, const int* __restrict__ qoff,
+                                                               unsigned* __restrict__ gq, int gq_cap, int ntx, int nty) {
+    const int tile = blockIdx.x, i = threadIdx.x;
+    if (i >= qcnt[tile]) return;
+    const int b = tile / (ntx * nty), tr = tile % (ntx * nty);
+    const int q = qlist[(long long)tile * 128 + i];
+    const unsigned y = (unsigned)((tr / ntx) * 16 + 2 * (q >> 4)), x = (unsigned)((tr % ntx) * 32 + 2 * (q & 15));
+    gq[(long long)b * gq_cap + qoff[tile] + i] = y << 16 | x;
+}
+hipError_t wino_gather_lists(const uint8_t* qlist, const int* qcnt, int* qoff, unsigned* gq, int* gq_n, int gq_cap, int B, int H, int W, hipStream_t s) {
+    if (H % 16 || W % 32 || B > 32 || H > 65535 || W > 65535) return hipErrorInvalidValue;
+    const int ntx = W / 32, nty = H / 16;
+    hipLaunchKernelGGL(wino_gather_scan_kernel, dim3(B), dim3(1024), 0, s, qcnt, qoff, gq_n, ntx * nty);
+    hipLaunchKernelGGL(wino_gather_fill_kernel, dim3(B * ntx * nty), dim3(128), 0, s, qlist, qcnt, qoff, gq, gq_cap, ntx, nty);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(1024) void wino_gather_worklist_kernel(const int* __restrict__ gq_n, const int* __restrict__ pcnt, int B, int tps, int nrt,
+                                                                    unsigned* __restrict__ work, int* __restrict__ total) {
+    __shared__ int base[33];
+    __shared__ int stat[4];
+    const int tid = threadIdx.x;
+    const int npair = (nrt + 1) >> 1;
+    if (tid < 4) stat[tid] = 0;
+    if (tid == 0) {
+        int o = 0, sq = 0, sg = 0;
+        for (int b = 0; b < B; ++b) {
+            base[b] = o;
+            const int nq = gq_n[b];
+            o += ((nq + 63) >> 6) * npair;
+            sq += nq;
+            sg += (nq + 15) >> 4;
+        }
+        base[B] = o;
+        stat[0] = sq;
+        stat[1] = sg;
+    }
+    __syncthreads();
+    int sp = 0;
+    for (int t = tid; t < B * tps; t += 1024) sp += pcnt[t];
+    atomicAdd(&stat[2], sp);
+    for (int b = 0; b < B; ++b) {
+        const int ne = base[b + 1] - base[b];
+        for (int e = tid; e < ne; e += 1024) work[base[b] + e] = (unsigned)b | (unsigned)(e / npair) << 5 | (unsigned)(e % npair) << 16;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        total[0] = total[4] = base[B];
+        total[1] = stat[0];
+        total[5] = stat[2];
+        total[2] = total[6] = stat[1];
+        total[3] = total[7] = stat[1] * nrt;
+    }
+}
+hipError_t wino_gather_worklist(const int* gq_n, const int* pcnt, int B, int tiles_per_sample, int nrt, unsigned* work, int* total, hipStream_t s) {
+    if (B > 32 || nrt > 2 * 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(wino_gather_worklist_kernel, dim3(1), dim3(1024), 0, s, gq_n, pcnt, B, tiles_per_sample, nrt, work, total);
+    return hipGetLastError();
 }
 
 // ---- boundary quads of a tile of 32 x TH pixels: one block of 8 TH threads = the tile's 16 x TH / 2 quads, ordered compaction -----

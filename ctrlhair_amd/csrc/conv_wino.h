@@ -446,6 +446,10 @@ struct WinoAceParams {
     const unsigned* work;   // tile | row pair << 20 | part << 30 (part = which 64 of the tile's listed quads)
     const int* total;       // [0] = entries of `work`
     const float* zero;
+    // gather mode (wino_ace_gather_kernel): the boundary quads of each sample as ONE list, tasks of 64 consecutive entries
+    const unsigned* gq;     // [B][gq_cap]: y << 16 | x of the quad's first pixel
+    const int* gq_n;        // [B] quads per sample
+    int gq_cap;             // work entries in this mode: sample | chunk of 64 quads << 5 | row pair << 16
     int nrt, ntx, nty, K;   // set by the launcher
 };
 // Tile height 32 (16 x 16 quads) or 16 (16 x 8 quads), chosen per resolution level by the caller: a sparse tile must hold enough
@@ -759,6 +763,283 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
 }
 
+// ---- gather mode ------------------------------------------------------------------------------------------------------------------
+// The tile kernel above stages the patch of a whole tile of 32 x TH pixels for the (at most 64) boundary quads it holds: on sparse
+// levels most of that patch is never read, a tile rarely holds a multiple of 16 quads (256^2 on the benchmark labels: 56 -> 86 % of
+// the MFMA slots), and the taller tiles that the sparse levels need cost ring depth (TH = 32: four stages of 36 KB).  Here a task is 64
+// CONSECUTIVE entries of the sample's list of boundary quads x a pair of row tiles, wherever those quads lie: the LDS-DMA fetches
+// each quad's own 4 x 4 patch (per-lane source offsets were already the access pattern, so a gather costs the same eight
+// instructions per thread and k-step), stage layout [channel][patch row][quad slot][4 floats], 16 KB per k-step whatever the
+// level; a lane's four B rows are four conflict-free ds_read_b128.  Every task but the last of a sample fills all 64 slots.
+// Same arithmetic per quad as the tile kernel: bit-identical results (tests/test_hip_wino.py).
+namespace winog {
+constexpr int NPD = 8, PDW = 4096, NST = 4, ADW2 = 2 * wino::ADW, SDW = PDW + ADW2, NLD = NPD + 2;
+constexpr int LDS_BYTES = NST * SDW * 4;                         // 128 KB
+}  // namespace winog
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAceParams p) {
+    using namespace wino;
+    constexpr int WA_NST = winog::NST, WA_NLD = winog::NLD, WA_PDW = winog::PDW;
+    constexpr int AHEAD = WA_NST - 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kk = lane >> 4;
+    const int G = gridDim.x;
+    const int ntasks = p.total[0];
+    const int lb = xcd_remap(blockIdx.x, G);      // the row pairs of a chunk of quads are consecutive entries: one XCD, the same time
+    if (lb >= ntasks) return;
+    const int mytasks = (ntasks - lb + G - 1) / G;
+    const int nks = 32, nk = nks + (p.wsty ? 5 : 0);
+    const int HW = p.H * p.W;
+    constexpr unsigned SB = winog::SDW * 4, RING = WA_NST * SB;
+    const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
+
+    // ---- issue side: thread = (quad slot, patch column, two patch rows) of every channel of the k-step ------------------------------
+    const int islot_q = (tid & 255) >> 2, ipx = tid & 3, irs = tid >> 8;
+    unsigned vb0 = 0x80000000u, vb1 = 0x80000000u;                  // byte offsets of this thread's elements of patch rows irs, irs + 2
+    const unsigned va = (unsigned)tid * 16u;
+    wino_u32x4 d_in, d_h0, d_h1, d_s0, d_s1, dA0, dA1;
+    unsigned so_in = 0, so_a = 0;
+    const unsigned HW4 = (unsigned)HW * 4u;
+    auto task_quad = [&](int t, int slot) {                       // entry `slot` of task t's chunk (clamped to the sample's list)
+        const unsigned wk = p.work[t];
+        const int b = wk & 31, chunk = (wk >> 5) & 2047;
+        const int nq = p.gq_n[b];
+        int qi = chunk * 64 + slot;
+        qi = qi < nq ? qi : nq - 1;
+        return p.gq[(long long)b * p.gq_cap + qi];
+    };
+    auto issue_task = [&](int t, unsigned q) {                    // q = task_quad(t, islot_q), fetched a task ahead
+        const unsigned wk = p.work[t];
+        const int ib = wk & 31, pair = wk >> 16;
+        const int y = (int)(q >> 16) - 1 + irs, x = (int)(q & 0xFFFFu) - 1 + ipx;
+        const bool okx = (unsigned)x < (unsigned)p.W;
+        vb0 = (okx && (unsigned)y < (unsigned)p.H) ? (unsigned)(y * p.W + x) * 4u : 0x80000000u;
+        vb1 = (okx && (unsigned)(y + 2) < (unsigned)p.H) ? (unsigned)((y + 2) * p.W + x) * 4u : 0x80000000u;
+        const int r0 = 2 * pair, r1 = 2 * pair + 1 < p.nrt ? 2 * pair + 1 : 2 * pair;      // (odd row-tile count: the last pair repeats)
+        d_in = wino_rsrc(p.actv + (long long)ib * p.K * HW, (unsigned)p.K * HW * 4u);
+        d_h0 = wino_rsrc(p.wpk + (long long)r0 * nks * 2048, (unsigned)nks * 8192u);
+        d_h1 = wino_rsrc(p.wpk + (long long)r1 * nks * 2048, (unsigned)nks * 8192u);
+        if (p.wsty) {
+            d_s0 = wino_rsrc(p.wsty + ((long long)ib * p.nrt + r0) * 5 * 2048, 5u * 8192u);
+            d_s1 = wino_rsrc(p.wsty + ((long long)ib * p.nrt + r1) * 5 * 2048, 5u * 8192u);
+        }
+        dA0 = d_h0;
+        dA1 = d_h1;
+        so_in = 0;
+        so_a = 0;
+    };
+    unsigned islot = lds0;
+    // element e = i * 512 + tid of a stage's patch image: channel i >> 1, patch row 2 (i & 1) + (tid >> 8), quad slot, column
+    auto issue_group = [&](auto gt) {
+        constexpr int g = decltype(gt)::value;
+        const unsigned wb = islot + (unsigned)wave * 256u + (unsigned)g * 2048u;
+        wino_dma4((g & 1) ? vb1 : vb0, d_in, so_in + (unsigned)(g >> 1) * HW4, wb);
+        if constexpr (g == 6) wino_dma16(va, dA0, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u);
+        if constexpr (g == 7) {
+            wino_dma16(va, dA1, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u + ADW * 4u);
+            islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
+            so_in += 4u * HW4;
+            so_a += 8192u;
+        }
+    };
+
+    // ---- consumer side ---------------------------------------------------------------------------------------------------
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int cslot = (wave & 3) * 16 + n;                        // this lane's quad slot; row tile 2 * pair + (wave >> 2)
+    struct Ctx { int b, rt, y, x; bool active, valid; };
+    auto task_ctx = [&](int t) {
+        Ctx c;
+        const unsigned wk = p.work[t];
+        c.b = wk & 31;
+        const int chunk = (wk >> 5) & 2047, pair = wk >> 16;
+        const int nq = p.gq_n[c.b];
+        c.rt = 2 * pair + (wave >> 2);
+        c.active = chunk * 64 + (wave & 3) * 16 < nq && c.rt < p.nrt;
+        c.valid = c.active && chunk * 64 + cslot < nq;
+        const unsigned q = task_quad(t, cslot);
+        c.y = (int)(q >> 16);
+        c.x = (int)(q & 0xFFFFu);
+        return c;
+    };
+    Ctx cur = task_ctx(lb);
+    const int aoff = WA_PDW + (wave >> 2) * ADW;
+    const int boff = kk * 1024 + cslot * 4;                       // [channel][patch row][slot][4]
+    auto load_raw = [&](unsigned slot, float (&d)[4][4]) {
+        const float* sp = reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + boff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(sp + i * 256);
+            d[i][0] = r.x; d[i][1] = r.y; d[i][2] = r.z; d[i][3] = r.w;
+        }
+    };
+    auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + aoff) + lane; };
+
+    issue_task(lb, task_quad(lb, islot_q));
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) {
+        issue_group(WInt<0>{}); issue_group(WInt<1>{}); issue_group(WInt<2>{}); issue_group(WInt<3>{});
+        issue_group(WInt<4>{}); issue_group(WInt<5>{}); issue_group(WInt<6>{}); issue_group(WInt<7>{});
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
+    __syncthreads();
+    float v[16], t3[4];
+    f32x4 F[4];
+    {
+        float d[4][4];
+        load_raw(lds0, d);
+        wino_in_transform(d, v);                               // (v[12..15] are written again, from t3, by the first k-step)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t3[j] = d[1][j] - d[3][j];
+        const f32x4* ap = a_ptr(lds0);
+        F[0] = ap[0];
+        F[1] = ap[64];
+        F[2] = F[3] = F[0];
+    }
+    unsigned rslot = lds0;
+    auto kstep = [&]() {                                       // (see wino_ace_kernel: branch-free, every wave runs it)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WA_NLD * (WA_NST - 3)) : "memory");
+        __syncthreads();
+        const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
+        const f32x4* ap = a_ptr(rslot);
+        const f32x4* apn = a_ptr(nslot);
+        float dn[4][4], t[4][4];
+        auto g_loads = [&](auto gt) {
+            constexpr int g = decltype(gt)::value;
+            if constexpr (g < 6) F[(g + 2) & 3] = ap[(g + 2) * 64];
+            else F[(g + 2) & 3] = apn[(g - 6) * 64];
+            if constexpr (g == 0) load_raw(nslot, dn);
+        };
+        auto g_math = [&](auto gt) {
+            constexpr int g = decltype(gt)::value;
+            const f32x4 c = F[g & 3];
+            acc[2 * g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, v[2 * g], acc[2 * g][0], 0, 0, 0);
+            acc[2 * g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, v[2 * g], acc[2 * g][1], 0, 0, 0);
+            acc[2 * g + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, v[2 * g + 1], acc[2 * g + 1][0], 0, 0, 0);
+            acc[2 * g + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, v[2 * g + 1], acc[2 * g + 1][1], 0, 0, 0);
+            if constexpr (g == 0) {
+                v[12] = t3[0] - t3[2];
+                v[13] = t3[1] + t3[2];
+                v[14] = t3[2] - t3[1];
+                v[15] = t3[1] - t3[3];
+            }
+            if constexpr (g == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[0][j] = dn[0][j] - dn[2][j];
+                    t[1][j] = dn[1][j] + dn[2][j];
+                    t[2][j] = dn[2][j] - dn[1][j];
+                    t[3][j] = dn[1][j] - dn[3][j];
+                }
+            }
+            if constexpr (g >= 4 && g < 7) {
+                constexpr int i = g - 4;
+                v[4 * i + 0] = t[i][0] - t[i][2];
+                v[4 * i + 1] = t[i][1] + t[i][2];
+                v[4 * i + 2] = t[i][2] - t[i][1];
+                v[4 * i + 3] = t[i][1] - t[i][3];
+            }
+            if constexpr (g == 7) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t3[j] = t[3][j];
+            }
+        };
+        auto group = [&](auto gt) {
+            g_loads(gt);
+            __builtin_amdgcn_sched_barrier(0);
+            g_math(gt);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_group(gt);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(WInt<0>{}); group(WInt<1>{}); group(WInt<2>{}); group(WInt<3>{});
+        group(WInt<4>{}); group(WInt<5>{}); group(WInt<6>{}); group(WInt<7>{});
+        rslot = nslot;
+    };
+    for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
+        const bool more = k + 1 < mytasks;
+        const int tnext = more ? ct + G : ct;                   // (past the end: this task again -- never read; keeps the vmcnt counting uniform)
+        Ctx nxt = cur;
+        if (more) nxt = task_ctx(tnext);                        // (in flight during this task's k-steps)
+        const unsigned qnext = task_quad(tnext, islot_q);
+        for (int c = 0; c < nks - AHEAD; ++c) kstep();
+        if (nk > nks) {
+            dA0 = d_s0;
+            dA1 = d_s1;
+            so_a = 0;
+            for (int c = nks - AHEAD; c < nk - AHEAD; ++c) kstep();
+        }
+        issue_task(tnext, qnext);
+        for (int c = nk - AHEAD; c < nk; ++c) kstep();
+        // ---- ACE epilogue (as wino_ace_kernel) ---------------------------------------------------------------------------------
+        if (cur.active) {
+            const int b = cur.b, y = cur.y, x = cur.x;
+            const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
+            const float* nzp = p.noise + (long long)b * p.noise_bstride + (long long)x * p.H + y;      // plane layout [W][H]
+            const float2 nz0 = *reinterpret_cast<const float2*>(nzp), nz1 = *reinterpret_cast<const float2*>(nzp + p.H);
+            const int c0 = cur.rt * 16 + 4 * kk, c0c = c0 < p.C ? c0 : p.C - 4;
+            const float4 pg = *reinterpret_cast<const float4*>(p.bias_g + c0c), pb = *reinterpret_cast<const float4*>(p.bias_b + c0c);
+            const float4 pa = *reinterpret_cast<const float4*>(p.bn_a + c0c), pd = *reinterpret_cast<const float4*>(p.bn_d + c0c);
+            const float4 pn = *reinterpret_cast<const float4*>(p.nv + c0c);
+            float2 xr0[4], xr1[4];
+            const float* xp0 = p.x + ((long long)b * p.C + c0c) * xHW;
+            if (p.x_up) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xv = xp0[(long long)i * xHW + (y >> 1) * xW + (x >> 1)];
+                    xr0[i] = xr1[i] = make_float2(xv, xv);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xr0[i] = *reinterpret_cast<const float2*>(xp0 + (long long)i * xHW + y * xW + x);
+                    xr1[i] = *reinterpret_cast<const float2*>(xp0 + (long long)i * xHW + (y + 1) * xW + x);
+                }
+            }
+            const float g_[4] = {pg.x, pg.y, pg.z, pg.w}, b_[4] = {pb.x, pb.y, pb.z, pb.w};
+            const float a_[4] = {pa.x, pa.y, pa.z, pa.w}, d_[4] = {pd.x, pd.y, pd.z, pd.w}, n_[4] = {pn.x, pn.y, pn.z, pn.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + i;
+                float M[16], g00, g01, g10, g11, e00, e01, e10, e11;
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][0][i];
+                wino_out_transform(M, g00, g01, g10, g11);
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][1][i];
+                wino_out_transform(M, e00, e01, e10, e11);
+                const float gb = 1.f + g_[i], bb = b_[i];
+                float o00 = (a_[i] * xr0[i].x + n_[i] * nz0.x + d_[i]) * (gb + g00) + (bb + e00);
+                float o01 = (a_[i] * xr0[i].y + n_[i] * nz1.x + d_[i]) * (gb + g01) + (bb + e01);
+                float o10 = (a_[i] * xr1[i].x + n_[i] * nz0.y + d_[i]) * (gb + g10) + (bb + e10);
+                float o11 = (a_[i] * xr1[i].y + n_[i] * nz1.y + d_[i]) * (gb + g11) + (bb + e11);
+                if (p.act != ACT_NONE) {
+                    o00 = apply_act(o00, p.act); o01 = apply_act(o01, p.act);
+                    o10 = apply_act(o10, p.act); o11 = apply_act(o11, p.act);
+                }
+                if (cur.valid && c < p.C) {
+                    float* op = p.out + ((long long)b * p.C + c) * HW + y * p.W + x;
+                    *reinterpret_cast<float2*>(op) = make_float2(o00, o01);
+                    *reinterpret_cast<float2*>(op + p.W) = make_float2(o10, o11);
+                }
+            }
+        }
+#pragma unroll
+        for (int x2 = 0; x2 < 16; ++x2)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
+}
+
 inline bool wino_supported(int H, int W, int Cin) { return H % wino::TH == 0 && W % wino::TW == 0 && Cin % 8 == 0 && H >= 16; }
 
 inline void wino_fill_launch(WinoParams& p) {
@@ -780,5 +1061,9 @@ hipError_t wino_style_pack(const float* lut, float* wsty, int B, int C, hipStrea
 // (u5 == nullptr: every quad is a boundary quad -- levels without the interior reduction); pcnt: boundary pixels per tile; total: 8 ints
 hipError_t wino_quad_lists(const uint8_t* u5, uint8_t* qlist, int* qcnt, int* pcnt, int B, int H, int W, int TH, hipStream_t s);
 hipError_t wino_ace_worklist(const int* qcnt, const int* pcnt, int ntiles, int nrt, unsigned* work, int* total, hipStream_t s);
+// gather mode: the per-tile lists (tiles of 32 x 16) -> one list per sample gq[b][gq_cap] (tile order), counts gq_n[b], scratch
+// qoff[ntiles]; then the tasks (sample | chunk << 5 | row pair << 16; chunk-major) and the statistics of wino_ace_worklist
+hipError_t wino_gather_lists(const uint8_t* qlist, const int* qcnt, int* qoff, unsigned* gq, int* gq_n, int gq_cap, int B, int H, int W, hipStream_t s);
+hipError_t wino_gather_worklist(const int* gq_n, const int* pcnt, int B, int tiles_per_sample, int nrt, unsigned* work, int* total, hipStream_t s);
 
 }  // namespace chk

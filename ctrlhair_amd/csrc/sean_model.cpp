@@ -497,11 +497,18 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 if (r < 32 || r % 32) continue;
                 WinoLevel& L = wq_level[k];
                 if (!L.qlist) {
-                    L.TH = wino_tile_h(r);
+                    const bool gather = wino_gather && mb <= 32 && (r / 2) * (r / 2) <= 2048 * 64;
+                    L.TH = gather ? 16 : wino_tile_h(r);
                     L.cap_tiles = mb * (r / 32) * (r / L.TH);
                     L.qlist = static_cast<uint8_t*>(B.dalloc((size_t)L.cap_tiles * 8 * L.TH));
                     L.qcnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
                     L.pcnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
+                    if (gather) {
+                        L.gq_cap = (r / 2) * (r / 2);
+                        L.gq = static_cast<unsigned*>(B.dalloc((size_t)mb * L.gq_cap * sizeof(unsigned)));
+                        L.gq_n = static_cast<int*>(B.dalloc(32 * sizeof(int)));
+                        L.qoff = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
+                    }
                 }
                 const int nrt = (a->C + 15) / 16;
                 bool have = false;
@@ -509,7 +516,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 if (!have) {
                     WinoWork w;
                     w.nrt = nrt;
-                    w.work = static_cast<unsigned*>(B.dalloc((size_t)L.cap_tiles * 4 * ((nrt + 1) / 2) * sizeof(unsigned)));
+                    w.work = static_cast<unsigned*>(B.dalloc(((size_t)L.cap_tiles * 4 + mb) * ((nrt + 1) / 2) * sizeof(unsigned)));
                     w.total = static_cast<int*>(B.dalloc(8 * sizeof(int)));
                     L.works.push_back(w);
                 }
@@ -730,12 +737,14 @@ struct Runner {
         const int ntiles = B * (r / 32) * (r / L.TH);
         if (!wq_done[k]) {
             check(wino_quad_lists(o.S ? o.S->u5 : nullptr, L.qlist, L.qcnt, L.pcnt, B, r, r, L.TH, st), "wino_quad_lists");
+            if (L.gq) check(wino_gather_lists(L.qlist, L.qcnt, L.qoff, L.gq, L.gq_n, L.gq_cap, B, r, r, st), "wino_gather_lists");
             wq_done[k] = true;
         }
         bool done = false;
         for (int d : wwork_done[k]) done = done || d == nrt;
         if (!done) {
-            check(wino_ace_worklist(L.qcnt, L.pcnt, ntiles, nrt, o.W->work, o.W->total, st), "wino_ace_worklist");
+            if (L.gq) check(wino_gather_worklist(L.gq_n, L.pcnt, B, ntiles / B, nrt, o.W->work, o.W->total, st), "wino_gather_worklist");
+            else check(wino_ace_worklist(L.qcnt, L.pcnt, ntiles, nrt, o.W->work, o.W->total, st), "wino_ace_worklist");
             wwork_done[k].push_back(nrt);
         }
         return o;
@@ -964,6 +973,9 @@ struct Runner {
             w.work = wp.W->work;
             w.total = wp.W->total;
             w.zero = m.zero_page;
+            w.gq = wp.L->gq;
+            w.gq_n = wp.L->gq_n;
+            w.gq_cap = wp.L->gq_cap;
             // executed FLOPs = wave tasks x (32 rows x 16 quads x 16 positions x K) x 2; dense = the direct conv over every pixel
             timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 0.0, wp.W->total + 4, 2.0 * 32 * 16 * 16 * ktot, 4.0 * ktot + xpp + opp,
                   4.0 * 2.0 * a.C * ktot * 16, npix, [&] {

@@ -110,7 +110,12 @@ struct SeanModel {
     // Winograd ACE path (conv_wino.h wino_ace_kernel): per resolution level the boundary quads of every 32 x 16 tile and one task
     // list per distinct row-tile count; per-sample style images of the ACE being run
     struct WinoWork { int nrt = 0; unsigned* work = nullptr; int* total = nullptr; };
-    struct WinoLevel { uint8_t* qlist = nullptr; int* qcnt = nullptr; int* pcnt = nullptr; int cap_tiles = 0, TH = 16; std::vector<WinoWork> works; };
+    struct WinoLevel {
+        uint8_t* qlist = nullptr; int* qcnt = nullptr; int* pcnt = nullptr; int cap_tiles = 0, TH = 16; std::vector<WinoWork> works;
+        // gather mode (conv_wino.h): one list of boundary quads per sample, tasks of 64 consecutive entries
+        unsigned* gq = nullptr; int* gq_n = nullptr; int* qoff = nullptr; int gq_cap = 0;
+    };
+    int wino_gather = 1;                       // option "sean.wino_gather": 1 = gather mode of the Winograd ACE kernel (default), 0 = tile mode
     int wino_th = 0;                           // option "sean.wino_th": tile height 16 / 32 of the Winograd ACE kernel (0 = by level)
     // measured per level at B = 16, 512^2 on the benchmark labels (ms for the level's three ACEs, tiles of 32 x 16 / 32 x 32):
     // 512^2 13.8 / 9.6, 256^2 8.1 / 9.6, 128^2 7.9 / 7.1, 64^2 4.1 / 4.8

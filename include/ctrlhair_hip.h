@@ -76,7 +76,9 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   (The Zencoder follows "sean.f16x3".)
  * "sean.wino" (default 1; "sean.f16x3" = 0 only): the ResBlock 3x3 convs, the SPADE gamma/beta convs and the style convs as
  *   Winograd F(2x2,3x3) on the f32 matrix cores, the learned 1x1 shortcuts on the pointwise kernel of conv_pw.h.
- * "sean.wino_th": tile height 16 / 32 of the Winograd ACE kernel (0 = chosen per resolution level).
+ * "sean.wino_gather" (default 1): the Winograd ACE kernel takes tasks of 64 consecutive boundary quads of a sample and fetches each
+ *   quad's own 4 x 4 patch (csrc/conv_wino.h); 0 = tasks per tile of 32 x 16 / 32 x 32 pixels (bit-identical results).
+ * "sean.wino_th": tile height 16 / 32 of the tile mode (0 = chosen per resolution level).
  * "sean.sparse" (default 1): the exact SPADE-interior reduction (csrc/ace_sparse.h).  May be switched off (and back on) after
  *   ch_finalize; a handle finalised with 0 has no classification buffers and rejects 1 afterwards (CH_ERR_STATE).
  * "sean.sparse_min", "sean.sparse_th", "sean.sh16_compact": tuning knobs of that reduction (before ch_finalize).

@@ -4,7 +4,7 @@
 // timing ablations of the first version of the kernel -- whose findings DESIGN.md section 7 records -- were compiled into the
 // kernel itself and slowed it by 5-25 %: the product kernel carries no instrumentation.)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino_ace_bench.hip -o tools/wino_ace_bench.bin ; run on the GPU box.
-//   wino_ace_bench.bin [dbg bits] [TH override: 0 = the product's choice] [only r]
+//   wino_ace_bench.bin [mode: 0 = tile kernel, 1 = gather kernel] [TH override of the tile kernel: 0 = by level] [only r]
 #include "../ctrlhair_amd/csrc/conv_inst_wino.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +35,7 @@ static float* dev_rand(long long n, unsigned seed) {
 struct Shape { int r, C, styled, x_up; const char* name; };
 
 int main(int argc, char** argv) {
-    const int dbg = argc > 1 ? atoi(argv[1]) : 0;
+    const int gather = argc > 1 ? atoi(argv[1]) : 0;
     const int th_over = argc > 2 ? atoi(argv[2]) : 0;
     const int only_r = argc > 3 ? atoi(argv[3]) : 0;
     const int B = 16, grid = 16;
@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
     for (const Shape& c : all) {
         if (only_r && c.r != only_r) continue;
         const int r = c.r, C = c.C, K = 128 + (c.styled ? 20 : 0), nrt = (C + 15) / 16;
-        const int TH = th_over ? th_over : ((r >= 512 || r == 128) ? 32 : 16);
+        const int TH = gather ? 16 : (th_over ? th_over : ((r >= 512 || r == 128) ? 32 : 16));
         // blocky labels (grid x grid blocks per sample) and the interior map: 5x5 uniform and two pixels inside the image
         unsigned seed = 4242u + r;
         std::vector<uint8_t> lab((size_t)B * r * r), u5((size_t)B * r * r);
@@ -77,9 +77,16 @@ int main(int argc, char** argv) {
         const int ntiles = B * (r / 32) * (r / TH);
         uint8_t* d_ql; int *d_qc, *d_pc, *d_tot; unsigned* d_work;
         CK(hipMalloc(&d_ql, (size_t)ntiles * 8 * TH)); CK(hipMalloc(&d_qc, ntiles * 4)); CK(hipMalloc(&d_pc, ntiles * 4));
-        CK(hipMalloc(&d_tot, 32)); CK(hipMalloc(&d_work, (size_t)ntiles * 4 * ((nrt + 1) / 2) * 4));
+        CK(hipMalloc(&d_tot, 32)); CK(hipMalloc(&d_work, ((size_t)ntiles * 4 + B) * ((nrt + 1) / 2) * 4));
         CK(wino_quad_lists(r >= 64 ? d_u5 : nullptr, d_ql, d_qc, d_pc, B, r, r, TH, 0));
-        CK(wino_ace_worklist(d_qc, d_pc, ntiles, nrt, d_work, d_tot, 0));
+        unsigned* d_gq = nullptr; int *d_gqn = nullptr, *d_qoff = nullptr;
+        const int gq_cap = (r / 2) * (r / 2);
+        if (gather) {
+            CK(hipMalloc(&d_gq, (size_t)B * gq_cap * 4)); CK(hipMalloc(&d_gqn, 32 * 4)); CK(hipMalloc(&d_qoff, ntiles * 4));
+            CK(wino_gather_lists(d_ql, d_qc, d_qoff, d_gq, d_gqn, gq_cap, B, r, r, 0));
+            CK(wino_gather_worklist(d_gqn, d_pc, B, ntiles / B, nrt, d_work, d_tot, 0));
+        } else
+            CK(wino_ace_worklist(d_qc, d_pc, ntiles, nrt, d_work, d_tot, 0));
         int tot_h[8];
         CK(hipMemcpy(tot_h, d_tot, 32, hipMemcpyDeviceToHost));
         const long long px = (long long)B * r * r, xpx = c.x_up ? px / 4 : px;
@@ -96,7 +103,7 @@ int main(int argc, char** argv) {
         w.bias_g = d_par; w.bias_b = d_par + C; w.bn_a = d_par + 2 * C; w.bn_d = d_par + 3 * C; w.nv = d_par + 4 * C;
         w.noise = d_noise; w.noise_bstride = (long long)r * r;
         w.qlist = d_ql; w.TH = TH; w.qcnt = d_qc; w.work = d_work; w.total = d_tot; w.zero = d_zero;
-        (void)dbg;
+        w.gq = d_gq; w.gq_n = d_gqn; w.gq_cap = gq_cap;
         CK(conv_wino_ace(w, 0));
         CK(hipDeviceSynchronize());
         hipEvent_t e0, e1;
@@ -115,6 +122,7 @@ int main(int argc, char** argv) {
                c.name, r, C, K, TH, tot_h[0], tot_h[0] / 256.0, tot_h[1], tot_h[1] / (16.0 * tot_h[2]), ms, fl / ms * 1e-9, fl_q / ms * 1e-9);
         fflush(stdout);
         tot += ms * (c.x_up ? 2 : 1);
+        if (d_gq) { hipFree(d_gq); hipFree(d_gqn); hipFree(d_qoff); }
         hipFree(d_u5); hipFree(d_ql); hipFree(d_qc); hipFree(d_pc); hipFree(d_tot); hipFree(d_work);
         hipFree(d_actv); hipFree(d_wpk); if (d_wsty) hipFree(d_wsty); hipFree(d_x); hipFree(d_out); hipFree(d_noise); hipFree(d_par);
     }
