@@ -773,7 +773,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
 // level; a lane's four B rows are four conflict-free ds_read_b128.  Every task but the last of a sample fills all 64 slots.
 // Same arithmetic per quad as the tile kernel: bit-identical results (tests/test_hip_wino.py).
 namespace winog {
-constexpr int NPD = 8, PDW = 4096, NST = 4, ADW2 = 2 * wino::ADW, SDW = PDW + ADW2, NLD = NPD + 2;
+constexpr int NPD = 8, PDW = 4096, NST = 5, ADW2 = 2 * wino::ADW, SDW = PDW + ADW2, NLD = NPD + 2;
 constexpr int LDS_BYTES = NST * SDW * 4;                         // 128 KB
 }  // namespace winog
 
