@@ -299,9 +299,9 @@ def roofline_block(path, prof, value, B, sustained):
         kname = 'conv_sh16_ws_kernel / conv_sh16_kernel <KS=3,...,EPI_ACE> (SPADE gamma/beta conv, f16x3 split operands, fused ACE epilogue)'
     else:
         executed, peak, pk = useful, PEAK_F32_MFMA_TFLOPS, 'f32'
-        kname = ('wino_ace_kernel<TH> (SPADE gamma/beta conv + style convs as Winograd F(2x2,3x3) on the exact-f32 matrix cores over the '
-                 'boundary quads, fused ACE epilogue; --wino 0: conv_ace_sparse_kernel) + conv_mfma_kernel<KS=3,...,EPI_ACE> for '
-                 'the ACEs below 32 pixels')
+        kname = ('wino_ace_gather_kernel (SPADE gamma/beta conv + style convs as Winograd F(2x2,3x3) on the exact-f32 matrix cores over '
+                 'tasks of 64 boundary quads, fused ACE epilogue; --wino 0: conv_ace_sparse_kernel) + conv_mfma_kernel<KS=3,...,EPI_ACE> '
+                 'for the ACEs below 32 pixels')
     traffic = traffic_raw = detail = note = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes

@@ -6,7 +6,7 @@ The golden / oracle tests of test_hip_sean_generator.py already run with them on
 exact-f32 path); here the library is compared with ITSELF on the direct evaluation (sean.wino = 0) at a tolerance far inside the
 parity bound, on the shapes that exercise the kernels' edge cases: a single 16-channel row tile (ngf = 16: the second row tile
 of a pair does not exist), levels below 32 pixels (direct kernels), S < max_size, ragged batches, labels >= 19 at tile borders,
-label maps with no interior pixel, both tile heights of the ACE kernel."""
+label maps with no interior pixel, the gather mode of the ACE kernel (the default) and both tile heights of its tile mode."""
 import numpy as np
 import pytest
 import torch
@@ -49,7 +49,7 @@ def test_winograd_equals_direct_tiny(hip_lib, S, th):
     ngf, B = 16, 3
     sd = P.sean_state_dict(0, ngf)
     direct = _gen(sd, B, 128, 0)
-    wino = _gen(sd, B, 128, 1, {'sean.wino_th': th} if th else None)
+    wino = _gen(sd, B, 128, 1, {'sean.wino_gather': 0, 'sean.wino_th': th} if th else None)      # th = 0: gather mode
     codes, noise = P.style_codes(B, seed=3), P.noise_planes(B, S, ngf, seed=4)
     for name, lab in _label_sets(B, S).items():
         a, b = _run(direct, lab, codes, noise), _run(wino, lab, codes, noise)
@@ -71,7 +71,7 @@ def test_winograd_equals_direct_ngf64(hip_lib):
     from oracle import sean_oracle as O
     ngf, S, B = 64, 256, 2
     sd = P.sean_state_dict(0, ngf)
-    direct, wino = _gen(sd, B, S, 0), _gen(sd, B, S, 1)
+    direct, wino, tile = _gen(sd, B, S, 0), _gen(sd, B, S, 1), _gen(sd, B, S, 1, {'sean.wino_gather': 0})
     codes, noise = P.style_codes(B, seed=8), P.noise_planes(B, S, ngf, seed=9)
     sets = _label_sets(B, S)
     for name in ('face', 'blocky', 'noclass_at_tile_borders', 'diag'):
@@ -79,6 +79,9 @@ def test_winograd_equals_direct_ngf64(hip_lib):
         d = float(np.abs(a - b).max())
         print(f'ngf64 {name}: max |winograd - direct| = {d:.3e}')
         assert d <= 2e-5, name
+        # gather mode (tasks of 64 consecutive boundary quads) against tile mode (tasks per tile): the same arithmetic per quad
+        assert np.array_equal(b, _run(tile, sets[name], codes, noise)), f'{name}: gather and tile mode differ'
+    tile.handle.close()
     ref = O.generator_forward(O.to_torch(sd), sets['face'][:1], codes[:1], noise[:1], ngf).numpy()
     assert np.abs(_run(wino, sets['face'][:1], codes[:1], noise[:1]) - ref).max() <= 1e-3
     # executed-FLOP accounting of the plain convs: 16 / 36 of the dense count on the Winograd levels

@@ -57,9 +57,10 @@ def main(d):
     if cal:
         print(f'MFMA pipe busy is CALIBRATED: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of each kernel divided by the same ratio of an '
               f'MFMA-only loop (tools/mfma_peak.hip, ratio {cal[0]:.1f}, measured {cal[2]:.0f} TFLOP/s = {100 * cal[1]:.1f} % of the 2.5 PFLOP/s '
-              f'dense peak in the same profiled run), times that loop\'s fraction of peak -- i.e. the share of the 2.5 PFLOP/s issue '
-              f'rate at which the kernel kept the matrix cores busy.\n')
-    print('| kernel | grid (threads) | calls | fetch MB | fetch x2 MB | write MB | MFMA pipe busy, % of 2.5 PFLOP/s issue rate (calibrated) | LDS conflict % | avg ms (pmc pass) |')
+              f'dense peak in the same profiled run), times that loop\'s fraction of peak -- i.e. the share of the matrix pipe\'s issue slots '
+              f'the kernel filled, whatever the operand type: 100 % = 157.3 TFLOP/s for the kernels built on f32 MFMAs (wino_*, pw_conv, '
+              f'conv_mfma, conv_ace_sparse), 2.5 PFLOP/s for those on f16 / bf16 MFMAs (conv_sh16*).\n')
+    print('| kernel | grid (threads) | calls | fetch MB | fetch x2 MB | write MB | MFMA pipe busy, % of the pipe's issue slots (calibrated; f32-MFMA kernels: of 157.3 TFLOP/s, f16: of 2.5 PFLOP/s) | LDS conflict % | avg ms (pmc pass) |')
     print('|---|---|---|---|---|---|---|---|---|')
     keys = sorted(f, key=lambda k: -f[k][2])
     for k in keys[:40]:
