@@ -67,6 +67,7 @@ struct WinoParams {
     const float* bias;      // [Cout] or null
     const float* res;       // [B][Cout][H >> res_up][W >> res_up] or null
     int res_up, act;
+    int reflect;            // 1 = reflection padding (pad 1: row -1 is row 1, row H is row H - 2) instead of zeros
     const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image patch elements)
     // set by the launcher
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
@@ -210,7 +211,11 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             const int e = i * 512 + tid;
             const int k4 = e / PS, rem = e - k4 * PS;
             const int py = rem / PWP, px = rem - py * PWP;
-            const int y = y0 + py, x = x0 + px;
+            int y = y0 + py, x = x0 + px;
+            if (p.reflect) {                   // (architecture.py:159 ReflectionPad2d(1): a per-lane source offset like any other)
+                y = y < 0 ? -y : (y >= p.H ? 2 * p.H - 2 - y : y);
+                x = x < 0 ? -x : (x >= p.W ? 2 * p.W - 2 - x : x);
+            }
             const bool ok = k4 < 4 && rem < PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
         }

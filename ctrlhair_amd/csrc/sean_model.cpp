@@ -368,6 +368,12 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             z10 = make_conv(B, w, B.vec("Zencoder.model.10.bias", 256), 256, 128, 3, 1, 1);
         }
         plain("Zencoder.model.14", 512, 256, 1, z14);
+        z14_wino = nullptr;
+        if (!use_sh16 && wino) {   // exact-f32 path: the 256 -> 512 conv (91 % of the Zencoder FLOPs) as Winograd F(2x2,3x3), reflection-padded
+            auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
+            const float* wp = w14.data();
+            z14_wino = B.upload(pack_wino_A(512, 256, [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; }));
+        }
         if (use_sh16) {   // the 256->512 conv is 91 % of the Zencoder FLOPs: run it on the f16x3 path too
             auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
             const float* wp = w14.data();
@@ -1386,7 +1392,23 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             ck(conv_sh16_plain(p, 3, st), "zenc conv5 (f16x3)");
         } else {
             ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
-            ck(run_conv(z14, hs, h0, B, h2, h2, last, st), "zenc conv5");
+            if (z14_wino && wino_supported(h2, h2, 256)) {
+                WinoParams q{};
+                q.in = hs;
+                q.wpk = z14_wino;
+                q.out = h0;
+                q.B = B;
+                q.Cin = 256;
+                q.Cout = 512;
+                q.H = h2;
+                q.W = h2;
+                q.bias = z14.bias;
+                q.act = ACT_TANH;
+                q.reflect = 1;
+                q.zero = zero_page;
+                ck(conv_wino_plain(q, st), "zenc conv5 (winograd)");
+            } else
+                ck(run_conv(z14, hs, h0, B, h2, h2, last, st), "zenc conv5");
         }
         }   // phase != 2
         if (phase == 1) {
