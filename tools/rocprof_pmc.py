@@ -60,7 +60,7 @@ def main(d):
               f'dense peak in the same profiled run), times that loop\'s fraction of peak -- i.e. the share of the matrix pipe\'s issue slots '
               f'the kernel filled, whatever the operand type: 100 % = 157.3 TFLOP/s for the kernels built on f32 MFMAs (wino_*, pw_conv, '
               f'conv_mfma, conv_ace_sparse), 2.5 PFLOP/s for those on f16 / bf16 MFMAs (conv_sh16*).\n')
-    print('| kernel | grid (threads) | calls | fetch MB | fetch x2 MB | write MB | MFMA pipe busy, % of the pipe's issue slots (calibrated; f32-MFMA kernels: of 157.3 TFLOP/s, f16: of 2.5 PFLOP/s) | LDS conflict % | avg ms (pmc pass) |')
+    print("| kernel | grid (threads) | calls | fetch MB | fetch x2 MB | write MB | MFMA pipe busy, % of the pipe's issue slots (calibrated; f32-MFMA kernels: of 157.3 TFLOP/s, f16: of 2.5 PFLOP/s) | LDS conflict % | avg ms (pmc pass) |")
     print('|---|---|---|---|---|---|---|---|---|')
     keys = sorted(f, key=lambda k: -f[k][2])
     for k in keys[:40]:
