@@ -26,7 +26,7 @@ hipError_t fc_mu(const float* codes, const float* Wt, const float* bias, float* 
                  int pass = 0, int bf16 = 0);
 hipError_t fc_mu_batched(const float* codes, const float* const* Wts, const float* const* biases, float* mu_base,
                          long long mu_stride, int n_aces, int B, int Npad, int bs, float scale, unsigned* amax_slots, int pass,
-                         int bf16, hipStream_t s);
+                         int bf16, hipStream_t s, int sh16 = 1);
 // w4 (C4 path): the same weights packed [Cin/4][tap][co][4 channels] for scalar loads
 hipError_t conv_img_tanh(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                          hipStream_t s, int c4 = 0, const float* w4 = nullptr);

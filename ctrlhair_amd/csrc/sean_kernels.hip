@@ -506,18 +506,19 @@ __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ co
 __global__ __launch_bounds__(256) void fc_mu_batched_kernel(const float* __restrict__ codes, const float* const* __restrict__ Wts,
                                                             const float* const* __restrict__ biases, float* __restrict__ mu_base,
                                                             long long mu_stride, int B, int Npad, int bs, float scale,
-                                                            unsigned* __restrict__ amax_slots, int pass, int bf16) {
+                                                            unsigned* __restrict__ amax_slots, int pass, int bf16, int sh16) {
     const int a = blockIdx.z;
     const float* Wt = Wts[a];
     if (!Wt) return;
-    fc_mu_body(codes, Wt, biases[a], mu_base + a * mu_stride, B, Npad, nullptr, 1, bs, scale, amax_slots + 2 * a + 1, pass, bf16,
-               blockIdx.x, blockIdx.y);
+    fc_mu_body(codes, Wt, biases[a], mu_base + a * mu_stride, B, Npad, nullptr, sh16, bs, scale, sh16 ? amax_slots + 2 * a + 1 : nullptr, pass,
+               bf16, blockIdx.x, blockIdx.y);
 }
+// sh16 = 0: f32 images [512][Npad] (exact-f32 path; no scale protocol, one pass)
 hipError_t fc_mu_batched(const float* codes, const float* const* Wts, const float* const* biases, float* mu_base,
                          long long mu_stride, int n_aces, int B, int Npad, int bs, float scale, unsigned* amax_slots, int pass,
-                         int bf16, hipStream_t s) {
+                         int bf16, hipStream_t s, int sh16) {
     hipLaunchKernelGGL(fc_mu_batched_kernel, dim3(512 / 16, 19, n_aces), dim3(256), 0, s, codes, Wts, biases, mu_base, mu_stride, B,
-                       Npad, bs, scale, amax_slots, pass, bf16);
+                       Npad, bs, scale, amax_slots, pass, bf16, sh16);
     return hipGetLastError();
 }
 

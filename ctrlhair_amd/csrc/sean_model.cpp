@@ -451,7 +451,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     const size_t npad = ((MB * (LABEL_NC + 1) + 31) / 32) * 32;     // f16x3 path: 20 columns per sample (19 = zero column)
     mu_img = static_cast<float*>(B.dalloc((size_t)STYLE * npad * 4));
     if (mu_img) (void)hipMemset(mu_img, 0, (size_t)STYLE * npad * 4);      // pad columns stay zero
-    fcmu_batched = use_sh16 && max_batch * (LABEL_NC + 1) > 64;
+    // one fc_mu launch per chunk for all styled ACEs (f16x3: SH16 images; exact f32: f32 images, batches of more than 64 (sample, label) columns)
+    fcmu_batched = use_sh16 ? max_batch * (LABEL_NC + 1) > 64 : max_batch * LABEL_NC > 64;
     if (fcmu_batched) {
         mu_stride = (long long)STYLE * npad;
         mu_all = static_cast<float*>(B.dalloc((size_t)n_aces * mu_stride * 4));
@@ -828,9 +829,11 @@ struct Runner {
                 q.lut_rs = npad;
                 q.lut_ns = 4;
             } else {
-                check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s), "fc_mu");
+                const float* mu = m.mu_img;
+                if (m.fcmu_batched && N > 64) mu = m.mu_all + (size_t)a.index * m.mu_stride;      // projected at the start of the chunk (generate())
+                else check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s), "fc_mu");
                 ConvParams p{};
-                p.in = m.mu_img;
+                p.in = mu;
                 p.wpk = a.lut_wpk;
                 p.out = lut_buf;
                 p.B = 1;
@@ -1218,7 +1221,11 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         }
         for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");
         if (use_sh16) R.check(hipMemsetAsync(amax_slots, 0, 64 * sizeof(unsigned), st), "amax slots");
-        if (fcmu_batched) {
+        if (fcmu_batched && !use_sh16) {
+            if (B * LABEL_NC > 64)       // (smaller batches take the GEMV branch of ace_prepare, which projects per ACE)
+                R.check(fc_mu_batched(cd, fcmu_w_ptrs, fcmu_b_ptrs, mu_all, mu_stride, n_aces, B, ((B * LABEL_NC + 31) / 32) * 32, LABEL_NC, 1.f,
+                                      nullptr, 0, 0, st, 0), "fc_mu (all ACEs)");
+        } else if (fcmu_batched) {
             const int npad_c = ((B * (LABEL_NC + 1) + 31) / 32) * 32;
             for (int pass = 0; pass < 2; ++pass)         // second pass: returns at once unless a projection left the f16 window
                 R.check(fc_mu_batched(cd, fcmu_w_ptrs, fcmu_b_ptrs, mu_all, mu_stride, n_aces, B, npad_c, LABEL_NC + 1, SH16_ACT_SCALE,
