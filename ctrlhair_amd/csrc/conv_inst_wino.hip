@@ -29,7 +29,7 @@ static hipError_t wino_attr(K kern, int bytes, bool (&done)[64]) {
 }
 
 hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
-    if (!wino_supported(p.H, p.W, p.Cin) || !p.zero) return hipErrorInvalidValue;
+    if ((!wino_supported(p.H, p.W, p.Cin) && !(wino_supported_pair16(p.B, p.H, p.W, p.Cin) && !p.reflect && !p.res_up)) || !p.zero) return hipErrorInvalidValue;
     wino_fill_launch(p);
     const int grid = p.ntasks < wino_num_cus() ? p.ntasks : wino_num_cus();
     static bool d0[64] = {};

@@ -68,6 +68,7 @@ struct WinoParams {
     const float* res;       // [B][Cout][H >> res_up][W >> res_up] or null
     int res_up, act;
     int reflect;            // 1 = reflection padding (pad 1: row -1 is row 1, row H is row H - 2) instead of zeros
+    int pair16;             // set by the launcher for 16 x 16 images (B even): two samples side by side fill a tile of 32 x 16 pixels
     const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image patch elements)
     // set by the launcher
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
@@ -212,14 +213,20 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             const int k4 = e / PS, rem = e - k4 * PS;
             const int py = rem / PWP, px = rem - py * PWP;
             int y = y0 + py, x = x0 + px;
+            int sub = 0;                       // pair16: patch columns 0-17 = sample 2 ib, 18-35 = sample 2 ib + 1 (each 16 wide + its halo)
+            if (p.pair16) {
+                sub = px >= 18 ? 1 : 0;
+                x = px - 18 * sub - 1;
+            }
             if (p.reflect) {                   // (architecture.py:159 ReflectionPad2d(1): a per-lane source offset like any other)
                 y = y < 0 ? -y : (y >= p.H ? 2 * p.H - 2 - y : y);
                 x = x < 0 ? -x : (x >= p.W ? 2 * p.W - 2 - x : x);
             }
-            const bool ok = k4 < 4 && rem < PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
+            const bool ok = k4 < 4 && rem < PROWS * PWP && (p.pair16 || px < TW + 2) && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            voff[i] = ok ? (unsigned)((sub * p.Cin + k4) * HW + y * p.W + x) * 4u : 0x80000000u;
         }
-        d_in = wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
+        d_in = p.pair16 ? wino_rsrc(p.in + (long long)ib * 2 * p.Cin * HW, 2u * (unsigned)p.Cin * HW * 4u)
+                        : wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
         d_a = wino_rsrc(p.wpk + (long long)irt * p.nks * 2048, (unsigned)p.nks * 8192u);
         so_in = 0;
         so_a = 0;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[x][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int boff = kk * PS + (2 * wave) * PWP + 2 * n;      // this lane's patch origin (floats) inside a stage
+    const int boff = kk * PS + (2 * wave) * PWP + 2 * n + ((p.pair16 && n >= 8) ? 2 : 0);      // this lane's patch origin (floats) inside a stage
     auto load_raw = [&](unsigned slot, float (&d)[4][4]) {
         const float* sp = reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + boff;
 #pragma unroll
@@ -363,8 +370,9 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
         {
             int crt, tile;
             wino_task(p, ct, crt, tile);
-            const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
-            const int y = ty * TH + 2 * wave, x = tx * TW + 2 * n;
+            const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty;
+            const int b = p.pair16 ? 2 * (tile / (p.ntx * p.nty)) + (n >> 3) : tile / (p.ntx * p.nty);
+            const int y = ty * TH + 2 * wave, x = p.pair16 ? 2 * (n & 7) : tx * TW + 2 * n;
             const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
             float bs[2][4];
             float2 r0[2][4], r1[2][4];
@@ -1046,12 +1054,15 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
 }
 
 inline bool wino_supported(int H, int W, int Cin) { return H % wino::TH == 0 && W % wino::TW == 0 && Cin % 8 == 0 && H >= 16; }
+// 16 x 16 images (the generator's head block at 512^2): pairs of samples share a tile
+inline bool wino_supported_pair16(int B, int H, int W, int Cin) { return H == 16 && W == 16 && B % 2 == 0 && Cin % 8 == 0; }
 
 inline void wino_fill_launch(WinoParams& p) {
     p.nrt = (p.Cout + 31) / 32;
-    p.ntx = p.W / wino::TW;
+    p.pair16 = (p.W == 16 && p.H == 16) ? 1 : 0;
+    p.ntx = p.pair16 ? 1 : p.W / wino::TW;
     p.nty = p.H / wino::TH;
-    p.ntiles = p.B * p.ntx * p.nty;
+    p.ntiles = (p.pair16 ? p.B / 2 : p.B) * p.ntx * p.nty;
     p.ntasks = p.ntiles * p.nrt;
     p.nks = p.Cin / 4;
     p.rb = p.nrt >= 4 ? 4 : p.nrt;

@@ -1108,7 +1108,7 @@ struct Runner {
                !(((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192);
     }
     bool use_wino(const ConvW& w, int r) const {
-        return m.wino && !m.use_sh16 && w.wino && w.KS == 3 && wino_supported(r, r, w.Cin);
+        return m.wino && !m.use_sh16 && w.wino && w.KS == 3 && (wino_supported(r, r, w.Cin) || wino_supported_pair16(B, r, r, w.Cin));
     }
     // `prod` / `prod2`: the ACEs that wrote `in` / `in2` (their slots hold the scale in effect)
     void conv(const ConvW& w, const float* in, const AceW& prod, float* out, int r, const float* res, int res_up,
@@ -1142,7 +1142,7 @@ struct Runner {
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS, cin2 = w2 ? w2->Cin : 0;
-        if (use_wino(w, r) && !w2) {
+        if (use_wino(w, r) && !w2 && !(r == 16 && res_up)) {      // (16 x 16 sample pairs: residual at the same size only)
             // Winograd F(2x2,3x3) on the exact-f32 matrix cores: 16 MFMA products per quad and channel instead of 36
             WinoParams q{};
             q.in = in;

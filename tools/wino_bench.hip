@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
     const int dbg = argc > 2 && !strcmp(argv[1], "dbg") ? atoi(argv[2]) : 0;      // timing ablations (wrong results)
     const Shape all[] = {
         {2, 16, 16, 32, 0, 0, "tiny"}, {3, 32, 48, 64, 0, 1, "tiny res, ragged rows"}, {1, 28, 32, 32, 0, 2, "tiny res_up, odd k-steps"},
-        {2, 64, 64, 64, 0, 1, "small res"},
+        {2, 64, 64, 64, 0, 1, "small res"}, {4, 32, 48, 16, 0, 1, "16^2 sample pairs, ragged rows"}, {16, 1024, 1024, 16, 0, 1, "G_head conv (+x), 16^2 pairs"},
         {16, 1024, 1024, 32, 0, 0, "G_middle conv_0"}, {16, 1024, 1024, 32, 0, 1, "G_middle conv_1 (+x)"},
         {16, 1024, 512, 64, 0, 0, "up_0 conv_0"}, {16, 512, 512, 64, 0, 1, "up_0 conv_1 (+xs)"},
         {16, 512, 256, 128, 0, 0, "up_1 conv_0"}, {16, 256, 256, 128, 0, 1, "up_1 conv_1 (+xs)"},
@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
     for (const Shape& c : all) {
         if (quick && c.B * (long long)c.H * c.H * c.Cout > (1 << 22)) continue;
         if (dbg && c.B < 16) continue;
-        if (!wino_supported(c.H, c.H, c.Cin)) { printf("%-28s skipped (Cin / 4 k-steps do not exceed the ring's run-ahead: direct kernel)\n", c.name); continue; }
+        if (!wino_supported(c.H, c.H, c.Cin) && !wino_supported_pair16(c.B, c.H, c.H, c.Cin)) { printf("%-28s skipped (Cin / 4 k-steps do not exceed the ring's run-ahead: direct kernel)\n", c.name); continue; }
         const int B = c.B, Cin = c.Cin, Cout = c.Cout, H = c.H, W = c.H, Cin2 = c.Cin2;
         const size_t nin = (size_t)B * Cin * H * W, nout = (size_t)B * Cout * H * W, nin2 = (size_t)B * Cin2 * H * W;
         const int rh = c.res == 2 ? H / 2 : H;
