@@ -348,6 +348,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.wino = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.lut_grouped") == 0) {    // exact-f32 path: 1 = the style LUTs of a chunk from one grouped GEMM launch (default)
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.lut_grouped) must precede ch_finalize");
+        h->sean.lut_grouped = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.wino_gather") == 0) {    // 1 = gather mode of the Winograd ACE kernel (default), 0 = tile mode
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino_gather) must precede ch_finalize");
         h->sean.wino_gather = value != 0;

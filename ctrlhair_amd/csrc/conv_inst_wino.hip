@@ -57,7 +57,28 @@ static hipError_t launch_pw(PwParams p, hipStream_t s) {
 }
 hipError_t conv_pw(PwParams p, hipStream_t s) {
     if (!pw_supported(p.Cin, p.Cout, p.HW)) return hipErrorInvalidValue;
+    p.groups = nullptr;
+    p.ngroups = 0;
     return (p.Cout + 31) / 32 >= 4 ? launch_pw<4>(p, s) : launch_pw<2>(p, s);
+}
+// several GEMMs (same Cin, same Cout, own operands and pixel counts) as ONE persistent launch of the RT = 4 kernel (conv_pw.h)
+hipError_t conv_pw_grouped(PwParams p, int ntasks, hipStream_t s) {
+    using Cfg = PwCfg<4>;
+    if (p.Cin % 16 || p.Cout < 32 || !p.groups || p.ngroups < 1 || ntasks < 1) return hipErrorInvalidValue;
+    static bool d0[64] = {};
+    hipError_t e = wino_attr(pw_conv_kernel<4>, Cfg::LDS_BYTES, d0);
+    if (e != hipSuccess) return e;
+    p.in = p.wpk = nullptr;
+    p.out = nullptr;
+    p.B = 1;
+    p.HW = 0;
+    p.nrg = ((p.Cout + 31) / 32 + 3) / 4;
+    p.npt = 0;
+    p.ntasks = ntasks;
+    p.nst = p.Cin / 16;
+    const int grid = ntasks < wino_num_cus() ? ntasks : wino_num_cus();
+    hipLaunchKernelGGL(pw_conv_kernel<4>, dim3(grid), dim3(512), Cfg::LDS_BYTES, s, p);
+    return hipGetLastError();
 }
 
 template <int TH>

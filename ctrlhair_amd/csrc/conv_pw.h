@@ -14,11 +14,23 @@
 
 namespace chk {
 
+// GROUPED launch (conv_pw_grouped): several GEMMs with the same Cin and Cout but their own operands and pixel counts run as ONE
+// persistent launch -- the exact-f32 style-LUT builds of all styled ACEs of the generator (sean_model.cpp: operands swapped, the
+// "pixels" are the 18 C rows of conv_gamma / conv_beta, the GEMM rows the (sample, label) columns).  Group g owns the tasks
+// [start, next group's start) x row groups: local task -> (row group fastest, pixel tile).
+struct PwGroup {
+    const float* in;        // [Cin][HW]
+    const float* wpk;       // pack_pw_A image of the group's Cout rows
+    float* out;             // [Cout][HW]
+    int HW, start;          // HW % 128 == 0; pixel tiles (of 128) before this group: its first task is start * (row groups of the launch)
+};
 struct PwParams {
     const float* in;        // [B][Cin][HW]
     const float* wpk;       // pack_pw_A image
     float* out;             // [B][Cout][HW]
     int B, Cin, Cout, HW;   // Cin % 16 == 0, HW % (512 / RT) == 0
+    const PwGroup* groups;  // device array of ngroups entries, or null (plain launch)
+    int ngroups;
     // set by the launcher
     int nrg, npt, ntasks, nst;
 };
@@ -59,8 +71,14 @@ __global__ __launch_bounds__(512, 1) void pw_conv_kernel(const PwParams p) {
     const int lb = xcd_remap(blockIdx.x, G);
     if (lb >= p.ntasks) return;
     const int mytasks = (p.ntasks - lb + G - 1) / G;
-    const int nst = p.nst, HW = p.HW;
+    const int nst = p.nst;
     constexpr unsigned SB = SDW * 4, RING = NST * SB;
+    // grouped launch: task -> group (wave-uniform scan of at most a few dozen entries through scalar loads)
+    auto group_of = [&](int L) {
+        int g = 0;
+        while (g + 1 < p.ngroups && L >= p.groups[g + 1].start * p.nrg) ++g;
+        return g;
+    };
     const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
 
     // ---- issue side: task L -> (row group rg fastest, pixel tile, sample) ----------------------------------------------------------
@@ -69,17 +87,34 @@ __global__ __launch_bounds__(512, 1) void pw_conv_kernel(const PwParams p) {
     int it = lb, is = 0;
     wino_u32x4 d_in, d_a;
     unsigned so_in = 0, so_a = 0;
+    int HW = p.HW;                          // pixels per channel plane of the task the issue side serves
     auto issue_task = [&]() {
-        const int rg = it % p.nrg, pt = (it / p.nrg) % p.npt, ib = it / (p.nrg * p.npt);
+        int rg, pt, ib;
+        const float *tin, *twpk;
+        if (p.groups) {
+            const int g = group_of(it), local = it - p.groups[g].start * p.nrg;
+            rg = local % p.nrg;
+            pt = local / p.nrg;
+            ib = 0;
+            HW = p.groups[g].HW;
+            tin = p.groups[g].in;
+            twpk = p.groups[g].wpk;
+        } else {
+            rg = it % p.nrg;
+            pt = (it / p.nrg) % p.npt;
+            ib = it / (p.nrg * p.npt);
+            tin = p.in;
+            twpk = p.wpk;
+        }
 #pragma unroll
         for (int i = 0; i < NPD; ++i) {
             const int u = i * 512 + tid, ch = u / (PXB / 4), q = u - ch * (PXB / 4);
             vp[i] = (unsigned)(ch * HW + pt * PXB + 4 * q) * 4u;
         }
-        d_in = wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
+        d_in = wino_rsrc(tin + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
         // the RT row tiles of a group are consecutive images of nst * 2 KB each: thread tid copies unit (tid & 127) of row tile tid >> 7
         const int nrt = (p.Cout + 31) / 32, have = nrt - rg * RT < RT ? nrt - rg * RT : RT;       // (last group may be partial)
-        d_a = wino_rsrc(p.wpk + (long long)rg * RT * nst * 512, (unsigned)have * nst * 2048u);
+        d_a = wino_rsrc(twpk + (long long)rg * RT * nst * 512, (unsigned)have * nst * 2048u);
         so_in = 0;
         so_a = 0;
     };
@@ -158,15 +193,30 @@ __global__ __launch_bounds__(512, 1) void pw_conv_kernel(const PwParams p) {
         }
         // ---- epilogue: 32 rows x 64 pixels per wave, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel lane & 31 -------------------
         {
-            const int rg = ct % p.nrg, pt = (ct / p.nrg) % p.npt, b = ct / (p.nrg * p.npt);
+            int rg, pt, b, eHW;
+            float* tout;
+            if (p.groups) {
+                const int g = group_of(ct), local = ct - p.groups[g].start * p.nrg;
+                rg = local % p.nrg;
+                pt = local / p.nrg;
+                b = 0;
+                eHW = p.groups[g].HW;
+                tout = p.groups[g].out;
+            } else {
+                rg = ct % p.nrg;
+                pt = (ct / p.nrg) % p.npt;
+                b = ct / (p.nrg * p.npt);
+                eHW = p.HW;
+                tout = p.out;
+            }
             const int row0 = (rg * RT + rtl) * 32 + 4 * (lane >> 5);
-            float* ob = p.out + (long long)b * p.Cout * HW + pt * PXB + pg * 64 + (lane & 31);
+            float* ob = tout + (long long)b * p.Cout * eHW + pt * PXB + pg * 64 + (lane & 31);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2);
-                    if (row < p.Cout) ob[(long long)row * HW + n * 32] = acc[n][r];
+                    if (row < p.Cout) ob[(long long)row * eHW + n * 32] = acc[n][r];
                     acc[n][r] = 0.f;
                 }
             after_epi = true;
@@ -177,5 +227,8 @@ __global__ __launch_bounds__(512, 1) void pw_conv_kernel(const PwParams p) {
 
 inline bool pw_supported(int Cin, int Cout, int HW) { return Cin % 16 == 0 && HW % 256 == 0 && Cout >= 32; }
 hipError_t conv_pw(PwParams p, hipStream_t s);              // conv_inst_wino.hip
+// grouped launch: p.groups / p.ngroups (device array), p.Cin, p.Cout; ntasks = (sum of the groups' pixel tiles) x row groups
+inline int pw_group_tasks(int Cout, int HW) { return ((((Cout + 31) / 32) + 3) / 4) * (HW / 128); }
+hipError_t conv_pw_grouped(PwParams p, int ntasks, hipStream_t s);
 
 }  // namespace chk

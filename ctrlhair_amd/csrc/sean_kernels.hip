@@ -421,7 +421,7 @@ __device__ __forceinline__ void fc_mu_body(const float* __restrict__ codes, cons
     // SH16 output (f16x3 LUT GEMM): first pass writes with `scale` and records max |mu * scale|; the second pass returns
     // at once unless that maximum left the f16 window, else rewrites with the corrected scale (sh16.h)
     sh16_mode_on();
-    if (sh16 && amax && pass == 1) {
+    if (sh16 == 1 && amax && pass == 1) {
         const float e = sh16_dyn_extra(*amax);
         if (e == 1.f) return;
         scale *= e;
@@ -474,13 +474,15 @@ __device__ __forceinline__ void fc_mu_body(const float* __restrict__ codes, cons
                         if (bs > 19 && j == 0) {   // (re)write the zero column: the image pitch Npad changes with the batch
                             const int nz = (bb + t) * bs + 19;
                             if (mu_rows) mu_rows[(long long)nz * 512 + o] = 0.f;
-                            else if (sh16) {
+                            else if (sh16 == 1) {
                                 _Float16* mh = reinterpret_cast<_Float16*>(mu_img);
                                 mh[(((long long)(o >> 3) * 2 + 0) * Npad + nz) * 8 + (o & 7)] = (_Float16)0.f;
                                 mh[(((long long)(o >> 3) * 2 + 1) * Npad + nz) * 8 + (o & 7)] = (_Float16)0.f;
                             }
                         }
                         if (mu_rows) mu_rows[(long long)n * 512 + o] = r;   // [N][512] for the GEMV path
+                        else if (sh16 == 2)   // A-fragment order of the grouped LUT build (conv_pw.h pack_pw_A: row n, input channel o)
+                            mu_img[((long long)(n >> 5) * 32 + (o >> 4)) * 512 + ((n & 31) + 32 * (o & 1)) * 8 + ((o & 15) >> 1)] = r;
                         else if (sh16) {   // split-operand image [512/8][hi|lo][Npad][8] for the f16x3 LUT GEMM
                             _Float16* mh = reinterpret_cast<_Float16*>(mu_img);
                             _Float16 h, l;
@@ -492,7 +494,7 @@ __device__ __forceinline__ void fc_mu_body(const float* __restrict__ codes, cons
                     }
         }
     }
-    if (sh16 && amax && pass == 0 && lane == 0) sh16_slot_max(amax, vmax);
+    if (sh16 == 1 && amax && pass == 0 && lane == 0) sh16_slot_max(amax, vmax);
 }
 __global__ __launch_bounds__(256) void fc_mu_kernel(const float* __restrict__ codes, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ mu_img, int B,
@@ -510,10 +512,10 @@ __global__ __launch_bounds__(256) void fc_mu_batched_kernel(const float* __restr
     const int a = blockIdx.z;
     const float* Wt = Wts[a];
     if (!Wt) return;
-    fc_mu_body(codes, Wt, biases[a], mu_base + a * mu_stride, B, Npad, nullptr, sh16, bs, scale, sh16 ? amax_slots + 2 * a + 1 : nullptr, pass,
+    fc_mu_body(codes, Wt, biases[a], mu_base + a * mu_stride, B, Npad, nullptr, sh16, bs, scale, sh16 == 1 ? amax_slots + 2 * a + 1 : nullptr, pass,
                bf16, blockIdx.x, blockIdx.y);
 }
-// sh16 = 0: f32 images [512][Npad] (exact-f32 path; no scale protocol, one pass)
+// sh16 = 0: f32 images [512][Npad] (exact-f32 path; no scale protocol, one pass); sh16 = 2: f32 in the A-fragment order of conv_pw.h
 hipError_t fc_mu_batched(const float* codes, const float* const* Wts, const float* const* biases, float* mu_base,
                          long long mu_stride, int n_aces, int B, int Npad, int bs, float scale, unsigned* amax_slots, int pass,
                          int bf16, hipStream_t s, int sh16) {

@@ -321,6 +321,12 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     a.lut_wscale = B.upload(sh16_wscale(kexp));
                 } else {
                     a.lut_wpk = B.upload(pack_A(18 * C, STYLE, 1, CK_KS1, getl));
+                    if (max_batch * LABEL_NC > 64) {      // grouped LUT build (conv_pw.h): [k][row] image
+                        std::vector<float> wt((size_t)STYLE * 18 * C);
+                        for (int row = 0; row < 18 * C; ++row)
+                            for (int k = 0; k < STYLE; ++k) wt[(size_t)k * 18 * C + row] = getl(row, k, 0);
+                        a.lut_wt = B.upload(wt);
+                    }
                 }
                 if (max_batch * (LABEL_NC + 1) <= 64) {   // small batches (interactive use): the LUT build is a weight-streaming GEMV
                     std::vector<float> rows((size_t)18 * C * STYLE);
@@ -466,6 +472,37 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         if (fcmu_w_ptrs && fcmu_b_ptrs) {
             (void)hipMemcpy(fcmu_w_ptrs, wp.data(), n_aces * sizeof(float*), hipMemcpyHostToDevice);
             (void)hipMemcpy(fcmu_b_ptrs, bp.data(), n_aces * sizeof(float*), hipMemcpyHostToDevice);
+        }
+    }
+    lut_groups = nullptr;
+    lut_ngroups = lut_group_tiles = 0;
+    lut_group_rows = 0.0;
+    if (fcmu_batched && !use_sh16 && lut_grouped) {
+        if (lut_ahead.empty()) lut_ahead.assign(n_aces, nullptr);
+        std::vector<PwGroup> g;
+        bool ok = true;                           // all styled ACEs or none: the consumers take every LUT from the same place
+        for (const auto& b : blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1})
+                if (a && a->styled && (!a->lut_wt || (18 * a->C) % 128)) ok = false;
+        for (const auto& b : blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
+                if (!ok || !a || !a->styled) continue;
+                if (!lut_ahead[a->index]) lut_ahead[a->index] = B.falloc(npad * 18 * a->C);
+                PwGroup e{};
+                e.in = a->lut_wt;
+                e.wpk = mu_all + (size_t)a->index * mu_stride;
+                e.out = lut_ahead[a->index];
+                e.HW = 18 * a->C;                 // (C % 64 == 0: 18 C % 128 == 0)
+                e.start = lut_group_tiles;        // in pixel tiles; the kernel multiplies by the call's row groups
+                if (!e.out) { ok = false; continue; }
+                lut_group_tiles += e.HW / 128;
+                lut_group_rows += e.HW;
+                g.push_back(e);
+            }
+        if (ok && !g.empty()) {
+            lut_groups = B.dalloc(g.size() * sizeof(PwGroup));
+            if (lut_groups) (void)hipMemcpy(lut_groups, g.data(), g.size() * sizeof(PwGroup), hipMemcpyHostToDevice);
+            lut_ngroups = (int)g.size();
         }
     }
     size_t lutmax = 0, h0max = 0, midmax = 0, outmax = 0;
@@ -864,6 +901,13 @@ struct Runner {
     // full = false (large jobs): only the style LUT builds run ahead; the label-table kernels stay inline.
     bool ahead = false, ahead_luts = false;
     std::vector<AcePrep> prepared;
+    bool luts_ready = false;
+    void lut_entry(const AceW& a, AcePrep& e) const {
+        e.lut = m.lut_ahead[a.index];
+        e.lut_rs = 1;
+        e.lut_ns = 18 * a.C;
+        e.lut_bs = LABEL_NC;
+    }
     void prepare_all_ahead(const uint8_t* labfull, const float* codes, bool full) {
         ahead = full;
         ahead_luts = !full;
@@ -873,10 +917,35 @@ struct Runner {
         for (const auto& b : m.blocks)
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a || (!full && !a->styled)) continue;
-                prepared[a->index] = ace_prepare(*a, labfull, codes, m.side, m.actv_ahead[a->index], m.lut_ahead[a->index],
-                                                 m.splitk_side, false, full ? 3 : 1);
+                AcePrep e = ace_prepare(*a, labfull, codes, m.side, m.actv_ahead[a->index], m.lut_ahead[a->index], m.splitk_side, false,
+                                        full ? (luts_ready ? 2 : 3) : 1);
+                if (luts_ready && a->styled) lut_entry(*a, e);          // (the grouped launch on the main stream built it)
+                prepared[a->index] = e;
                 check(hipEventRecord(m.ev_join[a->index], m.side), "join record");
             }
+    }
+
+    // Exact-f32 path, more than 64 (sample, label) columns: the style LUTs P[(sample, label)][18 C] of ALL styled ACEs from one
+    // grouped GEMM launch on the main stream (conv_pw.h; 15 separate launches of the generic 1x1 kernel took 3.6 ms of GPU time per
+    // step on the side stream and delayed the persistent conv kernels they shared CUs with by 1.8 ms; inline 2.8 ms).  Operands
+    // swapped: GEMM rows = the (sample, label) columns (A = the projected codes, packed by fc_mu_batched), "pixels" = the 18 C rows
+    // of conv_gamma / conv_beta (normalization.py:172-173), so the output is the [n][18 C] layout the consumers read.
+    void luts_grouped() {
+        const int N = B * LABEL_NC;
+        PwParams q{};
+        q.Cin = STYLE;
+        q.Cout = N;
+        q.groups = static_cast<const PwGroup*>(m.lut_groups);
+        q.ngroups = m.lut_ngroups;
+        const int nrg = ((N + 31) / 32 + 3) / 4;
+        timed(2, 2.0 * m.lut_group_rows * STYLE * N, 4.0 * (m.lut_group_rows * STYLE + m.lut_group_rows * N + (double)m.lut_ngroups * STYLE * N),
+              [&] { check(conv_pw_grouped(q, m.lut_group_tiles * nrg, st), "style LUTs (grouped GEMM)"); });
+        prepared.assign(m.n_aces, AcePrep());
+        for (const auto& b : m.blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
+                if (a && a->styled) lut_entry(*a, prepared[a->index]);
+            }
+        luts_ready = true;
     }
 
     // one ACE: SPADE hidden activations (label LUT) -> fused gamma/beta conv + modulation -> h
@@ -918,6 +987,10 @@ struct Runner {
         if (ahead) {
             q = prepared[a.index];
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
+        } else if (luts_ready && a.styled) {
+            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt);     // label table inline
+            q = prepared[a.index];
+            q.actv = m.actv;
         } else if (ahead_luts && a.styled) {
             (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt);     // label table inline
             q = prepared[a.index];
@@ -1222,9 +1295,13 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");
         if (use_sh16) R.check(hipMemsetAsync(amax_slots, 0, 64 * sizeof(unsigned), st), "amax slots");
         if (fcmu_batched && !use_sh16) {
-            if (B * LABEL_NC > 64)       // (smaller batches take the GEMV branch of ace_prepare, which projects per ACE)
+            if (B * LABEL_NC > 64) {     // (smaller batches take the GEMV branch of ace_prepare, which projects per ACE)
+                // grouped LUT build: the projections are its A operand, written in fragment order (sh16 = 2: pack_pw_A layout)
+                const bool grouped = lut_groups && lut_ngroups > 0;
                 R.check(fc_mu_batched(cd, fcmu_w_ptrs, fcmu_b_ptrs, mu_all, mu_stride, n_aces, B, ((B * LABEL_NC + 31) / 32) * 32, LABEL_NC, 1.f,
-                                      nullptr, 0, 0, st, 0), "fc_mu (all ACEs)");
+                                      nullptr, 0, 0, st, grouped ? 2 : 0), "fc_mu (all ACEs)");
+                if (grouped) R.luts_grouped();
+            }
         } else if (fcmu_batched) {
             const int npad_c = ((B * (LABEL_NC + 1) + 31) / 32) * 32;
             for (int pass = 0; pass < 2; ++pass)         // second pass: returns at once unless a projection left the f16 window
@@ -1236,7 +1313,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             if (ahead_full && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd, true);
             // large jobs: only the style LUT builds (small, latency-bound GEMMs) run ahead, in the tails of the conv kernels
             // (exact-f32 path, B = 16 at 512^2: 147.2 -> 148.3 images/s)
-            else if ((fcmu_batched || !use_sh16) && !(dbg & 8192)) R.prepare_all_ahead(lab, cd, false);
+            else if ((fcmu_batched || !use_sh16) && !(dbg & 8192) && !R.luts_ready) R.prepare_all_ahead(lab, cd, false);
         }
 
         const int sw = S / 32;

@@ -33,6 +33,7 @@ struct AceW {
     float *fcmu_w = nullptr, *fcmu_b = nullptr;          // [19][512][512], [19][512]
     float* lut_wpk = nullptr;                   // rows (tap, gamma|beta, c) x K=512
     float* lut_rows = nullptr;                  // same rows, plain [18C][512] (GEMV path for batches <= 3)
+    float* lut_wt = nullptr;                    // the same matrix transposed, [512][18C]: the "image" of the grouped LUT build (exact f32)
     float *spade_wscale = nullptr, *lut_wscale = nullptr;   // f16x3 path: per-row 2^-k of the packed rows (sh16.h)
     float out_scale = 8.f;                      // f16x3 path: first-pass SH16 scale of this ACE's output (SH16_ACT_SCALE; the
                                                 //   shortcut's ace_s carries the 2^D aligning conv_s with conv_1, sean_model.cpp)
@@ -99,6 +100,11 @@ struct SeanModel {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     std::vector<float*> actv_ahead, lut_ahead;
+    // exact-f32 path, more than 64 (sample, label) columns: the style LUTs of all styled ACEs from ONE grouped GEMM launch at the
+    // start of a chunk (conv_pw.h: operands swapped -- the projected codes are the A operand, packed by fc_mu_batched) into lut_ahead
+    void* lut_groups = nullptr;                 // device array of PwGroup
+    int lut_ngroups = 0, lut_group_tiles = 0;   // total pixel tiles (tasks = tiles x row groups of the call's batch)
+    double lut_group_rows = 0.0;                // sum of 18 C over the groups (profiling figures)
     bool ahead_full = false;                   // handle sized for the full run-ahead mode (else: style LUTs only)
     float* splitk_side = nullptr;
     long long ahead_pixels = -1;               // largest B*S*S served in run-ahead mode (-1: default 8 x 512^2)
@@ -116,6 +122,7 @@ struct SeanModel {
         // gather mode (conv_wino.h): one list of boundary quads per sample, tasks of 64 consecutive entries
         unsigned* gq = nullptr; int* gq_n = nullptr; int* qoff = nullptr; int gq_cap = 0;
     };
+    int lut_grouped = 1;                       // option "sean.lut_grouped": exact-f32 path, style LUTs of all styled ACEs from one grouped GEMM launch
     int wino_gather = 1;                       // option "sean.wino_gather": 1 = gather mode of the Winograd ACE kernel (default), 0 = tile mode
     int wino_th = 0;                           // option "sean.wino_th": tile height 16 / 32 of the Winograd ACE kernel (0 = by level)
     // measured per level at B = 16, 512^2 on the benchmark labels (ms for the level's three ACEs, tiles of 32 x 16 / 32 x 32):

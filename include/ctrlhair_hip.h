@@ -76,6 +76,8 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   (The Zencoder follows "sean.f16x3".)
  * "sean.wino" (default 1; "sean.f16x3" = 0 only): the ResBlock 3x3 convs, the SPADE gamma/beta convs and the style convs as
  *   Winograd F(2x2,3x3) on the f32 matrix cores, the learned 1x1 shortcuts on the pointwise kernel of conv_pw.h.
+ * "sean.lut_grouped" (default 1; exact-f32 path, calls with more than 64 (sample, label) columns): the style LUTs of all styled ACEs
+ *   of a chunk come from ONE grouped GEMM launch at its start (csrc/conv_pw.h); 0 = one launch of the generic 1x1 kernel per ACE.
  * "sean.wino_gather" (default 1): the Winograd ACE kernel takes tasks of 64 consecutive boundary quads of a sample and fetches each
  *   quad's own 4 x 4 patch (csrc/conv_wino.h); 0 = tasks per tile of 32 x 16 / 32 x 32 pixels (bit-identical results).
  * "sean.wino_th": tile height 16 / 32 of the tile mode (0 = chosen per resolution level).

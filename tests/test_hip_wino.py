@@ -95,6 +95,32 @@ def test_winograd_equals_direct_ngf64(hip_lib):
     wino.handle.close()
 
 
+@pytest.mark.parametrize('S,mb', [(64, 8), (256, 9)])
+def test_grouped_style_luts_equal_per_ace_launches(hip_lib, S, mb):
+    """Exact-f32 path, more than 64 (sample, label) columns: the style LUTs of all styled ACEs from ONE grouped GEMM launch
+    (conv_pw.h, operands swapped; option sean.lut_grouped, the default) against one launch of the generic 1x1 kernel per ACE
+    (normalization.py:117-153,172-173 conv_gamma / conv_beta of the projected codes).  S = 64 runs in the full run-ahead mode of
+    small jobs, 9 x 256^2 in the large-job mode; ragged batches exercise the partial row groups (N = 95: 3 of 4 row tiles) and the
+    fall-back for N <= 64, and stale projections of a larger earlier call must not leak into a smaller one."""
+    from ctrlhair_amd import procedural as P
+    ngf = 64
+    sd = P.sean_state_dict(0, ngf)
+    grouped, single = _gen(sd, mb, S, 1), _gen(sd, mb, S, 1, {'sean.lut_grouped': 0})
+    codes, noise = P.style_codes(mb, seed=21), P.noise_planes(mb, S, ngf, seed=22)
+    lab = np.stack([P.face_like_labels(S, 60 + b) for b in range(mb)])
+    full = _run(grouped, lab, codes, noise)
+    d = float(np.abs(full - _run(single, lab, codes, noise)).max())
+    print(f'S={S} B={mb}: max |grouped - per-ACE| = {d:.3e}')
+    assert np.isfinite(full).all() and d <= 2e-6
+    for B in (5, 3):
+        a, b = _run(grouped, lab[:B], codes[:B], noise[:B]), _run(single, lab[:B], codes[:B], noise[:B])
+        assert float(np.abs(a - b).max()) <= 2e-6, B
+        assert float(np.abs(a - full[:B]).max()) <= 2e-5, B          # (batch composition changes kernel choices, not the maths)
+    assert np.array_equal(full, _run(grouped, lab, codes, noise)), 'repeated call differs'
+    grouped.handle.close()
+    single.handle.close()
+
+
 def test_option_must_precede_finalize(hip_lib):
     from ctrlhair_amd import procedural as P
     g = _gen(P.sean_state_dict(0, 16), 1, 64, 1)
