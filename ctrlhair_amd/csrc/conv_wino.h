@@ -68,6 +68,8 @@ struct WinoParams {
     const float* res;       // [B][Cout][H >> res_up][W >> res_up] or null
     int res_up, act;
     int reflect;            // 1 = reflection padding (pad 1: row -1 is row 1, row H is row H - 2) instead of zeros
+    int d2s;                // 1 = depth-to-space store: GEMM row 4 c + (2 py + px) holds phase (py, px) of channel c, out is [B][Cout / 4][2 H][2 W]
+                            //   (a stride-2 ConvTranspose2d as four phase convs of the input grid; no residual)
     int pair16;             // set by the launcher for 16 x 16 images (B even): two samples side by side fill a tile of 32 x 16 pixels
     const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image patch elements)
     // set by the launcher
@@ -180,7 +182,7 @@ __device__ __forceinline__ void wino_dma16(unsigned voff, const wino_u32x4& d, u
 template <int N>
 struct WInt { static constexpr int value = N; };
 
-template <int DUMMY>
+template <int D2S>         // D2S = 1: the depth-to-space epilogue (WinoParams::d2s) -- its own instantiation, so that the main one is untouched
 __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) {
     using namespace wino;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -367,7 +369,47 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
         }
         // ---- epilogue of task ct: every load first (rows clamped, so no load sits behind a branch: the per-row load -> use chains
         //      of the first version cost four memory round trips per task), then the output transforms, then the stores -----------
-        {
+        if constexpr (D2S != 0) {
+            // depth-to-space store (WinoParams::d2s): a lane's four rows of a 16-row half are the four phases of ONE channel, so its
+            // quad becomes a 4 x 4 block of the output at twice the resolution: four 16-byte stores per channel
+            int crt, tile;
+            wino_task(p, ct, crt, tile);
+            const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
+            const int y = ty * TH + 2 * wave, x = tx * TW + 2 * n;
+            const int Cr = p.Cout >> 2, W2 = 2 * p.W;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int c = crt * 8 + m * 4 + kk;
+                const float bsv = p.bias ? p.bias[c < Cr ? c : Cr - 1] : 0.f;
+                float yv[4][4];                                      // [phase][quad pixel 2 a + b]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float M[16];
+#pragma unroll
+                    for (int xi = 0; xi < 16; ++xi) M[xi] = acc[xi][m][i];
+                    wino_out_transform(M, yv[i][0], yv[i][1], yv[i][2], yv[i][3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        yv[i][e] += bsv;
+                        if (p.act != ACT_NONE) yv[i][e] = apply_act(yv[i][e], p.act);
+                    }
+                }
+                if (c < Cr) {
+                    float* op = p.out + (((long long)b * Cr + c) * 2 * p.H + 2 * y) * W2 + 2 * x;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int py = 0; py < 2; ++py)       // output row 2 (y + a) + py: columns 2 x .. 2 x + 3 = (b, px) = (0,0) (0,1) (1,0) (1,1)
+                            *reinterpret_cast<float4*>(op + (long long)(2 * a + py) * W2) =
+                                make_float4(yv[2 * py][2 * a], yv[2 * py + 1][2 * a], yv[2 * py][2 * a + 1], yv[2 * py + 1][2 * a + 1]);
+                }
+            }
+#pragma unroll
+            for (int x2 = 0; x2 < 16; ++x2)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            after_epi = true;
+        } else {
             int crt, tile;
             wino_task(p, ct, crt, tile);
             const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty;

@@ -374,11 +374,23 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             z10 = make_conv(B, w, B.vec("Zencoder.model.10.bias", 256), 256, 128, 3, 1, 1);
         }
         plain("Zencoder.model.14", 512, 256, 1, z14);
-        z14_wino = nullptr;
+        z14_wino = z10_wino = nullptr;
         if (!use_sh16 && wino) {   // exact-f32 path: the 256 -> 512 conv (91 % of the Zencoder FLOPs) as Winograd F(2x2,3x3), reflection-padded
             auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
             const float* wp = w14.data();
             z14_wino = B.upload(pack_wino_A(512, 256, [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; }));
+            // ConvTranspose2d(128, 256, k3, s2, p1, op1) (architecture.py:167-170) as four phase convs of the INPUT grid:
+            //   out[2y+py][2x+px] = sum over dy, dx in {0, 1} of x[y+dy][x+dx] * Wt[ci][co][py+1-2dy][px+1-2dx]   (taps outside 0..2 absent)
+            // each a 3x3 kernel with non-zero taps at offsets 0 / +1 only; as Winograd F(2x2,3x3) that is 4 products per output pixel,
+            // against 9 of the plain conv over the zero-inserted view (three quarters of them on inserted zeros).  Row = 4 co + phase.
+            auto wt10 = B.vec("Zencoder.model.10.weight", (size_t)128 * 256 * 9);
+            const float* w10 = wt10.data();
+            z10_wino = B.upload(pack_wino_A(1024, 128, [&](int row, int ci, int t) {
+                const int co = row >> 2, py = (row >> 1) & 1, px = row & 1, dy = t / 3 - 1, dx = t % 3 - 1;
+                if (dy < 0 || dx < 0) return 0.f;
+                const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
+                return (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) ? w10[((size_t)ci * 256 + co) * 9 + ky * 3 + kx] : 0.f;
+            }));
         }
         if (use_sh16) {   // the 256->512 conv is 91 % of the Zencoder FLOPs: run it on the f16x3 path too
             auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
@@ -1455,7 +1467,23 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             ck(instnorm_c4_to_sh16(hs, B, 256, h2 * h2, 1e-5f, ACT_LRELU, h1, st, splitk_ws), "zenc in4");
         } else {
             ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
-            ck(run_conv(z10, h1, hs, B, h4, h4, zins, st), "zenc convT");
+            if (z10_wino && !use_sh16 && wino_supported(h4, h4, 128)) {
+                WinoParams q{};
+                q.in = h1;
+                q.wpk = z10_wino;
+                q.out = hs;
+                q.B = B;
+                q.Cin = 128;
+                q.Cout = 1024;
+                q.H = h4;
+                q.W = h4;
+                q.bias = z10.bias;
+                q.act = ACT_NONE;
+                q.d2s = 1;
+                q.zero = zero_page;
+                ck(conv_wino_plain(q, st), "zenc convT (winograd phase convs)");
+            } else
+                ck(run_conv(z10, h1, hs, B, h4, h4, zins, st), "zenc convT");
             if (use_sh16) ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st, h1, 256), "zenc in4");
         }
         if (use_sh16) {

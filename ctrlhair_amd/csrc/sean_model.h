@@ -78,6 +78,7 @@ struct SeanModel {
     float* z1_w = nullptr;                             // Zencoder stem weights, unpacked (direct VALU conv)
     ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
     float *z14_sh = nullptr, *z10_sh = nullptr;        // z14 / the ConvTranspose packed for the f16x3 kernel
+    float* z10_wino = nullptr;                         // exact-f32 path: the ConvTranspose as four Winograd phase convs of the input grid (rows 4 co + phase)
     float* z14_wino = nullptr;                         // exact-f32 path: z14 as Winograd A images (conv_wino.h, reflection padding)
     float *z14_ws = nullptr, *z10_ws = nullptr;        // their per-row inverse weight scales
     float *z10_d2s = nullptr, *z10_d2s_ws = nullptr;   // the ConvTranspose in its 2x2-tap depth-to-space form (rows = phase * 256 + co)
