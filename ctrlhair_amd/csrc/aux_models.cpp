@@ -333,6 +333,9 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
     up.in_mode = IN_UP2_NEAREST;
     up.partial = splitk_ws;
     up.partial_cap = splitk_cap;
+    up.no_wino = !wino;
+    ConvOpts plain_o;
+    plain_o.no_wino = !wino;
     if (use_sh16) {
         // layer 0 (2x2 -> 4x4, input straight from the Linear) on the exact-f32 kernel; its LayerNorm writes SH16.  Layers 1-6:
         // f16x3 conv over the nearest-x2 view (SH16 in, C4 out) -> LayerNorm + lrelu (C4 in, SH16 out); output conv -> C4 logits.
@@ -389,7 +392,7 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
            "shape dec ln");
         x = y;
     }
-    ck(run_conv(dec_out[w], x, logit, B, size, size, ConvOpts(), st), "shape dec out");
+    ck(run_conv(dec_out[w], x, logit, B, size, size, plain_o, st), "shape dec out");
     return ck.err;
 }
 
@@ -664,7 +667,7 @@ std::string BiSeNetModel::parse(const float* img, uint8_t* labels, float* logits
     for (int bo = 0; bo < Btot; bo += max_batch) {
         const int B = std::min(max_batch, Btot - bo);
         Ck ck;
-        auto SK = [&](ConvOpts o) { o.partial = splitk_ws; o.partial_cap = splitk_cap; return o; };
+        auto SK = [&](ConvOpts o) { o.partial = splitk_ws; o.partial_cap = splitk_cap; o.no_wino = !wino; return o; };
         const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8, h16 = H / 16, w16 = W / 16,
                   h32 = H / 32, w32 = W / 32;
         // resnet.py:71-80

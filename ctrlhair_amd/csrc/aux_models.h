@@ -42,6 +42,7 @@ struct ShapeModel {
     // decoder layers 1..6 on the f16x3 split-operand kernels (conv_sh16.h): packed weights, per-row inverse scales, and the
     // power-of-two SH16 scale of each LayerNorm output (from the bound sqrt(C*HW) * max|gamma| + max|beta|: cannot saturate)
     bool use_sh16 = true;
+    int wino = 1;                   // option "aux.wino": exact-f32 kernels, 3x3 stride-1 convs as Winograd F(2x2,3x3) where the tiles fit (net_common.h run_conv)
     float *dec_sh[2][7] = {}, *dec_ws[2][7] = {};
     float dec_ln_scale[2][7] = {};
     // encoder layers (k4 s2 convs, 128^2 .. 2^2 outputs) in the space-to-depth form of the f16x3 kernels (conv_sh16.h S2D):
@@ -88,6 +89,7 @@ struct BiSeNetModel {
     // f32 activations kept in the C4 layout and split while they are staged (conv_sh16.h, INC4); the stride-2 convs stay on
     // the exact-f32 kernels (C4 in / out).  `amax`: one device slot per activation tensor (sh16.h).
     bool use_sh16 = true;
+    int wino = 1;                   // option "aux.wino" (see ShapeModel)
     unsigned* amax = nullptr;
     float *b0 = nullptr, *b1 = nullptr, *b2 = nullptr, *f8 = nullptr, *f16 = nullptr, *f32 = nullptr, *vec0 = nullptr,
           *vec1 = nullptr, *vec2 = nullptr, *splitk_ws = nullptr;

@@ -338,6 +338,10 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->bisenet.use_sh16 = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "aux.wino") == 0) {        // exact-f32 kernels of the shape VAE / BiSeNet: 3x3 stride-1 convs as Winograd F(2x2,3x3) (default 1)
+        h->shape.wino = h->bisenet.wino = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.ahead") == 0) {      // run-ahead mode up to `value` images of 512x512 per chunk (0 = off)
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.ahead) must precede ch_finalize");
         h->sean.ahead_pixels = (long long)value * 512 * 512;

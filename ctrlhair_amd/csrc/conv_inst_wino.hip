@@ -30,14 +30,21 @@ static hipError_t wino_attr(K kern, int bytes, bool (&done)[64]) {
 
 hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
     if ((!wino_supported(p.H, p.W, p.Cin) && !(wino_supported_pair16(p.B, p.H, p.W, p.Cin) && !p.reflect && !p.res_up)) || !p.zero) return hipErrorInvalidValue;
-    if (p.d2s && (p.Cout % 4 || p.res || p.reflect || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;
+    if (p.d2s && (p.Cout % 4 || p.res || p.reflect || p.in_up || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;
+    if (p.in_up && (p.reflect || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;      // (H, W: the conv's own = 2 x stored size)
     wino_fill_launch(p);
     const int grid = p.ntasks < wino_num_cus() ? p.ntasks : wino_num_cus();
-    static bool d0[64] = {}, d1[64] = {};
+    static bool d0[64] = {}, d1[64] = {}, d2[64] = {};
     if (p.d2s) {
         hipError_t e = wino_attr(wino_plain_kernel<1>, wino::LDS_BYTES, d1);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(wino_plain_kernel<1>, dim3(grid), dim3(512), wino::LDS_BYTES, s, p);
+        return hipGetLastError();
+    }
+    if (p.in_up) {
+        hipError_t e = wino_attr(wino_plain_kernel<2>, wino::LDS_BYTES, d2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino_plain_kernel<2>, dim3(grid), dim3(512), wino::LDS_BYTES, s, p);
         return hipGetLastError();
     }
     hipError_t e = wino_attr(wino_plain_kernel<0>, wino::LDS_BYTES, d0);

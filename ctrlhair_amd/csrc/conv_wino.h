@@ -68,6 +68,8 @@ struct WinoParams {
     const float* res;       // [B][Cout][H >> res_up][W >> res_up] or null
     int res_up, act;
     int reflect;            // 1 = reflection padding (pad 1: row -1 is row 1, row H is row H - 2) instead of zeros
+    int in_up;              // 1 = the input is [B][Cin][H / 2][W / 2], read through its nearest x2 view (generator.py:53-style up-sampling folded
+                            //   into the conv: a per-lane source offset like the padding)
     int d2s;                // 1 = depth-to-space store: GEMM row 4 c + (2 py + px) holds phase (py, px) of channel c, out is [B][Cout / 4][2 H][2 W]
                             //   (a stride-2 ConvTranspose2d as four phase convs of the input grid; no residual)
     int pair16;             // set by the launcher for 16 x 16 images (B even): two samples side by side fill a tile of 32 x 16 pixels
@@ -182,9 +184,13 @@ __device__ __forceinline__ void wino_dma16(unsigned voff, const wino_u32x4& d, u
 template <int N>
 struct WInt { static constexpr int value = N; };
 
-template <int D2S>         // D2S = 1: the depth-to-space epilogue (WinoParams::d2s) -- its own instantiation, so that the main one is untouched
+// MODE bit 0: the depth-to-space epilogue (WinoParams::d2s); bit 1: nearest x2 input view (WinoParams::in_up) -- their own
+// instantiations, so that the generator's main one is untouched
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) {
     using namespace wino;
+    constexpr int D2S = MODE & 1;
+    constexpr bool UP = (MODE & 2) != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
     const int mytasks = (p.ntasks - lb + G - 1) / G;
     const int nk = p.nks;
     const int HW = p.H * p.W;
+    const int Ws = UP ? p.W >> 1 : p.W, HWs = UP ? HW >> 2 : HW;          // the input planes as stored
     constexpr unsigned SB = SDW * 4, RING = NST * SB;
     const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;          // LDS byte address of the ring
 
@@ -225,10 +232,10 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
                 x = x < 0 ? -x : (x >= p.W ? 2 * p.W - 2 - x : x);
             }
             const bool ok = k4 < 4 && rem < PROWS * PWP && (p.pair16 || px < TW + 2) && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            voff[i] = ok ? (unsigned)((sub * p.Cin + k4) * HW + y * p.W + x) * 4u : 0x80000000u;
+            voff[i] = ok ? (unsigned)((sub * p.Cin + k4) * HWs + (UP ? (y >> 1) * Ws + (x >> 1) : y * p.W + x)) * 4u : 0x80000000u;
         }
-        d_in = p.pair16 ? wino_rsrc(p.in + (long long)ib * 2 * p.Cin * HW, 2u * (unsigned)p.Cin * HW * 4u)
-                        : wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
+        d_in = p.pair16 ? wino_rsrc(p.in + (long long)ib * 2 * p.Cin * HWs, 2u * (unsigned)p.Cin * HWs * 4u)
+                        : wino_rsrc(p.in + (long long)ib * p.Cin * HWs, (unsigned)p.Cin * HWs * 4u);
         d_a = wino_rsrc(p.wpk + (long long)irt * p.nks * 2048, (unsigned)p.nks * 8192u);
         so_in = 0;
         so_a = 0;
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
         }
         wino_dma16(va, d_a, so_a, islot + PDW * 4u + (unsigned)wave * 1024u);
         islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
-        so_in += 16u * (unsigned)HW;
+        so_in += 16u * (unsigned)HWs;
         so_a += 8192u;
         if (++is == nk) {
             if (it + G < p.ntasks) {
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
                 issue_task();
             } else {                       // past the end: keep re-issuing the last k-step (never read; keeps the vmcnt counting uniform)
                 is = nk - 1;
-                so_in -= 16u * (unsigned)HW;
+                so_in -= 16u * (unsigned)HWs;
                 so_a -= 8192u;
             }
         }

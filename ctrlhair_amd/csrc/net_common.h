@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "conv_mfma.h"
+#include "conv_wino.h"
 
 namespace chk {
 
@@ -175,6 +176,8 @@ struct ConvLayer {
     float* sh_wpk = nullptr;       // f16x3 packing (make_conv_sh16 / make_conv_s2d): split-operand A fragments + per-row inverse scales
     float* sh_wscale = nullptr;
     int s2d_cr = 0, s2d_phase0 = 0; // make_conv_s2d: real (padded) input channels and first phase of the space-to-depth form
+    float* wino = nullptr;          // 3x3 stride-1 pad-1 layers of the exact-f32 path: Winograd F(2x2,3x3) A images (conv_wino.h) ...
+    float* zero = nullptr;          // ... and a few zero words (source of out-of-image patch elements)
 };
 
 // w: [Cout][Cin][KS][KS] (already folded: BN / spectral norm / flips), bias may be empty
@@ -192,6 +195,11 @@ inline ConvLayer make_conv(Builder& B, const std::vector<float>& w, const std::v
         return wp[((size_t)row * cin + ci) * ks * ks + t];
     }));
     if (!bias.empty()) L.bias = B.upload(bias);
+    if (ks == 3 && stride == 1 && pad == 1 && cin % 8 == 0 && cout >= 16) {
+        // the same conv as Winograd F(2x2,3x3) on the f32 matrix cores (run_conv takes it where the shape fits the kernel's tiles)
+        L.wino = B.upload(pack_wino_A(cout, cin, [&](int row, int ci, int t) { return wp[((size_t)row * cin + ci) * 9 + t]; }));
+        L.zero = B.upload(std::vector<float>(64, 0.f));
+    }
     return L;
 }
 
@@ -260,6 +268,7 @@ struct ConvOpts {
     int res_after_act = 0;
     float* partial = nullptr;      // split-K scratch (optional): enables split-K for few-tile / long-K layers
     long long partial_cap = 0;
+    int no_wino = 0;               // 1 = keep a 3x3 stride-1 layer on the direct kernel (A/B tests)
 };
 
 inline int conv_out_size(const ConvLayer& L, int in, int in_mode) {
@@ -270,6 +279,32 @@ inline int conv_out_size(const ConvLayer& L, int in, int in_mode) {
 // in: [B][Cin][Hin][Win] -> out: [B][Cout][Ho][Wo]
 inline hipError_t run_conv(const ConvLayer& L, const float* in, float* out, int B, int Hin, int Win,
                            const ConvOpts& o, hipStream_t st) {
+    {   // Winograd F(2x2,3x3) route (exact f32: the same sums in another association, conv_wino.h): 3x3 stride-1 pad-1 layers whose
+        // output fits the kernel's tiles of 32 x 16 pixels (16 x 16 images: pairs of samples), direct or nearest-x2 input view
+        const int H = conv_out_size(L, Hin, o.in_mode), W = conv_out_size(L, Win, o.in_mode);
+        const bool up = o.in_mode == IN_UP2_NEAREST, refl = o.pad_mode == PAD_REFLECT;
+        const bool tiles = wino_supported(H, W, L.Cin) || (!up && !refl && !o.res_up && wino_supported_pair16(B, H, W, L.Cin));
+        if (L.wino && L.zero && !o.no_wino && L.KS == 3 && L.stride == 1 && L.pad == 1 && (o.in_mode == IN_DIRECT || up) && !(up && refl) &&
+            !o.res_after_act && tiles) {
+            WinoParams q{};
+            q.in = in;
+            q.wpk = L.wino;
+            q.out = out;
+            q.B = B;
+            q.Cin = L.Cin;
+            q.Cout = L.Cout;
+            q.H = H;
+            q.W = W;
+            q.bias = L.bias;
+            q.res = o.res;
+            q.res_up = o.res_up;
+            q.act = o.act;
+            q.reflect = refl ? 1 : 0;
+            q.in_up = up ? 1 : 0;
+            q.zero = L.zero;
+            return conv_wino_plain(q, st);
+        }
+    }
     ConvParams p{};
     p.in = in;
     p.wpk = L.wpk;

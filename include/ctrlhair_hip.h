@@ -74,6 +74,8 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  * "bisenet.f16x3" (default 1): BiSeNet's convs on the f16x3 kernels; its f32 activations stay in the C4 layout and are split
  *   into f16 pairs while staged, with the scale derived from the maximum the producing kernel recorded; 0 = exact-f32 kernels.
  *   (The Zencoder follows "sean.f16x3".)
+ * "aux.wino" (default 1): the exact-f32 kernels of the shape VAE and BiSeNet ("shape.f16x3" / "bisenet.f16x3" = 0, and the layers those
+ *   options leave on them) run their 3x3 stride-1 convs as Winograd F(2x2,3x3) wherever the output fits the kernel's tiles; 0 = direct.
  * "sean.wino" (default 1; "sean.f16x3" = 0 only): the ResBlock 3x3 convs, the SPADE gamma/beta convs and the style convs as
  *   Winograd F(2x2,3x3) on the f32 matrix cores, the learned 1x1 shortcuts on the pointwise kernel of conv_pw.h.
  * "sean.lut_grouped" (default 1; exact-f32 path, calls with more than 64 (sample, label) columns): the style LUTs of all styled ACEs

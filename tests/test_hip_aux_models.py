@@ -158,8 +158,7 @@ def test_shape_decoder_exact_f32_path_matches_golden_too(hip_lib):
     e = env()
     z = np.load(os.path.join(GOLDEN, 'shape_054.npz'))
     h = lib.Handle(0)
-    h.set_option('shape.f16x3', 0)
-    sg = models.ShapeGenerator(h, e['dev']).load_state_dict(P.shape_state_dict(0), max_batch=2)
+    sg = models.ShapeGenerator(h, e['dev']).load_state_dict(P.shape_state_dict(0), max_batch=2, f16x3=False)     # (sets shape.f16x3 = 0)
     ghc, gfc = torch.from_numpy(z['hair_code']).to(e['dev']), torch.from_numpy(z['face_code']).to(e['dev'])
     fl = sg.forward_face_decoder(gfc)
     hl = sg.forward_hair_decoder(ghc, gfc)
@@ -172,6 +171,35 @@ def test_shape_decoder_exact_f32_path_matches_golden_too(hip_lib):
     print('shape decoder f16x3 vs exact f32: max |delta| of the logits', d, ' |logit| max', float(fl.abs().max()))
     assert d <= 2e-4
     h.close()
+
+
+def test_exact_f32_aux_convs_winograd_equals_direct(hip_lib):
+    """Option aux.wino (default 1): the exact-f32 kernels of the shape decoder (shape_branch/model.py:138-143: nearest x2 up-sampling
+    folded into each 3x3 conv) and of BiSeNet (face_parsing/resnet.py:36-48 BasicBlocks with residual + ReLU, model.py ARM / head /
+    output convs) run their 3x3 stride-1 convs as Winograd F(2x2,3x3) where the output fits the tiles (levels of 16 pixels: pairs of
+    samples); against the direct evaluation of the same library (aux.wino = 0), far inside the golden bar."""
+    from ctrlhair_amd import lib, models
+    from ctrlhair_amd import procedural as P
+    e = env()
+    z = np.load(os.path.join(GOLDEN, 'shape_054.npz'))
+    ghc, gfc = torch.from_numpy(z['hair_code']).to(e['dev']), torch.from_numpy(z['face_code']).to(e['dev'])
+    img = torch.from_numpy(P.synthetic_images(2, 512, seed=77)).to(e['dev'])
+    outs = {}
+    for wino in (1, 0):
+        h = lib.Handle(0)
+        h.set_option('aux.wino', wino)
+        sg = models.ShapeGenerator(h, e['dev']).load_state_dict(P.shape_state_dict(0), max_batch=2, f16x3=False)
+        fp = models.FaceParsing(h, e['dev']).load_state_dict(P.bisenet_state_dict(0), max_batch=2, max_size=512, f16x3=False)
+        lab, lg = fp.parse_tensor(img, want_logits=True)
+        lab1, lg1 = fp.parse_tensor(img[:1], want_logits=True)          # one sample: the 16-pixel level cannot pair samples
+        outs[wino] = [sg.forward_face_decoder(gfc).cpu(), sg.forward_hair_decoder(ghc, gfc).cpu(), lg.cpu(), lg1.cpu()]
+        torch.cuda.synchronize()
+        h.close()
+    for a, b, what in zip(outs[1], outs[0], ('face decoder', 'hair decoder', 'BiSeNet logits', 'BiSeNet logits, one sample')):
+        d, m = float((a - b).abs().max()), float(b.abs().max())
+        print(f'{what}: max |winograd - direct| = {d:.3e}  (max |value| {m:.3g})')
+        assert d <= 1e-4 * max(1.0, m), what
+    assert float((outs[1][2][:1] - outs[1][3]).abs().max()) <= 1e-4 * max(1.0, float(outs[1][3].abs().max()))
 
 
 def test_bisenet_non_square_and_exact_f32_option(hip_lib):
