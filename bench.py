@@ -328,8 +328,9 @@ def roofline_block(path, prof, value, B, sustained):
         'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE: the guide\'s gfx950 correction, an upper bound)',
         'traffic_uncorrected': traffic_raw,
         'algorithmic_bytes_per_launch': round(alg_bytes),
-        'algorithmic_bytes_note': 'sparse ACE launches: hidden activations + x + output of the BOUNDARY pixels only (the minimum); the kernel '
-                                  'stages whole tile patches, so its reads are those of every tile that holds a boundary pixel',
+        'algorithmic_bytes_note': 'sparse ACE launches: hidden activations + x + output of the BOUNDARY pixels only (the minimum); the exact-f32 '
+                                  'gather kernel fetches the 4 x 4 patch of every boundary quad once per pair of row tiles (overlapping patches, '
+                                  'mostly L2 hits), the f16x3 kernel stages the patch of every tile that holds a boundary pixel',
         'traffic_ratio': round(traffic / alg_bytes, 3) if (traffic and alg_bytes > 0) else None,
         'traffic_ratio_uncorrected': round(traffic_raw / alg_bytes, 3) if (traffic_raw and alg_bytes > 0) else None,
         'traffic_detail': detail, 'traffic_note': note,

@@ -16,7 +16,7 @@ for P in f16x3 f32; do
   if [ $P = f16x3 ]; then K='conv_sh16_ws_kernel<3, 32, 16, 1, 1, 3|conv_sh16_kernel<3, 16, 16, 2, 1, 3|conv_sh16_kernel<3, 32, 16, 1, 1, 3'
   else K='wino_ace_gather_kernel|wino_ace_kernel|conv_ace_sparse_kernel|conv_mfma_kernel<3, 1, 2, 32, 8, 1, 16, 1,|conv_mfma_kernel<3, 1, 2, 16, 16, 1, 16, 1,'; fi
   python $R/tools/make_traffic.py $D $P "$K" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/${TAG}_${P}_pmc.md" >> $OUT/${P}_run.log 2>&1
-  tail -1 $D/trace.log > $OUT/${TAG}_${P}_bench_line.json
+  grep '^{' $D/trace.log | tail -1 > $OUT/${TAG}_${P}_bench_line.json      # (rocprofv3 logs after the JSON line)
   cp $D/peak.log $OUT/${TAG}_${P}_mfma_peak.log 2>/dev/null
   rm -rf $D
 done
@@ -25,7 +25,7 @@ cd /tmp && export TMPDIR=/tmp
 D=$R/gpurun_out/prof_${TAG}_pipe
 rocprofv3 --kernel-trace --stats -d $D/trace -o t -- python $R/bench.py --workload pipeline --path f16x3 --only-headline --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pipe_run.log 2>&1
 python $R/tools/rocprof_summary.py $D/trace/t_results.db > $OUT/${TAG}_pipeline_kernel_trace.md 2>> $OUT/pipe_run.log
-tail -1 $OUT/pipe_run.log > $OUT/${TAG}_pipeline_bench_line.json
+grep '^{' $OUT/pipe_run.log | tail -1 > $OUT/${TAG}_pipeline_bench_line.json
 rm -rf $D
 ls -la $OUT
 bash $R/tools/stage_trace.sh ${TAG} > $OUT/stage_run.log 2>&1
