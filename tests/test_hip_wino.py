@@ -121,6 +121,26 @@ def test_grouped_style_luts_equal_per_ace_launches(hip_lib, S, mb):
     single.handle.close()
 
 
+def test_size_with_mixed_levels_against_the_oracle(hip_lib):
+    """S = 96 at ngf = 64: resolution levels of 3 ... 96 pixels, of which only the last fits the Winograd tiles (the others run on the
+    direct kernels, the 48-pixel level with the SPADE-interior reduction), five samples = 95 (sample, label) columns through the
+    grouped LUT build (three of four row tiles in its one row group) -- against the oracle."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    ngf, S, B = 64, 96, 5
+    sd = P.sean_state_dict(0, ngf)
+    g = _gen(sd, B, S, 1)
+    codes, noise = P.style_codes(B, seed=31), P.noise_planes(B, S, ngf, seed=32)
+    lab = np.stack([P.face_like_labels(S, 90 + b) for b in range(B)])
+    out = _run(g, lab, codes, noise)
+    assert np.isfinite(out).all()
+    ref = O.generator_forward(O.to_torch(sd), lab[3:5], codes[3:5], noise[3:5], ngf).numpy()
+    d = float(np.abs(out[3:5] - ref).max())
+    print(f'S=96 ngf=64: max |hip - oracle| = {d:.3e}')
+    assert d <= 1e-3
+    g.handle.close()
+
+
 def test_option_must_precede_finalize(hip_lib):
     from ctrlhair_amd import procedural as P
     g = _gen(P.sean_state_dict(0, 16), 1, 64, 1)
