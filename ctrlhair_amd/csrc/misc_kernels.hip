@@ -571,6 +571,57 @@ __global__ __launch_bounds__(256) void region_mean_kernel(const float* __restric
         if (threadIdx.x == 0) out[((long long)b * 19 + j) * F + f] = cv > 0.f ? sv / cv : 0.f;
     }
 }
+// Planar input, run-length form (exact-f32 path): a thread's pixels i, i + 256, ... lie in one image column when w divides 256, where
+// labels change rarely: it keeps a running (label, sum, count) and adds it to ITS OWN per-label LDS slot only when the label changes
+// (the 19-way compare-and-add per element of the kernel above made it VALU-bound: 0.66 ms for the 1.07 GB feature map of 8 images at
+// 512^2).  Deterministic: private slots, then the same block-wide tree per label.
+__global__ __launch_bounds__(256) void region_mean_runs_kernel(const float* __restrict__ codes, const uint8_t* __restrict__ lab,
+                                                               float* __restrict__ out, int F, int h, int w, int S) {
+    __shared__ float acc[19][256], cnt[19][256];
+    __shared__ float red[4];
+    const int f = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int fy = S / h, fx = S / w;
+    const float* p = codes + ((long long)b * F + f) * h * w;
+    const uint8_t* lb = lab + (long long)b * S * S;
+#pragma unroll
+    for (int j = 0; j < 19; ++j) { acc[j][t] = 0.f; cnt[j][t] = 0.f; }
+    int cur = -1;
+    float sum = 0.f, n = 0.f;
+    const int hw = h * w;
+    for (int i0 = t; i0 < hw; i0 += 8 * 256) {            // eight loads in flight per thread, consumed in pixel order
+        float v[8];
+        int l[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 256;
+            l[k] = -1;
+            v[k] = 0.f;
+            if (i < hw) {
+                const int y = i / w, x = i - y * w;
+                l[k] = lb[(long long)(y * fy) * S + x * fx];
+                v[k] = p[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (l[k] < 0) continue;                        // past the end
+            if (l[k] != cur) {
+                if (cur >= 0 && cur < 19) { acc[cur][t] += sum; cnt[cur][t] += n; }
+                cur = l[k];
+                sum = 0.f;
+                n = 0.f;
+            }
+            sum += v[k];
+            n += 1.f;
+        }
+    }
+    if (cur >= 0 && cur < 19) { acc[cur][t] += sum; cnt[cur][t] += n; }
+    for (int j = 0; j < 19; ++j) {
+        const float sv = block_sum(acc[j][t], red);
+        const float cv = block_sum(cnt[j][t], red);
+        if (t == 0) out[((long long)b * 19 + j) * F + f] = cv > 0.f ? sv / cv : 0.f;
+    }
+}
 // C4 input [B][F/4][h*w][4]: one block per (4-channel group, sample), float4 loads.  A thread walks down a column-ish
 // sequence of pixels (stride 256), where labels change rarely: it keeps a running (label, sum4, count) and flushes it to the
 // per-label LDS accumulators only when the label changes.  (LDS float atomics: the summation order, hence the last bits of a
@@ -622,6 +673,10 @@ hipError_t region_mean(const float* codes, const uint8_t* lab, float* out, int B
     if (c4 && (F & 3) == 0) {
         hipLaunchKernelGGL(region_mean_c4_kernel, dim3(F >> 2, B), dim3(256), 0, s, reinterpret_cast<const float4*>(codes), lab,
                            out, F, h, w, S);
+        return hipGetLastError();
+    }
+    if (!c4 && h * w >= 4096) {
+        hipLaunchKernelGGL(region_mean_runs_kernel, dim3(F, B), dim3(256), 0, s, codes, lab, out, F, h, w, S);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(region_mean_kernel, dim3(F, B), dim3(256), 0, s, codes, lab, out, F, h, w, S, c4);
