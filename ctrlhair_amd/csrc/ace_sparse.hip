@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
 }
 
 
+
 hipError_t ace_interior_f32(const AceInteriorParams& q, hipStream_t s) {
     if (q.act > ACT_RELU) return hipErrorInvalidValue;
     if (q.W % 4 != 0) return hipErrorInvalidValue;

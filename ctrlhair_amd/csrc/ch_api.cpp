@@ -357,6 +357,10 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.lut_grouped = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.hidden_wq") == 0) {    // Winograd ACE path: 1 = hidden activations + one-hot planes from spade_hidden_wq (default)
+        h->sean.hidden_wq = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.wino_gather") == 0) {    // 1 = gather mode of the Winograd ACE kernel (default), 0 = tile mode
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino_gather) must precede ch_finalize");
         h->sean.wino_gather = value != 0;

@@ -128,6 +128,212 @@ hipError_t label_onehot_planes(const uint8_t* lab, float* out, int B, int H, int
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// SPADE hidden activations for the Winograd ACE kernels (conv_wino.h), written ONLY where a boundary quad's 4 x 4 patch reads
+// them (normalization.py:249-251 mlp_shared + relu), with the one-hot label planes of the styled ACEs behind
+// the 128 hidden channels in the same pass.
+//   * Persistent blocks of 1024 threads, one per CU: the WHOLE label table (171 rows x 128 channels, padded pitch, + a zero row)
+//     and the 19 pre-summed rows A[j] = relu(bias + sum_t T[j][t]) sit in LDS for the block's lifetime (101 KB).
+//   * Task = 1024 pixels as TR rows x TC columns with TC = min(W, 512): ROW-SHAPED, and block i takes tasks i, i + G, ... -- the
+//     blocks running at the same time write neighbouring runs of the same rows of a plane.  (Tiles of 32 x 32 were measured first,
+//     tools/hidden_bench.hip: 0.8 TB/s -- 256 CUs each scattering 128-byte pieces over a whole 1 MB plane, 148 planes at a time.)
+//   * A pixel is WANTED when one of the (at most four) quads whose patch holds it is a boundary quad (some pixel of the quad has
+//     u5 == 255; u5 == nullptr: every quad).  Wanted pixels are compacted in raster order into ONE list; work items = 64 list
+//     entries x 16 channels, taken round-robin by the 16 waves: full waves, stores in runs of consecutive pixels.  A pixel whose
+//     3 x 3 label neighbourhood is uniform (inside the image, label < 19) could read ONE pre-summed row instead of nine table rows
+//     -- the same adds in the same order, bit-identical -- and does so when all 64 pixels of its item are of that kind.
+// Pixels outside every boundary quad's patch keep whatever the buffer held: nothing reads them.
+namespace hid {
+constexpr int K = 128, RS = K + 4, ZROW = 19 * 9;
+constexpr int T_FLOATS = (ZROW + 1) * RS, A_FLOATS = 19 * RS;
+constexpr int LP_BYTES = 2304, QF_BYTES = 1024;      // label patch (TR + 2) x (TC + 4) <= 4 x 516 / 34 x 36; quad flags (TR/2 + 2) x (TC/2 + 2)
+constexpr int LDS_BYTES = (T_FLOATS + A_FLOATS + K) * 4 + LP_BYTES + QF_BYTES + 1088 * 2 + 16 * 4 + 64;
+}  // namespace hid
+
+#ifndef HID_DBG
+#define HID_DBG 0      // tools/hidden_bench.hip: 1 = no stores, 2 = no work items (timing ablations)
+#endif
+__global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __restrict__ lab, const uint8_t* __restrict__ u5,
+                                                               const float* __restrict__ table, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int B, int H, int W, int kout, int onehot,
+                                                               int tcs) {      // tcs = log2(TC)
+    using namespace hid;
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    float* T = hsm;
+    float* A = T + T_FLOATS;
+    float* bs = A + A_FLOATS;
+    uint8_t* Lp = reinterpret_cast<uint8_t*>(bs + K);
+    uint8_t* qf = Lp + LP_BYTES;
+    uint16_t* lst = reinterpret_cast<uint16_t*>(qf + QF_BYTES);      // wanted pixels of the task, raster order: tid | uniform << 15
+    int* wc = reinterpret_cast<int*>(lst + 1088);                    // per-wave counts
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < (ZROW + 1) * K; i += 1024) {
+        const int jt = i / K, kk = i % K;
+        T[jt * RS + kk] = jt < ZROW ? table[(long long)jt * K + kk] : 0.f;
+    }
+    if (tid < K) bs[tid] = bias[tid];
+    __syncthreads();
+    for (int i = tid; i < 19 * K; i += 1024) {
+        const int j = i / K, k = i % K;
+        float a = bs[k];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a += T[(j * 9 + t) * RS + k];    // bias first, then the taps in order: as the per-pixel sum below
+        A[j * RS + k] = a > 0.f ? a : 0.f;
+    }
+    const int TC = 1 << tcs, TR = 1024 >> tcs;
+    const int LPW = TC + 4, LPH = TR + 2, QW = (TC >> 1) + 2, QH = (TR >> 1) + 2;
+    const int txn = W >> tcs, tyn = H / TR, ntasks = B * txn * tyn;
+    const long long HW = (long long)H * W;
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int b = task / (txn * tyn), tr = task - b * (txn * tyn);
+        const int y0 = (tr / txn) * TR, x0 = (tr % txn) << tcs;
+        const uint8_t* lb = lab + (long long)b * HW;
+        __syncthreads();                                             // (the previous task's lists / the A rows above)
+        for (int i = tid; i < LPH * (TC + 2); i += 1024) {
+            const int py = i / (TC + 2), px = i - py * (TC + 2);
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            Lp[py * LPW + px] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? lb[(long long)y * W + x] : (uint8_t)255;
+        }
+        for (int q = tid; q < QH * QW; q += 1024) {                  // boundary flags of the quads of the task + a ring of one quad
+            const int qy = q / QW, qx = q - qy * QW;
+            const int y = y0 + 2 * (qy - 1), x = x0 + 2 * (qx - 1);
+            uint8_t f = 0;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {      // (H, W even: a quad is inside or outside as a whole)
+                if (u5) {
+                    const uint8_t* up = u5 + (long long)b * HW + (long long)y * W + x;
+                    const unsigned short r0 = *reinterpret_cast<const unsigned short*>(up), r1 = *reinterpret_cast<const unsigned short*>(up + W);
+                    f = ((r0 & 0xFF) == 255 || (r0 >> 8) == 255 || (r1 & 0xFF) == 255 || (r1 >> 8) == 255) ? 1 : 0;
+                } else {
+                    f = 1;
+                }
+            }
+            qf[q] = f;
+        }
+        __syncthreads();
+        const int ty = tid >> tcs, tx = tid & (TC - 1);
+        const int r0 = (ty + 1) >> 1, c0 = (tx + 1) >> 1;            // pixel (ty, tx) lies in the patches of quads r0 - 1 .. r0, c0 - 1 .. c0 (+ 1: ring)
+        bool wanted = (qf[r0 * QW + c0] | qf[r0 * QW + c0 + 1] | qf[(r0 + 1) * QW + c0] | qf[(r0 + 1) * QW + c0 + 1]) != 0;
+        const uint8_t* lc = Lp + ty * LPW + tx;                      // 3 x 3 neighbourhood: rows ty .. ty + 2, columns tx .. tx + 2 of the patch
+        const uint8_t cl = lc[LPW + 1];
+        bool uni = cl < 19;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) uni = uni && lc[dy * LPW + dx] == cl;
+        // Written at the granularity of aligned groups of 16 pixels (64 bytes, one full write request): 32-byte pieces -- the 8-pixel
+        // bands along vertical region edges -- cost more than they save (tools/hidden_bench.hip, 512^2 on the benchmark labels:
+        // 40 % of the bytes in 1039 us at pixel granularity against 471 us for ALL of them).  The extra pixels get their true values.
+        const unsigned long long m1 = __ballot(wanted);
+        wanted = ((m1 >> (lane & 48)) & 0xFFFFull) != 0ull;          // (TC >= 32: the 16 lanes of a group are 16 consecutive pixels of a row)
+        const unsigned long long mW = __ballot(wanted);
+        if (lane == 0) wc[wave] = __popcll(mW);
+        __syncthreads();
+        int base = 0, n = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) base += wc[w];
+            n += wc[w];
+        }
+        if (wanted) lst[base + __popcll(mW & ((1ull << lane) - 1ull))] = (uint16_t)(tid | (uni ? 0x8000 : 0));
+        __syncthreads();
+        // Work items: 64 consecutive list entries (raster order: a wave's stores are runs of consecutive pixels, as long as the
+        // wanted band is wide) x half a slab of 16 channels.  The channel slabs are the OUTER loop: at any time the 16 waves of the
+        // block -- and the blocks running in step with it -- write the same 32 planes.  (Measured first, tools/hidden_bench.hip: one
+        // list per kind of pixel.  The non-uniform pixels are 2-pixel strips at the region edges; listed apart they become 8-byte
+        // stores and cut the uniform runs into unaligned pieces -- 8 write requests per wave store instead of 4, 0.8 TB/s.)
+        // A chunk whose pixels all have a uniform neighbourhood reads ONE pre-summed row per pixel; any other chunk the nine rows.
+        const int nch = (n + 63) >> 6;
+        for (int pass = 0; pass < ((HID_DBG & 2) ? 0 : (onehot ? 5 : 4)); ++pass) {
+            for (int it = wave; it < 2 * nch; it += 16) {
+                const int c = it >> 1, half = it & 1;
+                const int e = c * 64 + lane;
+                const bool valid = (HID_DBG & 1) ? (e < -1) : e < n;
+                const int ent = valid ? lst[e] : 0x8000;
+                const int pid = ent & 1023;
+                const int py = pid >> tcs, px = pid & (TC - 1);
+                const uint8_t* ll = Lp + py * LPW + px;
+                const int jc = ll[LPW + 1];
+                const long long pofs = (long long)(y0 + py) * W + x0 + px;
+                if (pass == 4) {                                     // one-hot planes K + 10 half .. K + 10 half + 9 (plane K + 19 stays zero)
+                    float* oh = out + ((long long)b * kout + K + half * 10) * HW + pofs;
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) oh[q * HW] = (half * 10 + q == jc && jc < 19) ? 1.f : 0.f;
+                    }
+                    continue;
+                }
+                const int k0 = pass * 32 + half * 16;
+                float* op = out + ((long long)b * kout + k0) * HW + pofs;
+                if (!__all((ent & 0x8000) != 0)) {
+                    int jt[9];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int j = ll[(t / 3) * LPW + t % 3];     // 255 outside the image; labels >= 19: all-zero one-hot
+                        jt[t] = (j < 19 ? j * 9 + t : ZROW) * RS + k0;
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float4 a = *reinterpret_cast<const float4*>(bs + k0 + gq * 4);
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            const float4 r = *reinterpret_cast<const float4*>(T + jt[t] + gq * 4);
+                            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+                        }
+                        a.x = a.x > 0.f ? a.x : 0.f; a.y = a.y > 0.f ? a.y : 0.f;
+                        a.z = a.z > 0.f ? a.z : 0.f; a.w = a.w > 0.f ? a.w : 0.f;
+                        if (valid) {                                 // (one running pointer: hoisted plane addresses cost two registers each)
+                            op[0] = a.x; op[HW] = a.y; op[2 * HW] = a.z; op[3 * HW] = a.w;
+                        }
+                        op += 4 * HW;
+                        __builtin_amdgcn_sched_barrier(0);           // one group of table reads in flight, not all of them (128 registers)
+                    }
+                } else {
+                    const float* ar = A + (jc < 19 ? jc : 0) * RS + k0;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 a = *reinterpret_cast<const float4*>(ar + gq * 4);
+                        if (valid) {
+                            op[0] = a.x; op[HW] = a.y; op[2 * HW] = a.z; op[3 * HW] = a.w;
+                        }
+                        op += 4 * HW;
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool spade_hidden_wq_supported(int H, int W) {
+    if (H % 32 || W % 32 || H < 32 || W < 32 || (W & (W - 1))) return false;
+    const int TC = W < 512 ? W : 512, TR = 1024 / TC;
+    return H % TR == 0;
+}
+
+hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* table, const float* bias, float* out, int B, int H, int W,
+                           int kout, int onehot, hipStream_t s) {
+    if (!spade_hidden_wq_supported(H, W) || kout < hid::K + (onehot ? 20 : 0)) return hipErrorInvalidValue;
+    static bool done[64] = {};
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spade_hidden_wq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           hid::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+        done[dev] = true;
+    }
+    const int TC = W < 512 ? W : 512;
+    int tcs = 0;
+    while ((1 << tcs) < TC) ++tcs;
+    const int ntasks = B * (H * W / 1024);
+    const int grid = ntasks < cus[dev] ? ntasks : cus[dev];
+    hipLaunchKernelGGL(spade_hidden_wq_kernel, dim3(grid), dim3(1024), hid::LDS_BYTES, s, lab, u5, table, bias, out, B, H, W, kout, onehot, tcs);
+    return hipGetLastError();
+}
+
 // Same computation, output in the SH16 layout of conv_sh16.h: [B][K/8][2][H*W][8] _Float16 (hi plane, lo plane).
 // One thread = one pixel x 32 channels = 4 groups; every store is one aligned 16-byte unit, lanes on consecutive
 // pixels -> 1 KiB contiguous per wave store.

@@ -820,9 +820,26 @@ struct Runner {
         int lut_rs = 1, lut_ns = 0, lut_bs = LABEL_NC;
     };
     // what: bit 0 = style LUT, bit 1 = SPADE hidden activations
-    bool use_wino_ace(const AceW& a, int r) const { return m.wino && !m.use_sh16 && a.spade_wino && r >= 32 && r % 32 == 0; }
+    // ONE predicate decides both the layout of the hidden activations (148 planes per sample with the one-hot planes behind the
+    // hidden channels) and the kernel that reads them: the level's quad lists and the task list of this row-tile count must have
+    // been sized at build time (they exist where (max_size >> k) % 32 == 0; a smaller S can reach a 32-grid level that max_size
+    // does not have, e.g. max_size = 96, S = 64 -- ADVICE r04), else the ACE takes the direct kernels and their [B][128][H][W] layout
+    bool use_wino_ace(const AceW& a, int r) const {
+        if (!(m.wino && !m.use_sh16 && a.spade_wino && r >= 32 && r % 32 == 0)) return false;
+        int k = 0;
+        while ((1 << k) < a.res_div) ++k;
+        const SeanModel::WinoLevel& L = m.wq_level[k];
+        if (!L.qlist) return false;
+        const int nrt = (a.C + 15) / 16;
+        for (const auto& w : L.works)
+            if (w.nrt == nrt) return true;
+        return false;
+    }
+    // u5 (Winograd ACE path): the level's interior map when the SPADE-interior reduction serves it -- the label-table kernel then
+    // writes the hidden activations only where a boundary quad's patch reads them (nullptr: everywhere)
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
-                        float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr) {
+                        float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr,
+                        const uint8_t* u5 = nullptr) {
         const int r = S / a.res_div;
         const uint8_t* lab = labels_at(labfull, a.res_div);
         AcePrep q;
@@ -899,7 +916,12 @@ struct Runner {
         if (m.use_sh16)
             check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2, need, tile_cnt,
                                       (m.dbg & 33554432) ? 1 : 0), "mlp_shared");
-        else if (use_wino_ace(a, r) && a.styled) {
+        else if (use_wino_ace(a, r) && m.hidden_wq && r >= 128 && spade_hidden_wq_supported(r, r)) {
+            // hidden activations (+ the one-hot planes of a styled ACE) in one persistent pass, whole 64-byte groups of pixels that a
+            // boundary quad's patch touches only (sean_kernels.hip; below 128 pixels its 88 KB table prologue costs more than it saves)
+            check(spade_hidden_wq(lab, u5, a.actv_table, a.actv_bias, actv_buf, B, r, r, a.styled ? HID + 20 : HID, a.styled ? 1 : 0, s),
+                  "mlp_shared (boundary-quad patches)");
+        } else if (use_wino_ace(a, r) && a.styled) {
             // Winograd ACE path: the one-hot label planes behind the hidden channels feed the style k-steps (conv_wino.h)
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, nullptr, HID + 20), "mlp_shared");
             check(label_onehot_planes(lab, actv_buf, B, r, r, HID + 20, HID, s), "one-hot planes");
@@ -996,20 +1018,21 @@ struct Runner {
         if (compact) need = SL->need;
         const int* tile_cnt = (SL && m.use_sh16 && !compact) ? SL->cnt : nullptr;
         AcePrep q;
+        const uint8_t* u5 = (wino_ace && wp.L && wp.S) ? wp.S->u5 : nullptr;
         if (ahead) {
             q = prepared[a.index];
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else if (luts_ready && a.styled) {
-            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt);     // label table inline
+            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
             q = prepared[a.index];
             q.actv = m.actv;
         } else if (ahead_luts && a.styled) {
-            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt);     // label table inline
+            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
             q = prepared[a.index];
             q.actv = m.actv;
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else {
-            q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true, 3, need, tile_cnt);
+            q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true, 3, need, tile_cnt, u5);
         }
         if (wino_ace && wp.L) {
             const double xpp = 4.0 * a.C / (x_up ? 4.0 : 1.0), opp = 4.0 * a.C;

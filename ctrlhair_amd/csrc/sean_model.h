@@ -123,6 +123,8 @@ struct SeanModel {
         // gather mode (conv_wino.h): one list of boundary quads per sample, tasks of 64 consecutive entries
         unsigned* gq = nullptr; int* gq_n = nullptr; int* qoff = nullptr; int gq_cap = 0;
     };
+    int hidden_wq = 1;                         // option "sean.hidden_wq": Winograd ACE path from 128 pixels, SPADE hidden activations + one-hot planes
+                                               //   from one persistent kernel, only where a boundary quad's patch reads them (0: every pixel, two kernels)
     int lut_grouped = 1;                       // option "sean.lut_grouped": exact-f32 path, style LUTs of all styled ACEs from one grouped GEMM launch
     int wino_gather = 1;                       // option "sean.wino_gather": 1 = gather mode of the Winograd ACE kernel (default), 0 = tile mode
     int wino_th = 0;                           // option "sean.wino_th": tile height 16 / 32 of the Winograd ACE kernel (0 = by level)

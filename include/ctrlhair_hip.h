@@ -56,7 +56,10 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
 /* Options, set before ch_finalize.  "sean.f16x3" (default 0) selects the arithmetic of the SEAN generator's MFMA convs:
  *   0  f32 throughout on the f32 matrix cores (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: every product and every sum an IEEE f32
  *      operation); with "sean.wino" = 1 (default) the 3x3 convs are evaluated as Winograd F(2x2,3x3)
- *      (ctrlhair_amd/csrc/conv_wino.h), with 0 directly (conv_mfma.h) -- two associations of the same f32 arithmetic;
+ *      (ctrlhair_amd/csrc/conv_wino.h: f32 operands and f32 accumulation, but TRANSFORMED operands -- U = G g G^T is computed in
+ *      double and rounded once to f32, the input / output transforms are f32 adds -- so this is not a re-association of the
+ *      direct sum and carries its own, slightly larger rounding error: <= ~4e-6 measured against the direct evaluation on the
+ *      generator output, 2e-5 asserted), with 0 directly (conv_mfma.h: the reference conv2d's products and sums);
  *   1  f16 matrix cores with the 3-term split-operand scheme of ctrlhair_amd/csrc/conv_sh16.h: f32-class accuracy, f32
  *      accumulation, activations between ACE and conv stored as f16 hi/lo pairs;
  *   2  f16 matrix cores, single term: operands rounded to f16, f32 accumulation and f32 normalisation / modulation
@@ -80,6 +83,9 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   Winograd F(2x2,3x3) on the f32 matrix cores, the learned 1x1 shortcuts on the pointwise kernel of conv_pw.h.
  * "sean.lut_grouped" (default 1; exact-f32 path, calls with more than 64 (sample, label) columns): the style LUTs of all styled ACEs
  *   of a chunk come from ONE grouped GEMM launch at its start (csrc/conv_pw.h); 0 = one launch of the generic 1x1 kernel per ACE.
+ * "sean.hidden_wq" (default 1; any time): Winograd ACE levels of 128 pixels and more take the SPADE hidden activations and the one-hot
+ *   planes from one persistent kernel that writes only the 64-byte pixel groups a boundary quad's patch touches
+ *   (csrc/sean_kernels.hip spade_hidden_wq); 0 = the label-table kernel over every pixel + the one-hot kernel (bit-identical results).
  * "sean.wino_gather" (default 1): the Winograd ACE kernel takes tasks of 64 consecutive boundary quads of a sample and fetches each
  *   quad's own 4 x 4 patch (csrc/conv_wino.h); 0 = tasks per tile of 32 x 16 / 32 x 32 pixels (bit-identical results).
  * "sean.wino_th": tile height 16 / 32 of the tile mode (0 = chosen per resolution level).

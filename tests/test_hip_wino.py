@@ -141,6 +141,46 @@ def test_size_with_mixed_levels_against_the_oracle(hip_lib):
     g.handle.close()
 
 
+def test_hidden_activations_on_boundary_quad_patches_only(hip_lib):
+    """Option sean.hidden_wq (default 1): from 128 pixels the SPADE hidden activations (normalization.py:249-251) and the one-hot
+    planes come from one persistent kernel that writes only the 64-byte pixel groups some boundary quad's 4 x 4 patch touches;
+    0 = the label-table kernel over every pixel.  Same sums in the same order, and no unwritten pixel is ever read: the images
+    must be bit-identical -- also when a call with other labels ran in between (stale hidden activations in the skipped pixels)."""
+    from ctrlhair_amd import procedural as P
+    ngf, B, S = 16, 3, 256
+    sd = P.sean_state_dict(0, ngf)
+    g = _gen(sd, B, S, 1)
+    codes, noise = P.style_codes(B, seed=51), P.noise_planes(B, S, ngf, seed=52)
+    sets = _label_sets(B, S)
+    outs = {}
+    for name in ('face', 'blocky', 'one_region', 'noclass_at_tile_borders', 'diag'):
+        outs[name] = _run(g, sets[name], codes, noise)
+    g.handle.set_option('sean.hidden_wq', 0)
+    for name in ('diag', 'noclass_at_tile_borders', 'one_region', 'blocky', 'face'):
+        ref = _run(g, sets[name], codes, noise)
+        assert np.isfinite(ref).all()
+        assert np.array_equal(ref, outs[name]), name
+    g.handle.close()
+
+
+def test_runtime_size_reaches_a_level_max_size_does_not_have(hip_lib):
+    """max_size = 96, S = 64, B = 2: the 32-pixel level of S = 64 sits on the Winograd grid, the same level of the
+    handle (48 pixels) does not, so no quad lists exist for it -- the ACE must take the direct kernels AND write the hidden
+    activations in their layout (one predicate for both).  Samples b >= 1 are the ones a layout mismatch corrupts."""
+    from ctrlhair_amd import procedural as P
+    ngf, B, S = 16, 2, 64
+    sd = P.sean_state_dict(0, ngf)
+    direct, wino = _gen(sd, B, 96, 0), _gen(sd, B, 96, 1)
+    codes, noise = P.style_codes(B, seed=41), P.noise_planes(B, S, ngf, seed=42)
+    lab = np.stack([P.face_like_labels(S, 70 + b) for b in range(B)])
+    a, b = _run(direct, lab, codes, noise), _run(wino, lab, codes, noise)
+    d = [float(np.abs(a[i] - b[i]).max()) for i in range(B)]
+    print(f'max_size=96 S=64: max |winograd - direct| per sample = {d}')
+    assert np.isfinite(b).all() and max(d) <= 2e-5
+    direct.handle.close()
+    wino.handle.close()
+
+
 def test_option_must_precede_finalize(hip_lib):
     from ctrlhair_amd import procedural as P
     g = _gen(P.sean_state_dict(0, 16), 1, 64, 1)

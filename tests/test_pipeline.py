@@ -15,10 +15,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-@pytest.fixture(scope='module')
-def pipe(hip_lib):
+@pytest.fixture(scope='module', params=[1, 0], ids=['f16x3', 'f32'])
+def pipe(hip_lib, request):
+    """Both arithmetic legs bench.py reports for configs[2]: the split-operand f16 MFMA path and the exact-f32 path (Winograd
+    Zencoder / BiSeNet / shape-decoder routes and the Winograd generator chained, as `pipeline.f32` of the bench line runs them)."""
     from ctrlhair_amd.pipeline import EditPipeline
-    p = EditPipeline(device=0, img_size=512, max_batch=8, f16x3=1)
+    p = EditPipeline(device=0, img_size=512, max_batch=8, f16x3=request.param)
     yield p
     p.close()
 
@@ -122,14 +124,15 @@ def test_end_to_end_batch8(pipe):
     assert np.abs(one[0] - out[5]).max() <= 1e-5
 
 
-def test_backend_512_matches_pipeline(hip_lib):
+@pytest.mark.parametrize('f16x3', [True, False], ids=['f16x3', 'f32'])
+def test_backend_512_matches_pipeline(hip_lib, f16x3):
     """The drop-in API at BASELINE size: Backend(img_size=512, max_batch=8).set_input_img / change_* / output() on one
     portrait == the pipeline on the same portrait, sliders and noise (uint8 image, +-1 level)."""
     from ctrlhair_amd import procedural as P
     from ctrlhair_amd.pipeline import EditPipeline
     from ctrlhair_amd.ui.backend import Backend
     S, ngf = 512, 64
-    be = Backend(2.5, blending=False, img_size=S, max_batch=8, f16x3=True)
+    be = Backend(2.5, blending=False, img_size=S, max_batch=8, f16x3=f16x3)
     img_u8 = np.clip((P.synthetic_images(1, S, seed=11)[0].transpose(1, 2, 0) * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
     be.set_input_img(img_u8)
     be.noise = torch.from_numpy(P.noise_planes(1, S, ngf, seed=93)).to(be.device)
