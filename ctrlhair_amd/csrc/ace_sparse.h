@@ -102,6 +102,8 @@ struct AceInteriorParams {
                                 // 2 = exact-f32 kernel only: four pixels per thread, blocks of 128 x 8 (W >= 128)
     int fill_min;               // f16x3 kernel, variant 1: a block with at least this many interior pixels (of 256) writes ALL its
                                 // pixels -- the boundary conv, launched after this pass, overwrites the others; 0 = 128
+    int quad_only;              // exact-f32 tile kernels: 1 = write an interior pixel only when its whole 2 x 2 quad is interior (the Winograd
+                                // boundary conv writes all four pixels of a boundary quad; needed when the two run concurrently)
     int variant;                // exact-f32 kernel: 0 = one pixel per thread (default), 1 = four pixels per thread (16-byte
                                 // accesses), 2 = one pixel per thread writing whole 32-byte sectors (A/B measurements)
 };

@@ -327,6 +327,10 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
     const bool inimg = x < q.W && y < q.H;
     const int pix = y * q.W + x;
     int j = inimg ? q.u5[(long long)b * HW + pix] : 255;
+    if (q.quad_only && inimg) {          // overlap mode: the boundary conv writes every pixel of a boundary quad at the same time
+        const uint8_t* uq = q.u5 + (long long)b * HW + (y & ~1) * q.W + (x & ~1);
+        if (uq[0] >= 19 || uq[1] >= 19 || uq[q.W] >= 19 || uq[q.W + 1] >= 19) j = 255;
+    }
     const bool mine = j < 19;
     const int nmine = __syncthreads_count(mine);
     if (nmine == 0) return;                                  // no interior pixel in this block
@@ -374,7 +378,13 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
     const int pix = y * q.W + x;
     uchar4 j4 = make_uchar4(255, 255, 255, 255);
     if (inimg) j4 = *reinterpret_cast<const uchar4*>(q.u5 + (long long)b * HW + pix);
-    const bool i0 = j4.x < 19, i1 = j4.y < 19, i2 = j4.z < 19, i3 = j4.w < 19;
+    bool i0 = j4.x < 19, i1 = j4.y < 19, i2 = j4.z < 19, i3 = j4.w < 19;
+    if (q.quad_only && inimg) {          // overlap mode: the boundary conv writes every pixel of a boundary quad at the same time
+        const uchar4 o4 = *reinterpret_cast<const uchar4*>(q.u5 + (long long)b * HW + (y ^ 1) * q.W + x);      // the other row of the two quads
+        const bool q0 = i0 && i1 && o4.x < 19 && o4.y < 19, q1 = i2 && i3 && o4.z < 19 && o4.w < 19;
+        i0 = i1 = q0;
+        i2 = i3 = q1;
+    }
     const int nmine = __syncthreads_count(i0) + __syncthreads_count(i1) + __syncthreads_count(i2) + __syncthreads_count(i3);
     if (nmine == 0) return;                                  // no interior pixel in this block
     const bool fill = nmine >= 4 * (q.fill_min > 0 ? q.fill_min : 128);

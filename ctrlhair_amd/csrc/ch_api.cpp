@@ -357,6 +357,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.lut_grouped = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.overlap") == 0) {      // CUs of the side streams of the overlap mode (sean_model.h), 0 = off
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.overlap) must precede ch_finalize");
+        h->sean.overlap = value < 0 ? 0 : value;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.hidden_wq") == 0) {    // Winograd ACE path: 1 = hidden activations + one-hot planes from spade_hidden_wq (default)
         h->sean.hidden_wq = value != 0;
         return CH_OK;

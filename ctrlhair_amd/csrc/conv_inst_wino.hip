@@ -33,6 +33,7 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
     if (p.d2s && (p.Cout % 4 || p.res || p.reflect || p.in_up || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;
     if (p.in_up && (p.reflect || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;      // (H, W: the conv's own = 2 x stored size)
     wino_fill_launch(p);
+    if (p.nks < wino::NST) p.claim = nullptr;     // (the issue side may run two tasks ahead: static split only)
     const int grid = p.ntasks < wino_num_cus() ? p.ntasks : wino_num_cus();
     static bool d0[64] = {}, d1[64] = {}, d2[64] = {};
     if (p.d2s) {

@@ -74,6 +74,7 @@ struct WinoParams {
                             //   (a stride-2 ConvTranspose2d as four phase convs of the input grid; no residual)
     int pair16;             // set by the launcher for 16 x 16 images (B even): two samples side by side fill a tile of 32 x 16 pixels
     const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image patch elements)
+    unsigned* claim;        // eight zeroed counters: dynamic task claiming (below; Cin >= 24), or null: static split
     // set by the launcher
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
 };
@@ -178,6 +179,30 @@ __device__ __forceinline__ void wino_dma16(unsigned voff, const wino_u32x4& d, u
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(d), "s"(soff), "s"(lds) : "memory");
 }
 
+// ---- dynamic task claiming (round 5) -----------------------------------------------------------------------------------------------
+// A persistent kernel that splits its tasks statically (block b takes tasks b, b + G, ...) ends when its LAST block does: a block
+// that starts late -- because a kernel of another stream (label tables, interior passes: HBM-bound work that runs beside these
+// matrix-bound convs on a few CUs, sean_model.cpp) held its CU -- holds the whole launch back by as much.  With `claim` set the
+// blocks take their tasks from eight counters, one per XCD (device memory, zeroed before the launch): claim number j of XCD x is
+// task ((j >> cs) * 8 + x) << cs | (j & (2^cs - 1)) -- chunks of 2^cs consecutive tasks stay on one XCD, as the static order's
+// xcd_remap arranges (their A images / patches meet in that XCD's L2), and the XCDs' shares differ by at most one chunk.  A block
+// claims its first two tasks when it starts and then, before the epilogue of task k, the task after next; the answer is read
+// after that epilogue's own `s_waitcnt vmcnt(0)` and handed to the other waves through LDS (one more barrier per task).  Which
+// block computes a task never changes what is computed: results stay bit-identical from run to run.
+__device__ __forceinline__ int wino_xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (2 << 11)) & 7u); }      // HW_REG_XCC_ID[2:0]
+__device__ __forceinline__ int wino_claim_task(unsigned j, int xcc, int cs, int ntasks) {
+    const long long t = ((((long long)(j >> cs) << 3) + xcc) << cs) + (j & ((1u << cs) - 1u));
+    return t < ntasks ? (int)t : ntasks;
+}
+// a word another wave of this CU stored a few microseconds ago, read past the scalar cache (SGPR result: lgkmcnt, not the ring's vmcnt)
+__device__ __forceinline__ int wino_mail_read(const unsigned* p) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return (int)v;
+}
+// chunk size of a launch with `ntasks` tasks (log2): 32 where every XCD gets several chunks, smaller for short launches
+__host__ __device__ inline int wino_claim_cs(int ntasks) { return ntasks >= 2048 ? 5 : (ntasks >= 1024 ? 4 : (ntasks >= 512 ? 3 : (ntasks >= 256 ? 2 : 0))); }
+
 #ifndef WINO_NG
 #define WINO_NG 8      // MFMA groups per k-step between scheduling fences: 8 (of four MFMAs) or 4 (of eight)
 #endif
@@ -196,9 +221,28 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kk = lane >> 4;
     const int G = gridDim.x;
-    const int lb = xcd_remap(blockIdx.x, G);
+    // static split: block lb takes tasks lb, lb + G, ...; dynamic (p.claim set; the launcher guarantees nks >= NST, so that the issue
+    // side is never more than one task ahead of the consumers): tasks claimed from the XCD's counter, see wino_claim_task
+    __shared__ int mbox[2];
+    const bool dyn = p.claim != nullptr && p.ntasks >= 8 * G;      // (a block holds two claimed tasks: only where a block gets many)
+    int lb, tn;                                    // first task, the task after it (ntasks: none)
+    if (dyn) {
+        if (tid == 0) {
+            const int xcc = wino_xcc_id(), ccs = wino_claim_cs(p.ntasks);
+            const unsigned j0 = __hip_atomic_fetch_add(p.claim + xcc, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mbox[0] = wino_claim_task(j0, xcc, ccs, p.ntasks);
+            mbox[1] = wino_claim_task(j0 + 1u, xcc, ccs, p.ntasks);
+        }
+        __syncthreads();
+        lb = __builtin_amdgcn_readfirstlane(mbox[0]);
+        tn = __builtin_amdgcn_readfirstlane(mbox[1]);
+        __syncthreads();
+    } else {
+        lb = xcd_remap(blockIdx.x, G);
+        tn = p.ntasks;
+    }
     if (lb >= p.ntasks) return;
-    const int mytasks = (p.ntasks - lb + G - 1) / G;
+    int ct = lb;                                   // the task the consumers work on
     const int nk = p.nks;
     const int HW = p.H * p.W;
     const int Ws = UP ? p.W >> 1 : p.W, HWs = UP ? HW >> 2 : HW;          // the input planes as stored
@@ -258,8 +302,9 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
         so_in += 16u * (unsigned)HWs;
         so_a += 8192u;
         if (++is == nk) {
-            if (it + G < p.ntasks) {
-                it += G;
+            const int nx = dyn ? (it == ct ? tn : p.ntasks) : it + G;
+            if (nx < p.ntasks) {
+                it = nx;
                 is = 0;
                 issue_task();
             } else {                       // past the end: keep re-issuing the last k-step (never read; keeps the vmcnt counting uniform)
@@ -369,11 +414,14 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
         }
         rslot = nslot;
     };
-    for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
+    for (int k = 0;; ++k) {
         for (int cs = 0; cs < nk; cs += 2) {
             kstep(v, w);          // (nks is even: wino_supported)
             kstep(w, v);
         }
+        const bool more = dyn ? tn < p.ntasks : ct + G < p.ntasks;
+        unsigned jnext = 0;       // dynamic claiming: the task after next, answered during the epilogue
+        if (dyn && more && tid == 0) jnext = __hip_atomic_fetch_add(p.claim + wino_xcc_id(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- epilogue of task ct: every load first (rows clamped, so no load sits behind a branch: the per-row load -> use chains
         //      of the first version cost four memory round trips per task), then the output transforms, then the stores -----------
         if constexpr (D2S != 0) {
@@ -471,6 +519,16 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
                 for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
             after_epi = true;
         }
+        if (!more) break;
+        if (dyn) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) mbox[k & 1] = wino_claim_task(jnext, wino_xcc_id(), wino_claim_cs(p.ntasks), p.ntasks);
+            __syncthreads();
+            ct = tn;
+            tn = __builtin_amdgcn_readfirstlane(mbox[k & 1]);
+        } else {
+            ct += G;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
 }
@@ -512,6 +570,7 @@ struct WinoAceParams {
     const unsigned* gq;     // [B][gq_cap]: y << 16 | x of the quad's first pixel
     const int* gq_n;        // [B] quads per sample
     int gq_cap;             // work entries in this mode: sample | chunk of 64 quads << 5 | row pair << 16
+    unsigned* claim;        // gather mode: eight zeroed counters (dynamic task claiming, above) or null (static split)
     int nrt, ntx, nty, K;   // set by the launcher
 };
 // Tile height 32 (16 x 16 quads) or 16 (16 x 8 quads), chosen per resolution level by the caller: a sparse tile must hold enough
@@ -850,9 +909,31 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
     const int n = lane & 15, kk = lane >> 4;
     const int G = gridDim.x;
     const int ntasks = p.total[0];
-    const int lb = xcd_remap(blockIdx.x, G);      // the row pairs of a chunk of quads are consecutive entries: one XCD, the same time
+    // static split: block lb takes tasks lb, lb + G, ... (the row pairs of a chunk of quads are consecutive entries: one XCD, the same
+    // time); dynamic: tasks claimed from the XCD's counter (wino_claim_task).  This kernel's ring fills all 160 KB of LDS, so the
+    // claimed task travels from wave 0 to the other waves through device memory: p.claim[16 + 2 blockIdx + parity], written after
+    // the epilogue's drain and read eight k-steps into the next task by a scalar load that bypasses the scalar cache (wave 0's
+    // counted waits in between retire the store; both ends sit on one CU, L2 is their coherence point).  The first two tasks are
+    // claimed while the ring is still empty and pass through its first words.
+    const bool dyn = p.claim != nullptr && ntasks >= 8 * G;       // (a block holds two claimed tasks: only where a block gets many)
+    int lb, tn;                                    // first task, the task after it (ntasks: none)
+    if (dyn) {
+        int* mb = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int xcc = wino_xcc_id(), ccs = wino_claim_cs(ntasks);
+            const unsigned j0 = __hip_atomic_fetch_add(p.claim + xcc, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mb[0] = wino_claim_task(j0, xcc, ccs, ntasks);
+            mb[1] = wino_claim_task(j0 + 1u, xcc, ccs, ntasks);
+        }
+        __syncthreads();
+        lb = __builtin_amdgcn_readfirstlane(mb[0]);
+        tn = __builtin_amdgcn_readfirstlane(mb[1]);
+        __syncthreads();
+    } else {
+        lb = xcd_remap(blockIdx.x, G);
+        tn = lb + G < ntasks ? lb + G : ntasks;
+    }
     if (lb >= ntasks) return;
-    const int mytasks = (ntasks - lb + G - 1) / G;
     const int nks = 32, nk = nks + (p.wsty ? 5 : 0);
     const int HW = p.H * p.W;
     constexpr unsigned SB = winog::SDW * 4, RING = WA_NST * SB;
@@ -1024,13 +1105,24 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
         group(WInt<4>{}); group(WInt<5>{}); group(WInt<6>{}); group(WInt<7>{});
         rslot = nslot;
     };
-    for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
-        const bool more = k + 1 < mytasks;
-        const int tnext = more ? ct + G : ct;                   // (past the end: this task again -- never read; keeps the vmcnt counting uniform)
+    constexpr int KREAD = 8;                                   // k-steps into a task at which the next task's id is read
+    for (int k = 0, ct = lb;; ++k) {
+        for (int c = 0; c < KREAD; ++c) kstep();
+        if (k > 0) {
+            if (dyn) {
+                unsigned v;
+                do v = (unsigned)wino_mail_read(p.claim + 16 + 2 * blockIdx.x + ((k - 1) & 1));
+                while ((v >> 21) != (unsigned)(k & 0x7FF));
+                tn = (int)(v & 0x1FFFFFu);
+            }
+            else tn = ct + G < ntasks ? ct + G : ntasks;
+        }
+        const bool more = tn < ntasks;
+        const int tnext = more ? tn : ct;                       // (past the end: this task again -- never read; keeps the vmcnt counting uniform)
         Ctx nxt = cur;
-        if (more) nxt = task_ctx(tnext);                        // (in flight during this task's k-steps)
+        if (more) nxt = task_ctx(tnext);                        // (in flight during this task's remaining k-steps)
         const unsigned qnext = task_quad(tnext, islot_q);
-        for (int c = 0; c < nks - AHEAD; ++c) kstep();
+        for (int c = KREAD; c < nks - AHEAD; ++c) kstep();
         if (nk > nks) {
             dA0 = d_s0;
             dA1 = d_s1;
@@ -1039,6 +1131,8 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
         }
         issue_task(tnext, qnext);
         for (int c = nk - AHEAD; c < nk; ++c) kstep();
+        unsigned jnext = 0;                                     // dynamic claiming: the task after next, answered during the epilogue
+        if (dyn && more && tid == 0) jnext = __hip_atomic_fetch_add(p.claim + wino_xcc_id(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- ACE epilogue (as wino_ace_kernel) ---------------------------------------------------------------------------------
         if (cur.active) {
             const int b = cur.b, y = cur.y, x = cur.x;
@@ -1097,7 +1191,12 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc[x2][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!more) break;
+        // (tagged with the iteration: the reader spins until it sees THIS iteration's word -- the counted waits make that the first read)
+        if (dyn && tid == 0)
+            p.claim[16 + 2 * blockIdx.x + (k & 1)] = (unsigned)wino_claim_task(jnext, wino_xcc_id(), wino_claim_cs(ntasks), ntasks) | (unsigned)((k + 1) & 0x7FF) << 21;
         cur = nxt;
+        ct = tn;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the block
 }

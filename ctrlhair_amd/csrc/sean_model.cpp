@@ -437,10 +437,41 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     // 1.6 % at that size -- so larger handles opt in explicitly: option "sean.ahead" = images of 512^2 per chunk (0 = never).
     if (ahead_pixels < 0) ahead_pixels = (long long)2 * 512 * 512;
     // Larger jobs keep the (HBM-write-bound) label-table kernels inline and run only the style LUT builds -- small,
-    // latency-bound GEMMs -- ahead (ahead_full = false).
+    // latency-bound GEMMs -- ahead (ahead_full = false) -- unless the overlap mode serves them (sean_model.h): then the label
+    // tables of every ACE run ahead too, on a side stream confined to a few CUs.
+    overlap_on = false;
+    if (overlap > 0 && !use_sh16 && wino && (long long)mb * ms * ms > ahead_pixels && ms >= 128) {
+        int ncu = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+        const int want = std::min(overlap, ncu / 2) & ~7;
+        if (want >= 8) {
+            uint32_t mask[16] = {};
+            for (int i = 0; i < want; ++i) mask[i >> 5] |= 1u << (i & 31);      // (CU i of the mask sits on XCD i % 8)
+            const uint32_t words = (uint32_t)((ncu + 31) / 32);
+            if (hipExtStreamCreateWithCUMask(&side, words, mask) == hipSuccess && hipExtStreamCreateWithCUMask(&side_int, words, mask) == hipSuccess &&
+                hipStreamCreateWithFlags(&main_i, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess) {
+                overlap_on = true;
+            } else {
+                return "overlap mode: stream creation failed (hipExtStreamCreateWithCUMask)";
+            }
+        }
+    }
+    if (overlap_on) {
+        if (ahead_pixels <= 0) ahead_pixels = 1;      // (the per-ACE buffers below)
+        ev_x.assign(n_aces, nullptr);
+        ev_int.assign(n_aces, nullptr);
+        for (auto& e : ev_x)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return "event creation failed";
+        for (auto& e : ev_int)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return "event creation failed";
+        claim_pool = static_cast<unsigned*>(B.dalloc((size_t)CLAIM_SLOTS * CLAIM_WORDS * sizeof(unsigned)));
+    }
     if (ahead_pixels > 0) {
-        ahead_full = (long long)mb * ms * ms <= ahead_pixels;
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess)
+        ahead_full = overlap_on || (long long)mb * ms * ms <= ahead_pixels;
+        if (!overlap_on && (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess))
             return "side stream creation failed";
         ev_join.assign(n_aces, nullptr);
         actv_ahead.assign(n_aces, nullptr);
@@ -588,7 +619,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         sp_level[k][0] = sp_level[k][1] = SparseLevel();
         sp_work[k].clear();
     }
-    gtab = nullptr;
+    gtab = gtab_side = nullptr;
     if (sparse) {
         int cmax = 0;
         for (const auto& b : blocks)
@@ -631,6 +662,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 cmax = std::max(cmax, a->C);
             }
         if (cmax) gtab = B.falloc((size_t)mb * LABEL_NC * 2 * cmax);
+        if (cmax && overlap_on) gtab_side = B.falloc((size_t)mb * LABEL_NC * 2 * cmax);
     }
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "hipDeviceSynchronize failed after weight upload";
@@ -647,6 +679,20 @@ void SeanModel::destroy() {
     ev_fork = nullptr;
     if (side) (void)hipStreamDestroy(side);
     side = nullptr;
+    if (side_int) (void)hipStreamDestroy(side_int);
+    if (main_i) (void)hipStreamDestroy(main_i);
+    side_int = main_i = nullptr;
+    for (auto e : ev_x)
+        if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_int)
+        if (e) (void)hipEventDestroy(e);
+    ev_x.clear();
+    ev_int.clear();
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    ev_in = ev_out = nullptr;
+    overlap_on = false;
+    claim_pool = nullptr;
     actv_ahead.clear();
     lut_ahead.clear();
     splitk_side = nullptr;
@@ -736,6 +782,13 @@ struct Runner {
         if (it != m.taps.end() && it->second)
             check(hipMemcpyAsync(it->second, src, floats * 4, hipMemcpyDeviceToDevice, st), "tap copy");
     }
+    // overlap mode (sean_model.h): interior passes on m.side_int beside the boundary convs, dynamic task claiming in the convs
+    bool overlap = false;
+    int claim_next = 0;
+    unsigned* next_claim() {
+        if (!m.claim_pool || claim_next >= SeanModel::CLAIM_SLOTS) return nullptr;
+        return m.claim_pool + (size_t)SeanModel::CLAIM_WORDS * claim_next++;
+    }
     // exact SPADE-interior reduction: the level's classification and the work list of (level, row tiles), once per chunk
     bool lvl_done[6][2] = {};
     std::vector<int> work_done[6];
@@ -810,6 +863,25 @@ struct Runner {
         int k = 0;
         while ((1 << k) < res_div) ++k;
         return m.lab_r[k];
+    }
+    // the interior map of an ACE's level once its classification has run in this chunk (else nullptr)
+    const uint8_t* level_u5(const AceW& a, int r) const {
+        if (!m.sparse || r < m.sparse_min_r) return nullptr;
+        int k = 0;
+        while ((1 << k) < a.res_div) ++k;
+        for (int ti = 1; ti >= 0; --ti)
+            if (m.sp_level[k][ti].u5 && lvl_done[k][ti]) return m.sp_level[k][ti].u5;
+        return nullptr;
+    }
+    // classification, quad lists and task lists of every Winograd ACE level up front (they depend on the labels only): the label
+    // tables that run ahead on the side stream need the interior maps
+    void prepass(const uint8_t* labfull) {
+        for (const auto& b : m.blocks)
+            for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
+                if (!a) continue;
+                const int r = S / a->res_div;
+                if (use_wino_ace(*a, r)) (void)wino_prepare(*a, labels_at(labfull, a->res_div), r);
+            }
     }
 
     // What an ACE needs that depends on the label map and the style codes only -- never on the activations flowing
@@ -951,8 +1023,9 @@ struct Runner {
         for (const auto& b : m.blocks)
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a || (!full && !a->styled)) continue;
+                const int ra = S / a->res_div;
                 AcePrep e = ace_prepare(*a, labfull, codes, m.side, m.actv_ahead[a->index], m.lut_ahead[a->index], m.splitk_side, false,
-                                        full ? (luts_ready ? 2 : 3) : 1);
+                                        full ? (luts_ready ? 2 : 3) : 1, nullptr, nullptr, use_wino_ace(*a, ra) ? level_u5(*a, ra) : nullptr);
                 if (luts_ready && a->styled) lut_entry(*a, e);          // (the grouped launch on the main stream built it)
                 prepared[a->index] = e;
                 check(hipEventRecord(m.ev_join[a->index], m.side), "join record");
@@ -1060,10 +1133,23 @@ struct Runner {
                 // (tools/interior_bench.hip); level in the 100 ms step of round 3, measurable in this one
                 ip.impl = r >= 128 ? 2 : 0;
                 ip.fill_min = (x_up && r < 128) ? 257 : 128;
-                timed(3, 0.0, 0.0, wp.W->total + 4, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
-                    check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
-                    check(ace_interior_f32(ip, st), "ace interior");
-                });
+                if (overlap) {
+                    // beside the boundary conv of the same ACE (disjoint output pixels -- so no block may fill its boundary pixels),
+                    // on the few CUs of the side stream; the consumer of `hout` waits for ev_int below
+                    ip.fill_min = 257;
+                    ip.quad_only = 1;
+                    ip.gtab = m.gtab_side;
+                    check(hipEventRecord(m.ev_x[a.index], st), "x ready");
+                    check(hipStreamWaitEvent(m.side_int, m.ev_x[a.index], 0), "x ready wait");
+                    check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab_side, B, a.C, m.side_int), "ace_gtable");
+                    check(ace_interior_f32(ip, m.side_int), "ace interior");
+                    check(hipEventRecord(m.ev_int[a.index], m.side_int), "interior done");
+                } else {
+                    timed(3, 0.0, 0.0, wp.W->total + 4, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
+                        check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
+                        check(ace_interior_f32(ip, st), "ace interior");
+                    });
+                }
             }
             WinoAceParams w{};
             w.actv = q.actv;
@@ -1093,12 +1179,14 @@ struct Runner {
             w.gq = wp.L->gq;
             w.gq_n = wp.L->gq_n;
             w.gq_cap = wp.L->gq_cap;
+            w.claim = w.gq ? next_claim() : nullptr;
             // executed FLOPs = wave tasks x (32 rows x 16 quads x 16 positions x K) x 2; dense = the direct conv over every pixel
             timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 0.0, wp.W->total + 4, 2.0 * 32 * 16 * 16 * ktot, 4.0 * ktot + xpp + opp,
                   4.0 * 2.0 * a.C * ktot * 16, npix, [&] {
                       if (w.wsty) check(wino_style_pack(q.lut, m.wsty, B, a.C, st), "wino_style_pack");
                       check(conv_wino_ace(w, st), "spade conv (winograd, boundary quads)");
                   });
+            if (overlap && wp.S) check(hipStreamWaitEvent(st, m.ev_int[a.index], 0), "interior done wait");
             return;
         }
         ConvParams p{};
@@ -1266,6 +1354,7 @@ struct Runner {
             q.res_up = res_up;
             q.act = ACT_NONE;
             q.zero = m.zero_page;
+            q.claim = next_claim();
             next_flops_exec = 2.0 * w.Cout * w.Cin * 16.0 * npix / 4.0;
             timed(0, 2.0 * w.Cout * w.Cin * 9.0 * npix,
                   4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * 16.0),
@@ -1315,9 +1404,22 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
     if (S % 32 != 0 || S < 32 || S > max_size) return "S must be a multiple of 32 and <= max_size";
     if (Btot < 1) return "B must be >= 1";
     const size_t nf = noise_floats(S);
+    // overlap handles: everything runs on the internal main stream (the CU-masked side streams are blocking streams: work on the
+    // caller's stream, if that is the NULL stream, would serialise with them), forked from and joined to the caller's stream
+    hipStream_t st_user = st;
+    if (overlap_on) {
+        if (hipEventRecord(ev_in, st_user) != hipSuccess || hipStreamWaitEvent(main_i, ev_in, 0) != hipSuccess) return "overlap mode: fork failed";
+        st = main_i;
+    }
+    auto join = [&](const std::string& e) {
+        if (overlap_on && (hipEventRecord(ev_out, main_i) != hipSuccess || hipStreamWaitEvent(st_user, ev_out, 0) != hipSuccess) && e.empty())
+            return std::string("overlap mode: join failed");
+        return e;
+    };
     for (int bo = 0; bo < Btot; bo += max_batch) {
         const int B = std::min(max_batch, Btot - bo);
         Runner R(*this, st, B, S);
+        if (claim_pool) R.check(hipMemsetAsync(claim_pool, 0, (size_t)CLAIM_SLOTS * CLAIM_WORDS * sizeof(unsigned), st), "claim counters");
         const uint8_t* lab = labels + (size_t)bo * S * S;
         const float* cd = codes + (size_t)bo * LABEL_NC * STYLE;
         const float* nz;
@@ -1345,7 +1447,12 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         }
         // interactive-size jobs: everything that depends on labels / codes only runs ahead on the side stream
         if (side && !prof_on && !(dbg & 4096)) {
-            if (ahead_full && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd, true);
+            const bool ov = overlap_on && (long long)B * S * S > ahead_pixels && R.luts_ready;
+            if (ov) {      // large job on an overlap handle: label tables of every ACE ahead on the CU-masked side stream, interior passes beside the convs
+                R.prepass(lab);
+                R.overlap = gtab_side != nullptr;
+                R.prepare_all_ahead(lab, cd, true);
+            } else if (ahead_full && (long long)B * S * S <= ahead_pixels) R.prepare_all_ahead(lab, cd, true);
             // large jobs: only the style LUT builds (small, latency-bound GEMMs) run ahead, in the tails of the conv kernels
             // (exact-f32 path, B = 16 at 512^2: 147.2 -> 148.3 images/s)
             else if ((fcmu_batched || !use_sh16) && !(dbg & 8192) && !R.luts_ready) R.prepare_all_ahead(lab, cd, false);
@@ -1395,9 +1502,9 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
             std::swap(x, y);
         }
         R.check(conv_img_tanh(x, img_w, img_b, out + (size_t)bo * 3 * S * S, B, ngf, S, S, st, use_sh16 ? 1 : 0, img_w4), "conv_img");
-        if (!R.err.empty()) return R.err;
+        if (!R.err.empty()) return join(R.err);
     }
-    return "";
+    return join("");
 }
 
 // phase: 0 = the whole encoder; 1 = the convolutional part only (feature map stays in the workspace; one chunk: Btot <=

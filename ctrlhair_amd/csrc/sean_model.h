@@ -123,6 +123,19 @@ struct SeanModel {
         // gather mode (conv_wino.h): one list of boundary quads per sample, tasks of 64 consecutive entries
         unsigned* gq = nullptr; int* gq_n = nullptr; int* qoff = nullptr; int gq_cap = 0;
     };
+    // Overlap mode (round 5; option "sean.overlap" = CUs of the side streams, 0 = off; exact-f32 Winograd path, jobs beyond the
+    // run-ahead sizes): the HBM-bound kernels -- label tables of all ACEs, interior passes -- run on streams whose CU mask holds
+    // `overlap` CUs (hipExtStreamCreateWithCUMask: every XCD gives overlap / 8 of its CUs), beside the matrix-bound convs on the
+    // internal main stream, which claim their tasks dynamically (conv_wino.h) and so lose only the CUs, not the time, the side
+    // kernels hold.  CU-masked streams are blocking streams (they synchronise with the NULL stream), so the whole generate() runs
+    // on `main_i`, forked from and joined to the caller's stream by events.
+    int overlap = 0;                           // (measured, DESIGN.md section 7: the side kernels are CU-bound, not HBM-bound, once confined -- no gain; default off)
+    bool overlap_on = false;                   // streams / buffers of the mode exist (build())
+    hipStream_t main_i = nullptr, side_int = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    std::vector<hipEvent_t> ev_x, ev_int;      // per ACE: its input is ready (main -> side_int), its interior pass is done (side_int -> main)
+    unsigned* claim_pool = nullptr;            // dynamic task claiming: CLAIM_SLOTS launches x CLAIM_WORDS words (8 counters + mailboxes), zeroed per chunk
+    static constexpr int CLAIM_SLOTS = 96, CLAIM_WORDS = 1024;
     int hidden_wq = 1;                         // option "sean.hidden_wq": Winograd ACE path from 128 pixels, SPADE hidden activations + one-hot planes
                                                //   from one persistent kernel, only where a boundary quad's patch reads them (0: every pixel, two kernels)
     int lut_grouped = 1;                       // option "sean.lut_grouped": exact-f32 path, style LUTs of all styled ACEs from one grouped GEMM launch
@@ -150,6 +163,7 @@ struct SeanModel {
         return sparse_th == 8 || sparse_th == 16 ? sparse_th : ((mtiles <= 2 || r >= 512) ? 16 : 8);
     }
     float* gtab = nullptr;
+    float* gtab_side = nullptr;                // overlap mode: the table of the interior passes on the side stream
     std::map<std::string, float*> taps;
     // profiling
     bool prof_on = false;

@@ -163,6 +163,31 @@ def test_hidden_activations_on_boundary_quad_patches_only(hip_lib):
     g.handle.close()
 
 
+def test_overlap_mode_equals_the_serial_schedule(hip_lib):
+    """Option sean.overlap (CUs of the side streams; default 0 = off; handles beyond the run-ahead sizes --
+    forced here with sean.ahead = 0): label tables of all
+    ACEs ahead on a CU-masked side stream, interior passes on a second one beside the boundary convs (disjoint pixels, no filling),
+    everything on the library's own main stream, forked from and joined to the caller's.  Scheduling only: the images must be
+    bit-identical to the serial schedule (sean.overlap = 0), call after call, also with the caller on a non-default stream."""
+    from ctrlhair_amd import procedural as P
+    ngf, B, S = 16, 3, 256
+    sd = P.sean_state_dict(0, ngf)
+    ov, serial = _gen(sd, B, S, 1, {'sean.ahead': 0, 'sean.overlap': 64}), _gen(sd, B, S, 1, {'sean.ahead': 0, 'sean.overlap': 0})
+    codes, noise = P.style_codes(B, seed=61), P.noise_planes(B, S, ngf, seed=62)
+    sets = _label_sets(B, S)
+    for name in ('face', 'blocky', 'one_region', 'noclass_at_tile_borders', 'diag'):
+        ref = _run(serial, sets[name], codes, noise)
+        for rep in range(2):
+            got = _run(ov, sets[name], codes, noise)
+            assert np.isfinite(got).all()
+            assert np.array_equal(ref, got), (name, rep)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        got = _run(ov, sets['face'][:2], codes[:2], noise[:2])
+    assert np.array_equal(got, _run(serial, sets['face'][:2], codes[:2], noise[:2]))
+    ov.handle.close()
+    serial.handle.close()
+
+
 def test_runtime_size_reaches_a_level_max_size_does_not_have(hip_lib):
     """max_size = 96, S = 64, B = 2: the 32-pixel level of S = 64 sits on the Winograd grid, the same level of the
     handle (48 pixels) does not, so no quad lists exist for it -- the ACE must take the direct kernels AND write the hidden

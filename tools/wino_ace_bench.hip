@@ -38,6 +38,9 @@ int main(int argc, char** argv) {
     const int gather = argc > 1 ? atoi(argv[1]) : 0;
     const int th_over = argc > 2 ? atoi(argv[2]) : 0;
     const int only_r = argc > 3 ? atoi(argv[3]) : 0;
+    const int dyn = argc > 4 ? atoi(argv[4]) : 0;      // 1 = dynamic task claiming (gather kernel)
+    unsigned* d_claim;
+    CK(hipMalloc(&d_claim, 64 * 1024 * 4));      // per launch: 8 counters, pad, 2 mailbox words per block
     const int B = 16, grid = 16;
     const Shape all[] = {
         {64, 1024, 1, 1, "up_0 ace_s/ace_0"}, {64, 512, 1, 0, "up_0 ace_1"},
@@ -104,13 +107,18 @@ int main(int argc, char** argv) {
         w.noise = d_noise; w.noise_bstride = (long long)r * r;
         w.qlist = d_ql; w.TH = TH; w.qcnt = d_qc; w.work = d_work; w.total = d_tot; w.zero = d_zero;
         w.gq = d_gq; w.gq_n = d_gqn; w.gq_cap = gq_cap;
+        CK(hipMemset(d_claim, 0, 64 * 1024 * 4));
+        w.claim = dyn ? d_claim : nullptr;
         CK(conv_wino_ace(w, 0));
         CK(hipDeviceSynchronize());
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int it = 5;
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < it; ++i) CK(conv_wino_ace(w, 0));
+        for (int i = 0; i < it; ++i) {
+            w.claim = dyn ? d_claim + 1024 * (i + 1) : nullptr;
+            CK(conv_wino_ace(w, 0));
+        }
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;

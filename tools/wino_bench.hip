@@ -49,6 +49,9 @@ __global__ void ref_pw_kernel(const float* in, const float* w, float* out, int B
     }
 }
 
+static unsigned* g_claim = nullptr;      // "dyn" runs: 64 launches x 1024 words (eight counters each), zeroed before every timed series
+static int g_claim_i = 0;
+static unsigned* next_claim() { return g_claim ? g_claim + 1024 * (g_claim_i++ % 64) : nullptr; }
 static int run_pw() {      // the four learned shortcuts of the ngf = 64 generator at 512^2, B = 16 (+ two small shapes)
     struct S1 { int B, Cin, Cout, H; };
     const S1 all[] = {{2, 32, 48, 32}, {1, 64, 32, 16}, {16, 1024, 512, 64}, {16, 512, 256, 128}, {16, 256, 128, 256}, {16, 128, 64, 512}};
@@ -72,6 +75,8 @@ static int run_pw() {      // the four learned shortcuts of the ngf = 64 generat
         CK(hipMemset(d_out, 0xFF, nout * 4));
         PwParams p{};
         p.in = d_in; p.wpk = d_pk; p.out = d_out; p.B = c.B; p.Cin = c.Cin; p.Cout = c.Cout; p.HW = HW;
+        if (g_claim) CK(hipMemset(g_claim, 0, 64 * 1024 * 4));
+        g_claim_i = 0;
         CK(conv_pw(p, 0));
         hipLaunchKernelGGL(ref_pw_kernel, dim3(4096), dim3(256), 0, 0, d_in, d_w, d_ref, c.B, c.Cin, c.Cout, HW);
         CK(hipDeviceSynchronize());
@@ -97,6 +102,12 @@ static int run_pw() {      // the four learned shortcuts of the ngf = 64 generat
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strncmp(argv[1], "dyn", 3)) {      // dynamic task claiming of the 3x3 convs
+        CK(hipMalloc(&g_claim, 64 * 1024 * 4));
+        CK(hipMemset(g_claim, 0, 64 * 1024 * 4));
+        --argc;
+        ++argv;
+    }
     if (argc > 1 && !strcmp(argv[1], "pw")) return run_pw();
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
     const int dbg = argc > 2 && !strcmp(argv[1], "dbg") ? atoi(argv[2]) : 0;      // timing ablations (wrong results)
@@ -156,6 +167,9 @@ int main(int argc, char** argv) {
         p.in = d_in; p.wpk = d_pk; p.out = d_out; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
         p.bias = d_b; p.res = d_res; p.res_up = c.res == 2 ? 1 : 0; p.act = ACT_NONE;
         p.zero = d_zero;
+        if (g_claim) CK(hipMemset(g_claim, 0, 64 * 1024 * 4));
+        g_claim_i = 0;
+        p.claim = next_claim();
         CK(conv_wino_plain(p, 0));
         CK(hipDeviceSynchronize());
         // reference (subsampled batch for the big shapes: samples 0 and B-1 only)
@@ -184,9 +198,10 @@ int main(int argc, char** argv) {
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             const int it = 5;
+            p.claim = next_claim();
             CK(conv_wino_plain(p, 0));
             CK(hipEventRecord(e0, 0));
-            for (int i = 0; i < it; ++i) CK(conv_wino_plain(p, 0));
+            for (int i = 0; i < it; ++i) { p.claim = next_claim(); CK(conv_wino_plain(p, 0)); }
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1));
