@@ -549,8 +549,15 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
 //     waves without quads only take part in the staging.  A tile with more than 64 boundary quads gets up to four tasks.
 //     (Tiles of 32 x 16 left half of the waves idle on sparse levels -- about 30 boundary quads per tile at 512^2 on the
 //     benchmark labels -- and a k-step costs nearly the same with four busy waves as with eight: 5.4 -> ms per C = 128 ACE.)
+// Layout of the SPADE hidden activations both ACE kernels read (written by spade_hidden_wq, sean_kernels.hip): planes of H rows x
+// wino_apitch(W) floats, image column x at x + WINO_AXOFF, zeros in the columns just left and right of the image.  The gather
+// kernel fetches a quad's four patch rows (columns x - 1 .. x + 2) as ONE 16-byte LDS-DMA unit each; the offset of 32 pixels (one
+// 128-byte line; rows stay 128-byte aligned) keeps the writer's runs of 64 pixels on whole lines (measured with an offset of 16
+// pixels: the 512^2 label-table launches 480 -> 659 us, every run split over three lines).
+constexpr int WINO_AXOFF = 32;
+__host__ __device__ inline int wino_apitch(int W) { return W + 64; }
 struct WinoAceParams {
-    const float* actv;      // [B][K][H][W]: K = 128 (+ 20 one-hot planes when wsty is set)
+    const float* actv;      // [B][K][H][wino_apitch(W)] (see above): K = 128 (+ 20 one-hot planes when wsty is set)
     const float* wpk;       // pack_wino_A image of the (gamma | beta) rows over the 128 hidden channels
     const float* wsty;      // [B][nrt][5][2048] per-sample style images, or null (unstyled ACE)
     float* out;             // [B][C][H][W]
@@ -605,6 +612,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
     const int mytasks = (ntasks - lb + G - 1) / G;
     const int nks = 32, nk = nks + (p.wsty ? 5 : 0);
     const int HW = p.H * p.W;
+    const int AP = wino_apitch(p.W), APL = p.H * AP;           // pitch / plane size of the hidden activations (floats)
     constexpr unsigned SB = WA_SDW * 4, RING = WA_NST * SB;
     const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
 
@@ -628,10 +636,10 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
             const int py = rem / PWP, px = rem - py * PWP;
             const int y = y0 + py, x = x0 + px;
             const bool ok = k4 < 4 && rem < WA_PROWS * PWP && px < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
+            voff[i] = ok ? (unsigned)(k4 * APL + y * AP + x + WINO_AXOFF) * 4u : 0x80000000u;
         }
         const int r0 = 2 * pair, r1 = 2 * pair + 1 < p.nrt ? 2 * pair + 1 : 2 * pair;      // (odd row-tile count: the last pair repeats)
-        d_in = wino_rsrc(p.actv + (long long)ib * p.K * HW, (unsigned)p.K * HW * 4u);
+        d_in = wino_rsrc(p.actv + (long long)ib * p.K * APL, (unsigned)p.K * APL * 4u);
         d_h0 = wino_rsrc(p.wpk + (long long)r0 * nks * 2048, (unsigned)nks * 8192u);
         d_h1 = wino_rsrc(p.wpk + (long long)r1 * nks * 2048, (unsigned)nks * 8192u);
         if (p.wsty) {
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
         } else {
             wino_dma16(va, dA1, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u + ADW * 4u);
             islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
-            so_in += 16u * (unsigned)HW;
+            so_in += 16u * (unsigned)APL;
             so_a += 8192u;
         }
     };
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_kernel(const WinoAceParams p)
 // level; a lane's four B rows are four conflict-free ds_read_b128.  Every task but the last of a sample fills all 64 slots.
 // Same arithmetic per quad as the tile kernel: bit-identical results (tests/test_hip_wino.py).
 namespace winog {
-constexpr int NPD = 8, PDW = 4096, NST = 5, ADW2 = 2 * wino::ADW, SDW = PDW + ADW2, NLD = NPD + 2;
+constexpr int NPD = 2, PDW = 4096, NST = 5, ADW2 = 2 * wino::ADW, SDW = PDW + ADW2, NLD = NPD + 2;
 constexpr int LDS_BYTES = NST * SDW * 4;                         // 128 KB
 }  // namespace winog
 
@@ -939,13 +947,17 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
     constexpr unsigned SB = winog::SDW * 4, RING = WA_NST * SB;
     const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
 
-    // ---- issue side: thread = (quad slot, patch column, two patch rows) of every channel of the k-step ------------------------------
-    const int islot_q = (tid & 255) >> 2, ipx = tid & 3, irs = tid >> 8;
-    unsigned vb0 = 0x80000000u, vb1 = 0x80000000u;                  // byte offsets of this thread's elements of patch rows irs, irs + 2
+    // ---- issue side: lane = quad slot; wave w fetches patch row (w & 3) of channels (w >> 2) and 2 + (w >> 2) of the k-step: a row of
+    //      a quad's patch -- columns x - 1 .. x + 2 -- is ONE 16-byte unit of the padded plane (4-byte aligned), a wave instruction
+    //      fills one [64 slots][4 floats] line of the stage.  Two patch + two A instructions per wave and k-step (the first version
+    //      issued eight 4-byte patch DMAs per thread: ten vector-memory instructions per k-step next to 32 MFMAs). -----------------
+    const int AP = wino_apitch(p.W), APL = p.H * AP;
+    const int irow = wave & 3;
+    unsigned vb = 0x80000000u;                                  // byte offset of this lane's unit (row irow of its slot's patch) in a plane
     const unsigned va = (unsigned)tid * 16u;
     wino_u32x4 d_in, d_h0, d_h1, d_s0, d_s1, dA0, dA1;
     unsigned so_in = 0, so_a = 0;
-    const unsigned HW4 = (unsigned)HW * 4u;
+    const unsigned APL4 = (unsigned)APL * 4u;
     auto task_quad = [&](int t, int slot) {                       // entry `slot` of task t's chunk (clamped to the sample's list)
         const unsigned wk = p.work[t];
         const int b = wk & 31, chunk = (wk >> 5) & 2047;
@@ -954,15 +966,13 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
         qi = qi < nq ? qi : nq - 1;
         return p.gq[(long long)b * p.gq_cap + qi];
     };
-    auto issue_task = [&](int t, unsigned q) {                    // q = task_quad(t, islot_q), fetched a task ahead
+    auto issue_task = [&](int t, unsigned q) {                    // q = task_quad(t, lane), fetched a task ahead
         const unsigned wk = p.work[t];
         const int ib = wk & 31, pair = wk >> 16;
-        const int y = (int)(q >> 16) - 1 + irs, x = (int)(q & 0xFFFFu) - 1 + ipx;
-        const bool okx = (unsigned)x < (unsigned)p.W;
-        vb0 = (okx && (unsigned)y < (unsigned)p.H) ? (unsigned)(y * p.W + x) * 4u : 0x80000000u;
-        vb1 = (okx && (unsigned)(y + 2) < (unsigned)p.H) ? (unsigned)((y + 2) * p.W + x) * 4u : 0x80000000u;
+        const int y = (int)(q >> 16) - 1 + irow, x = (int)(q & 0xFFFFu);      // (x - 1 + WINO_AXOFF: always inside the padded row)
+        vb = (unsigned)y < (unsigned)p.H ? (unsigned)(y * AP + x + WINO_AXOFF - 1) * 4u : 0x80000000u;
         const int r0 = 2 * pair, r1 = 2 * pair + 1 < p.nrt ? 2 * pair + 1 : 2 * pair;      // (odd row-tile count: the last pair repeats)
-        d_in = wino_rsrc(p.actv + (long long)ib * p.K * HW, (unsigned)p.K * HW * 4u);
+        d_in = wino_rsrc(p.actv + (long long)ib * p.K * APL, (unsigned)p.K * APL * 4u);
         d_h0 = wino_rsrc(p.wpk + (long long)r0 * nks * 2048, (unsigned)nks * 8192u);
         d_h1 = wino_rsrc(p.wpk + (long long)r1 * nks * 2048, (unsigned)nks * 8192u);
         if (p.wsty) {
@@ -975,16 +985,16 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
         so_a = 0;
     };
     unsigned islot = lds0;
-    // element e = i * 512 + tid of a stage's patch image: channel i >> 1, patch row 2 (i & 1) + (tid >> 8), quad slot, column
+    // stage layout [channel][patch row][slot][4 floats]: line (c, row) at byte (4 c + row) * 1024
     auto issue_group = [&](auto gt) {
         constexpr int g = decltype(gt)::value;
-        const unsigned wb = islot + (unsigned)wave * 256u + (unsigned)g * 2048u;
-        wino_dma4((g & 1) ? vb1 : vb0, d_in, so_in + (unsigned)(g >> 1) * HW4, wb);
-        if constexpr (g == 6) wino_dma16(va, dA0, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u);
-        if constexpr (g == 7) {
+        if constexpr (g == 0) wino_dma16(vb, d_in, so_in + (unsigned)(wave >> 2) * APL4, islot + (unsigned)(4 * (wave >> 2) + irow) * 1024u);
+        if constexpr (g == 2) wino_dma16(vb, d_in, so_in + (unsigned)(2 + (wave >> 2)) * APL4, islot + (unsigned)(4 * (2 + (wave >> 2)) + irow) * 1024u);
+        if constexpr (g == 4) wino_dma16(va, dA0, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u);
+        if constexpr (g == 6) {
             wino_dma16(va, dA1, so_a, islot + WA_PDW * 4u + (unsigned)wave * 1024u + ADW * 4u);
             islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
-            so_in += 4u * HW4;
+            so_in += 4u * APL4;
             so_a += 8192u;
         }
     };
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
     };
     auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem) + (slot - lds0) / 4 + aoff) + lane; };
 
-    issue_task(lb, task_quad(lb, islot_q));
+    issue_task(lb, task_quad(lb, lane));
 #pragma unroll
     for (int j = 0; j < AHEAD; ++j) {
         issue_group(WInt<0>{}); issue_group(WInt<1>{}); issue_group(WInt<2>{}); issue_group(WInt<3>{});
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
         const int tnext = more ? tn : ct;                       // (past the end: this task again -- never read; keeps the vmcnt counting uniform)
         Ctx nxt = cur;
         if (more) nxt = task_ctx(tnext);                        // (in flight during this task's remaining k-steps)
-        const unsigned qnext = task_quad(tnext, islot_q);
+        const unsigned qnext = task_quad(tnext, lane);
         for (int c = KREAD; c < nks - AHEAD; ++c) kstep();
         if (nk > nks) {
             dA0 = d_s0;

@@ -14,10 +14,12 @@ hipError_t onehot_conv3x3(const uint8_t* lab, const float* table, const float* b
 hipError_t label_onehot_planes(const uint8_t* lab, float* out, int B, int H, int W, int kout, int k0, hipStream_t s);
 // Winograd ACE path: the SPADE hidden activations (K = 128 table channels, relu) + optionally the 20 one-hot planes behind them, written
 // only at the pixels some boundary quad's 4 x 4 patch reads (u5: the interior map of ace_classify, 255 = boundary pixel; nullptr:
-// every quad is a boundary quad).  out has kout planes per sample.  Shapes: spade_hidden_wq_supported (W a power of two >= 32, ...).
+// every quad is a boundary quad).  out has kout planes per sample, each H rows of `pitch` floats with image column x at x + xoff
+// (pitch = 0: plain [H][W] planes; xoff > 0: the padded layout of the Winograd ACE kernels, conv_wino.h WINO_AXOFF -- the columns
+// left and right of the image must hold zeros, the kernel never writes them: the caller clears them).  Shapes: spade_hidden_wq_supported (H, W multiples of 32).
 bool spade_hidden_wq_supported(int H, int W);
 hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* table, const float* bias, float* out, int B, int H, int W,
-                           int kout, int onehot, hipStream_t s);
+                           int kout, int onehot, hipStream_t s, int pitch = 0, int xoff = 0);
 // `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
                                int K, int relu, float scale, hipStream_t s, int bf16 = 0, const uint8_t* need = nullptr,

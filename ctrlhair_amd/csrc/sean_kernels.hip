@@ -156,7 +156,8 @@ constexpr int LDS_BYTES = (T_FLOATS + A_FLOATS + K) * 4 + LP_BYTES + QF_BYTES + 
 __global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __restrict__ lab, const uint8_t* __restrict__ u5,
                                                                const float* __restrict__ table, const float* __restrict__ bias,
                                                                float* __restrict__ out, int B, int H, int W, int kout, int onehot,
-                                                               int tcs) {      // tcs = log2(TC)
+                                                               int tcs,        // tcs = log2(TC)
+                                                               int pitch, int xoff) {      // output planes: H rows of `pitch` floats, image column x at x + xoff
     using namespace hid;
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     float* T = hsm;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __
     const int LPW = TC + 4, LPH = TR + 2, QW = (TC >> 1) + 2, QH = (TR >> 1) + 2;
     const int txn = W >> tcs, tyn = H / TR, ntasks = B * txn * tyn;
     const long long HW = (long long)H * W;
+    const long long PL = (long long)H * pitch;                       // floats per output plane
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const int b = task / (txn * tyn), tr = task - b * (txn * tyn);
         const int y0 = (tr / txn) * TR, x0 = (tr % txn) << tcs;
@@ -253,17 +255,17 @@ __global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __
                 const int py = pid >> tcs, px = pid & (TC - 1);
                 const uint8_t* ll = Lp + py * LPW + px;
                 const int jc = ll[LPW + 1];
-                const long long pofs = (long long)(y0 + py) * W + x0 + px;
+                const long long pofs = (long long)(y0 + py) * pitch + xoff + x0 + px;
                 if (pass == 4) {                                     // one-hot planes K + 10 half .. K + 10 half + 9 (plane K + 19 stays zero)
-                    float* oh = out + ((long long)b * kout + K + half * 10) * HW + pofs;
+                    float* oh = out + ((long long)b * kout + K + half * 10) * PL + pofs;
                     if (valid) {
 #pragma unroll
-                        for (int q = 0; q < 10; ++q) oh[q * HW] = (half * 10 + q == jc && jc < 19) ? 1.f : 0.f;
+                        for (int q = 0; q < 10; ++q) oh[q * PL] = (half * 10 + q == jc && jc < 19) ? 1.f : 0.f;
                     }
                     continue;
                 }
                 const int k0 = pass * 32 + half * 16;
-                float* op = out + ((long long)b * kout + k0) * HW + pofs;
+                float* op = out + ((long long)b * kout + k0) * PL + pofs;
                 if (!__all((ent & 0x8000) != 0)) {
                     int jt[9];
 #pragma unroll
@@ -282,9 +284,9 @@ __global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __
                         a.x = a.x > 0.f ? a.x : 0.f; a.y = a.y > 0.f ? a.y : 0.f;
                         a.z = a.z > 0.f ? a.z : 0.f; a.w = a.w > 0.f ? a.w : 0.f;
                         if (valid) {                                 // (one running pointer: hoisted plane addresses cost two registers each)
-                            op[0] = a.x; op[HW] = a.y; op[2 * HW] = a.z; op[3 * HW] = a.w;
+                            op[0] = a.x; op[PL] = a.y; op[2 * PL] = a.z; op[3 * PL] = a.w;
                         }
-                        op += 4 * HW;
+                        op += 4 * PL;
                         __builtin_amdgcn_sched_barrier(0);           // one group of table reads in flight, not all of them (128 registers)
                     }
                 } else {
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __
                     for (int gq = 0; gq < 4; ++gq) {
                         const float4 a = *reinterpret_cast<const float4*>(ar + gq * 4);
                         if (valid) {
-                            op[0] = a.x; op[HW] = a.y; op[2 * HW] = a.z; op[3 * HW] = a.w;
+                            op[0] = a.x; op[PL] = a.y; op[2 * PL] = a.z; op[3 * PL] = a.w;
                         }
-                        op += 4 * HW;
+                        op += 4 * PL;
                     }
                 }
             }
@@ -304,14 +306,16 @@ __global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __
 }
 
 bool spade_hidden_wq_supported(int H, int W) {
-    if (H % 32 || W % 32 || H < 32 || W < 32 || (W & (W - 1))) return false;
-    const int TC = W < 512 ? W : 512, TR = 1024 / TC;
+    if (H % 32 || W % 32 || H < 32 || W < 32) return false;
+    const int TC = (W & (W - 1)) ? 32 : (W < 512 ? W : 512), TR = 1024 / TC;      // (widths that are not powers of two: tiles of 32 x 32)
     return H % TR == 0;
 }
 
 hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* table, const float* bias, float* out, int B, int H, int W,
-                           int kout, int onehot, hipStream_t s) {
+                           int kout, int onehot, hipStream_t s, int pitch, int xoff) {
     if (!spade_hidden_wq_supported(H, W) || kout < hid::K + (onehot ? 20 : 0)) return hipErrorInvalidValue;
+    if (pitch <= 0) { pitch = W; xoff = 0; }
+    if (xoff < 0 || (xoff > 0 && pitch < W + xoff + 1)) return hipErrorInvalidValue;
     static bool done[64] = {};
     static int cus[64] = {};
     int dev = 0;
@@ -325,12 +329,13 @@ hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* t
         cus[dev] = v;
         done[dev] = true;
     }
-    const int TC = W < 512 ? W : 512;
+    const int TC = (W & (W - 1)) ? 32 : (W < 512 ? W : 512);
     int tcs = 0;
     while ((1 << tcs) < TC) ++tcs;
     const int ntasks = B * (H * W / 1024);
     const int grid = ntasks < cus[dev] ? ntasks : cus[dev];
-    hipLaunchKernelGGL(spade_hidden_wq_kernel, dim3(grid), dim3(1024), hid::LDS_BYTES, s, lab, u5, table, bias, out, B, H, W, kout, onehot, tcs);
+    hipLaunchKernelGGL(spade_hidden_wq_kernel, dim3(grid), dim3(1024), hid::LDS_BYTES, s, lab, u5, table, bias, out, B, H, W, kout, onehot, tcs,
+                       pitch, xoff);
     return hipGetLastError();
 }
 

@@ -483,7 +483,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a) continue;
                 const size_t r = (size_t)ms / a->res_div;
-                if (ahead_full) actv_ahead[a->index] = B.falloc((size_t)mb * r * r * (HID + 20));
+                if (ahead_full) actv_ahead[a->index] = B.falloc((size_t)mb * r * (r + 64) * (HID + 20));
                 if (a->styled) lut_ahead[a->index] = B.falloc(npad_b * 18 * a->C);
             }
         splitk_side = B.falloc((size_t)splitk_cap);
@@ -562,7 +562,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         midmax = std::max(midmax, MB * S * S * (use_sh16 ? 64 : 16));
     }
     lut = static_cast<float*>(B.dalloc(lutmax * 4));
-    actv = static_cast<float*>(B.dalloc(MB * S * S * (HID + 20) * 4));      // (+ 20 one-hot planes: Winograd ACE path, <= S/2)
+    actv = static_cast<float*>(B.dalloc(MB * S * S * HID * 4));      // (direct kernels; the Winograd ACE levels own padded buffers, actv_lvl)
     h0 = static_cast<float*>(B.dalloc(h0max * 4));
     hs = static_cast<float*>(B.dalloc(h0max * 4));
     dx = static_cast<float*>(B.dalloc(midmax * 4));
@@ -571,7 +571,11 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     xa = static_cast<float*>(B.dalloc(outmax * 4));
     xb = static_cast<float*>(B.dalloc(outmax * 4));
     // ---- Winograd ACE path: boundary-quad lists per level, task lists per (level, row tiles), per-sample style images ------
-    for (int k = 0; k < 6; ++k) wq_level[k] = WinoLevel();
+    for (int k = 0; k < 6; ++k) {
+        wq_level[k] = WinoLevel();
+        actv_lvl[k] = nullptr;
+    }
+    pad_state.clear();
     wsty = nullptr;
     if (wino && !use_sh16) {
         size_t wsty_max = 0;
@@ -610,6 +614,11 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 if (a->styled) wsty_max = std::max(wsty_max, (size_t)mb * nrt * 5 * 2048);
             }
         if (wsty_max) wsty = B.falloc(wsty_max);
+        for (int k = 0; k < 6; ++k)
+            if (wq_level[k].qlist) {
+                const size_t r = (size_t)ms >> k;
+                actv_lvl[k] = B.falloc((size_t)mb * r * wino_apitch((int)r) * (HID + 20));
+            }
     }
     prof_stats_cap = 16384;
     prof_stats_used = 0;
@@ -988,15 +997,21 @@ struct Runner {
         if (m.use_sh16)
             check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2, need, tile_cnt,
                                       (m.dbg & 33554432) ? 1 : 0), "mlp_shared");
-        else if (use_wino_ace(a, r) && m.hidden_wq && r >= 128 && spade_hidden_wq_supported(r, r)) {
-            // hidden activations (+ the one-hot planes of a styled ACE) in one persistent pass, whole 64-byte groups of pixels that a
-            // boundary quad's patch touches only (sean_kernels.hip; below 128 pixels its 88 KB table prologue costs more than it saves)
-            check(spade_hidden_wq(lab, u5, a.actv_table, a.actv_bias, actv_buf, B, r, r, a.styled ? HID + 20 : HID, a.styled ? 1 : 0, s),
-                  "mlp_shared (boundary-quad patches)");
-        } else if (use_wino_ace(a, r) && a.styled) {
-            // Winograd ACE path: the one-hot label planes behind the hidden channels feed the style k-steps (conv_wino.h)
-            check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, nullptr, HID + 20), "mlp_shared");
-            check(label_onehot_planes(lab, actv_buf, B, r, r, HID + 20, HID, s), "one-hot planes");
+        else if (use_wino_ace(a, r)) {
+            // Winograd ACE path: hidden activations (+ the one-hot planes of a styled ACE, which feed the style k-steps) in one
+            // persistent pass into the padded planes the ACE kernels read (conv_wino.h WINO_AXOFF), whole 64-byte groups of pixels
+            // that a boundary quad's patch touches only (sean.hidden_wq = 0: every pixel)
+            // the zero columns left and right of the image: the kernel never writes them, so they are cleared whenever the buffer
+            // changes its geometry (first use, another image size) -- per-pixel pad stores cost 200 us per 512^2 launch
+            const int kout = a.styled ? HID + 20 : HID;
+            const long long geo = ((long long)r << 20) | ((long long)kout << 8) | 1;
+            auto it = m.pad_state.find(actv_buf);
+            if (it == m.pad_state.end() || it->second != geo) {
+                check(hipMemsetAsync(actv_buf, 0, (size_t)m.max_batch * kout * r * wino_apitch(r) * sizeof(float), s), "hidden activations: zero pads");
+                m.pad_state[actv_buf] = geo;
+            }
+            check(spade_hidden_wq(lab, m.hidden_wq ? u5 : nullptr, a.actv_table, a.actv_bias, actv_buf, B, r, r, kout, a.styled ? 1 : 0, s,
+                                  wino_apitch(r), WINO_AXOFF), "mlp_shared (boundary-quad patches)");
         } else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, need), "mlp_shared");
         return q;
@@ -1092,20 +1107,26 @@ struct Runner {
         const int* tile_cnt = (SL && m.use_sh16 && !compact) ? SL->cnt : nullptr;
         AcePrep q;
         const uint8_t* u5 = (wino_ace && wp.L && wp.S) ? wp.S->u5 : nullptr;
+        float* abuf = m.actv;                      // hidden activations: the Winograd ACE levels own padded buffers (pads zeroed once per size)
+        if (wino_ace) {
+            int lk = 0;
+            while ((1 << lk) < a.res_div) ++lk;
+            if (m.actv_lvl[lk]) abuf = m.actv_lvl[lk];
+        }
         if (ahead) {
             q = prepared[a.index];
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else if (luts_ready && a.styled) {
-            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
+            (void)ace_prepare(a, labfull, codes, st, abuf, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
             q = prepared[a.index];
-            q.actv = m.actv;
+            q.actv = abuf;
         } else if (ahead_luts && a.styled) {
-            (void)ace_prepare(a, labfull, codes, st, m.actv, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
+            (void)ace_prepare(a, labfull, codes, st, abuf, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
             q = prepared[a.index];
-            q.actv = m.actv;
+            q.actv = abuf;
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else {
-            q = ace_prepare(a, labfull, codes, st, m.actv, m.lut, m.splitk_ws, true, 3, need, tile_cnt, u5);
+            q = ace_prepare(a, labfull, codes, st, abuf, m.lut, m.splitk_ws, true, 3, need, tile_cnt, u5);
         }
         if (wino_ace && wp.L) {
             const double xpp = 4.0 * a.C / (x_up ? 4.0 : 1.0), opp = 4.0 * a.C;

@@ -145,6 +145,8 @@ struct SeanModel {
     // 512^2 13.8 / 9.6, 256^2 8.1 / 9.6, 128^2 7.9 / 7.1, 64^2 4.1 / 4.8
     int wino_tile_h(int r) const { return (wino_th == 16 || wino_th == 32) ? (r % wino_th ? 16 : wino_th) : ((r >= 512 || r == 128) ? 32 : 16); }
     WinoLevel wq_level[6];
+    float* actv_lvl[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per Winograd ACE level: hidden activations in the padded layout (conv_wino.h WINO_AXOFF)
+    std::map<const float*, long long> pad_state;   // geometry (size, planes) a padded buffer's zero columns were last cleared for
     float* wsty = nullptr;
     int* prof_stats = nullptr;                 // profiling: snapshots of the work-list statistics of sparse launches (16 B each)
     int prof_stats_cap = 0, prof_stats_used = 0;

@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
         int tot_h[8];
         CK(hipMemcpy(tot_h, d_tot, 32, hipMemcpyDeviceToHost));
         const long long px = (long long)B * r * r, xpx = c.x_up ? px / 4 : px;
-        float* d_actv = dev_rand(px * K, 1);
+        float* d_actv = dev_rand((long long)B * r * wino_apitch(r) * K, 1);      // padded planes (conv_wino.h WINO_AXOFF)
         float* d_wpk = dev_rand((long long)nrt * 32 * 2048, 2);
         float* d_wsty = c.styled ? dev_rand((long long)B * nrt * 5 * 2048, 3) : nullptr;
         float* d_x = dev_rand(xpx * C, 4);
