@@ -74,7 +74,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(ngf, S, sd_np, budget_s=45.0, weights=None):
+def cpu_baseline(ngf, S, sd_np, budget_s=120.0, weights=None, b16=False):
     """The oracle (torch fp32 CPU restatement of the reference path) timed on this host's cores on a bounded sample of the same
     workload (SURVEY.md 8d asks for Config 2 at B=1 and B=16 and for Config 1; B=16 of the dense reference graph takes minutes
     here, so the sample is: one 128x128 warm-up, single-image forwards at the benchmark size while the budget lasts (median), and
@@ -103,7 +103,12 @@ def cpu_baseline(ngf, S, sd_np, budget_s=45.0, weights=None):
                      f'{torch.__version__} CPU, after a 128x128 warm-up',
            'b1_seconds': [round(t, 2) for t in times],
            'b16': {'run': False, 'estimate_seconds_per_batch': round(16 * med, 1),
-                   'why': 'no cross-sample op in the graph: a batch of 16 is 16 of these forwards; not run inside the bench budget'}}
+                   'why': 'no cross-sample op in the graph: a batch of 16 is 16 of these forwards; run it with --cpu-b16 (minutes)'}}
+    if b16:
+        t = time.time()
+        O.generator_forward(sd, P.blocky_labels(16, S), P.style_codes(16), P.noise_planes(16, S, ngf), ngf, weights_cache=wc)
+        dt = time.time() - t
+        out['b16'] = {'run': True, 'seconds_per_batch': round(dt, 1), 'images_per_s': round(16.0 / dt, 4)}
     if weights is not None:
         try:
             from ctrlhair_amd.ui.backend import Backend
@@ -198,20 +203,41 @@ class PipelineJob:
     def step(self, out):
         self.pipe.edit(self.img, out=out)
 
-    # algorithmic GFLOP per image of each stage (generator: the dense evaluation after the LUT reformulations)
+    # dense GFLOP per image of each stage (generator: the dense evaluation after the LUT reformulations) and the share of
+    # them the matrix cores execute on the exact-f32 path where it is known analytically: Winograd F(2x2,3x3) runs 16 of 36 products
+    # of a 3x3 stride-1 conv (Zencoder: the 256 -> 512 conv and the four phase convs of the ConvTranspose; BiSeNet / shape decoder:
+    # their 3x3 stride-1 layers, the rest direct).  The generator's share is MEASURED (device-side counters of the work lists).
     STAGE_GFLOP = {'parse': 27.5, 'shape_encode': 4.9, 'zencoder': 169.6, 'shape_decode': 32.2, 'generator': 1083.8}
+    F32_EXECUTED_SHARE = {'parse': 0.72, 'shape_encode': 1.0, 'zencoder': 0.48, 'shape_decode': 0.50}
 
     def stages(self, path):
-        """Per-stage time and roofline of one edit (separate instrumented runs, torch events)."""
+        """Per-stage time and roofline of one edit (separate instrumented runs, torch events).  `frac` prices the FLOPs the matrix
+        cores EXECUTED (f16x3: three f16 products per f32 product) against the peak of the unit that ran them."""
+        import torch
         ms = self.pipe.stage_times(self.img)
+        gen_share = None
+        try:        # executed / dense of the generator stage on this workload's label maps (instrumented pass, not timed)
+            self.handle.profile_enable(True)
+            self.pipe.edit(self.img)
+            torch.cuda.synchronize()
+            self.handle.profile_enable(False)
+            allk = self.handle.profile_read(-1)
+            gen_share = allk['flops_executed'] / max(allk['flops'], 1.0)
+        except Exception:
+            gen_share = None
         out = {}
         for k, t in ms.items():
             row = {'ms': round(t, 3)}
             if k in self.STAGE_GFLOP:
-                tf = self.STAGE_GFLOP[k] * self.images / t            # GFLOP per ms = TFLOP/s
+                dense = self.STAGE_GFLOP[k] * self.images / t            # GFLOP per ms = TFLOP/s
                 f16 = path != 'f32'          # every stage's convs run on the f16 matrix cores unless the strict-f32 path is on
-                row.update({'algorithmic_tflops': round(tf, 1), 'bound': 'mfma',
-                            'peak_tflops': PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS})
+                share = gen_share if k == 'generator' else (1.0 if f16 else self.F32_EXECUTED_SHARE[k])
+                row.update({'dense_tflops': round(dense, 1), 'bound': 'mfma', 'peak_tflops': PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS})
+                if share is not None:
+                    ex = dense * share * (3.0 if path == 'f16x3' else 1.0)
+                    row.update({'executed_over_dense': round(share, 4), 'executed_tflops': round(ex, 1),
+                                'executed_share_source': 'work-list counters' if k == 'generator' else ('3 f16 products per f32 product' if f16 else 'analytic (layer mix)'),
+                                'frac': round(ex / row['peak_tflops'], 4)})
             else:
                 row['bound'] = 'launch latency (three small MLPs + slider arithmetic)'
             out[k] = row
@@ -253,10 +279,13 @@ def run_leg(job, args, dist, dev, world, steps=None, warmup=None, profile=True):
         step()
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    enq = []
     t0 = time.perf_counter()
     for i in range(steps):
         marks[i].record()            # on the launch stream; nothing waits on it inside the region
+        h0 = time.perf_counter()
         step()
+        enq.append((time.perf_counter() - h0) * 1e3)       # host time to enqueue the step's launches (no synchronisation inside)
     marks[steps].record()
     sync()
     dt = time.perf_counter() - t0
@@ -284,7 +313,7 @@ def run_leg(job, args, dist, dev, world, steps=None, warmup=None, profile=True):
         prof['steps'] = nprof
     value = world * job.images * steps / dt if steps else 0.0
     return {'value': round(value, 3), 'ms_per_step': round(dt / max(steps, 1) * 1e3, 3), 'step_ms': percentiles(step_ms),
-            'steps': steps, 'warmup': warmup}, prof
+            'host_enqueue_ms_per_step': percentiles(enq), 'steps': steps, 'warmup': warmup}, prof
 
 
 def roofline_block(path, prof, value, B, sustained):
@@ -393,6 +422,7 @@ def main():
     ap.add_argument('--workload', choices=('all', 'generator', 'pipeline'), default='all')
     ap.add_argument('--labels', choices=('blocky', 'face'), default='blocky', help='label maps of the top-level generator legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-b16', action='store_true', help='CPU baseline: also run ONE real batch-16 forward of the dense graph (minutes)')
     ap.add_argument('--only-headline', action='store_true', help='top-level leg only (no f16x3 / face-like / pipeline blocks)')
     ap.add_argument('--no-strict-fp32', action='store_true', help=argparse.SUPPRESS)      # (older tools: implies --only-headline)
     ap.add_argument('--path', choices=tuple(PATH_OPTION), default='f32',
@@ -482,21 +512,26 @@ def main():
         # per GPU), and at N = 1 the same job without the Winograd convs and without the SPADE-interior reduction (worst case)
         side = {}
         if args.path == 'f32' and (extras or world == 8) and user_batch == 0:
-            variants = [('configs3_b32_per_gpu', {'batch': 32})]
+            variants = [('configs3_b32_per_gpu', {'batch': 32}), ('configs4_bf16_b32_per_gpu', {'batch': 32, '_path': 'bf16'})]
             if extras:
                 variants += [('direct_convs_no_winograd', {'wino': 0}), ('dense_worst_case_no_interior_reduction', {'sparse': 0})]
             for name, over in variants:
                 a2 = argparse.Namespace(**vars(args))
+                vpath = over.get('_path', 'f32')
                 for k, v in over.items():
-                    setattr(a2, k, v)
+                    if not k.startswith('_'):
+                        setattr(a2, k, v)
                 try:
-                    job = GeneratorJob(a2, 'f32', dev, rank, sd, labels=args.labels)
+                    job = GeneratorJob(a2, vpath, dev, rank, sd, labels=args.labels)
                     r2, p2 = run_leg(job, a2, dist, dev, world, steps=max(5, args.steps // 3), warmup=max(2, args.warmup // 3))
-                    rb = roofline_block('f32', p2, r2['value'] / world, a2.batch, sustained)
+                    rb = roofline_block(vpath, p2, r2['value'] / world, a2.batch, sustained)
                     side[name] = {'value': r2['value'], 'unit': 'images/s', 'ms_per_step': r2['ms_per_step'], 'steps': r2['steps'],
-                                  'batch_per_gpu': a2.batch, 'global_batch': world * a2.batch,
+                                  'batch_per_gpu': a2.batch, 'global_batch': world * a2.batch, 'dtype': DTYPE[vpath],
                                   'all_mfma_convs': rb['all_mfma_convs'], 'dominant_kernel_tflops': rb['achieved'],
-                                  'executed_over_dense_spade': rb['executed_over_dense']}
+                                  'dominant_kernel_frac': rb['frac'], 'executed_over_dense_spade': rb['executed_over_dense']}
+                    if vpath == 'bf16':
+                        side[name]['note'] = ('BASELINE.json configs[4] per-GPU shape: bf16 operands on MFMA, f32 accumulate; tolerance 5e-2 '
+                                              '(tests/test_hip_sean_generator.py [bf16-32]); no reference counterpart (normalization.py:139,153 fail under autocast)')
                     job.close()
                     del job
                 except Exception as e:           # e.g. not enough memory for the 32-image handle next to another process
@@ -509,7 +544,8 @@ def main():
         res = {
             'metric': '512x512 edited images/sec (SEAN generator forward), whole job', 'value': head['value'], 'unit': 'images/s',
             'n_gpus': world, 'steps': head['steps'], 'warmup': head['warmup'], 'ms_per_step': head['ms_per_step'],
-            'step_ms': head['step_ms'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[args.path],
+            'step_ms': head['step_ms'], 'host_enqueue_ms_per_step': head['host_enqueue_ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[args.path],
             'data': f'synthetic ({args.labels} labels, tanh-normal codes, explicit noise planes; procedural calibrated weights, '
                     'no checkpoint ships with the reference)',
             'config': {'workload': f'SEAN generator forward only, batch {gen_batch}/GPU, {S}x{S}, ngf={ngf} (BASELINE.json {cfgn})',
@@ -571,7 +607,7 @@ def main():
                 res['pipeline'][path] = r
 
     if rank == 0 and do_gen and not args.no_cpu_baseline and world == 1:
-        res['cpu_baseline'] = cpu_baseline(ngf, S, sd, weights=all_weights)
+        res['cpu_baseline'] = cpu_baseline(ngf, S, sd, weights=all_weights, b16=args.cpu_b16)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -51,3 +51,8 @@ def test_default_line_carries_every_block():
     assert line['config']['conv_path'] == 'f32' and line['f32_class_f16x3']['value'] > 0
     assert set(line['pipeline']) >= {'f16x3', 'f32'} and 'stages' in line['pipeline']['f16x3']
     assert line['face_like_labels']['f32']['value'] > 0
+    assert line['host_enqueue_ms_per_step']['n'] == 3 and line['host_enqueue_ms_per_step']['median'] > 0
+    for leg in ('f16x3', 'f32'):         # stage rows: executed FLOPs against the peak of the unit that ran them -- never above it
+        for name, row in line['pipeline'][leg]['stages'].items():
+            if row.get('bound') == 'mfma':
+                assert 0 <= row['frac'] < 1 and 0 < row['executed_tflops'] <= row['peak_tflops'], (leg, name, row)      # (tiny here: 2 x 256^2)
