@@ -349,7 +349,7 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
     }
     if (std::strcmp(key, "sean.wino") == 0) {       // exact-f32 path: 3x3 convs as Winograd F(2x2,3x3) on the f32 matrix cores (conv_wino.h)
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino) must precede ch_finalize");
-        h->sean.wino = value != 0;
+        h->sean.wino = value < 0 ? 0 : (value > 2 ? 2 : value);      // 1 = F(2x2,3x3); 2 = + the ResBlock convs as F(4x4,3x3) (default)
         return CH_OK;
     }
     if (std::strcmp(key, "sean.lut_grouped") == 0) {    // exact-f32 path: 1 = the style LUTs of a chunk from one grouped GEMM launch (default)

@@ -1,0 +1,344 @@
+// conv_wino4.h -- 3x3 stride-1 zero-padded convolutions as Winograd F(4x4, 3x3) on the f32 matrix cores of gfx950
+// (v_mfma_f32_16x16x4_f32): 36 multiplies per 4x4 output tile and channel pair instead of 144 -- 2.25 per output pixel against 4 of
+// F(2x2, 3x3) (conv_wino.h) and 9 of the direct evaluation.  Serves the ResBlock convs conv_0 / conv_1 of the SEAN generator
+// (/root/reference/sean_codes/models/networks/architecture.py:82-91) from 32 x 32 pixels up (option "sean.wino" = 2).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        g: 3x3 kernel, d: 6x6 input patch, Y: 4x4 output tile   (Lavin & Gray, F(4x4,3x3))
+//   M[xi][row][tile] = sum_ci U[xi][row][ci] * V[xi][ci][tile]            (xi = 0..35: thirty-six independent GEMMs)
+//
+// Arithmetic: every product and sum is an IEEE f32 operation (transforms: f32 adds / fmas with the constants 2, 4, 5, 8; U = G g G^T
+// in double at ch_finalize, rounded once; contraction: the MFMA's f32 fma chain).  Unlike F(2x2,3x3), whose transforms only add,
+// the F(4x4,3x3) transforms amplify rounding: measured 1e-5 .. 3.5e-5 per layer against a double-precision conv at O(1)
+// activations (tests/test_winograd_model.py), 5-10x the error of the direct f32 sum itself, far inside the 1e-3 parity bound.
+//
+// Mapping to the hardware:
+//   * Persistent 512-thread blocks (grid = #CUs), 8 waves = 2 per SIMD.  Block task = a spatial tile of 32 x 32 pixels (8 x 8 tiles of
+//     4 x 4) x a row tile of 32 GEMM rows; wave w owns the 16-row half (w >> 2) for tile rows 2 (w & 3), 2 (w & 3) + 1 (16 tiles) and all
+//     36 xi: 36 accumulators of 16x16 (144 registers, in the accumulator half of the wave's 256).  One k-step = 4 input channels = 36
+//     MFMAs per wave.  (A wave with both halves -- 288 accumulator registers, one wave per SIMD -- was written first: hipcc keeps
+//     accumulators beyond 256 in arch VGPRs and shuttles every one of them through an AGPR quad around its MFMA.)
+//   * B operand: lane (n = lane & 15: tile, kk = lane >> 4: channel) transforms ITS 6 x 6 patch (18 LDS reads, 12 one-dimensional
+//     transforms of 12 operations) into the 36 B registers of the NEXT k-step while the MFMAs of this one run; the two waves that
+//     share the tiles (one per row half) each do it -- the price of the smaller wave tile.
+//   * Both operands by LDS-DMA in 16-byte units (buffer_load_dwordx4 ... lds, counted waits): the patch of the tile -- image columns
+//     x0 - 4 .. x0 + 35, rows y0 - 1 .. y0 + 32: units are aligned groups of 4 pixels, wholly inside or wholly outside the image (an
+//     outside unit's offset lies beyond num_records: zeros) -- and the k-step's 18 KB A image.  Stage = 40 KB, ring of four = all
+//     160 KB of LDS, the issue side three k-steps ahead as ONE flat sequence across the block's tasks; one barrier per k-step.
+//   * Epilogue: output transform in registers (100 operations per (row, tile)), bias / residual, 16-byte stores (8 lanes = one
+//     128-byte line).
+#pragma once
+#include "conv_wino.h"
+
+namespace chk {
+
+namespace wino4 {
+constexpr int TS = 32;                            // spatial tile (pixels), 8 x 8 output tiles of 4 x 4
+constexpr int PROWS = 34, PUN = 10;               // patch: 34 rows of 10 units (40 floats: image columns x0 - 4 .. x0 + 35)
+constexpr int PPL = PROWS * PUN;                  // units per channel plane (340)
+constexpr int PUNITS = 4 * PPL;                   // 1360 patch units per k-step
+constexpr int PSLOTS = 1408;                      // 2 rounds of 512 threads + 1 round of 384 (waves 0-5): 48 dummy slots
+constexpr int AUNITS = 1152;                      // A image: 18 x 64 lanes x 16 bytes: 2 rounds of 512 + 1 round of 128 (waves 0-1)
+constexpr int SUNITS = PSLOTS + AUNITS;           // 2560 units = 40 KB per stage
+constexpr int NST = 4;
+constexpr int LDS_BYTES = NST * SUNITS * 16;      // 163 840
+constexpr int ADW = AUNITS * 4;                   // A floats per (row tile, k-step)
+}  // namespace wino4
+
+struct Wino4Params {
+    const float* in;        // [B][Cin][H][W]
+    const float* wpk;       // pack_wino4_A image
+    float* out;             // [B][Cout][H][W]
+    int B, Cin, Cout, H, W; // H % 32 == 0, W % 32 == 0, Cin % 8 == 0, Cin >= 16
+    const float* bias;      // [Cout] or null
+    const float* res;       // [B][Cout][H >> res_up][W >> res_up] or null
+    int res_up;
+    // set by the launcher
+    int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
+};
+
+// image of (row tile rt, k-step s): [idx 0..17][lane][4 floats]; float e of idx holds fragment a = 4 idx + e = 36 m + xi (the nine
+// reads of a row half are contiguous):  U[xi][row = 32 rt + 16 m + (lane & 15)][ci = 4 s + (lane >> 4)],  U = G g G^T  (xi = 6 i + j)
+template <class F>
+std::vector<float> pack_wino4_A(int rows, int Cin, F get) {
+    static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int nrt = (rows + 31) / 32, nks = Cin / 4;
+    std::vector<float> dst((size_t)nrt * nks * wino4::ADW, 0.f);
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int s = 0; s < nks; ++s) {
+            float* img = dst.data() + ((size_t)rt * nks + s) * wino4::ADW;
+            for (int m = 0; m < 2; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = rt * 32 + m * 16 + (lane & 15), ci = 4 * s + (lane >> 4);
+                    if (row >= rows) continue;
+                    double g[3][3], t[6][3];
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) g[a][b] = get(row, ci, a * 3 + b);
+                    for (int i = 0; i < 6; ++i)
+                        for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = 0; j < 6; ++j) {
+                            const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                            const int a = m * 36 + i * 6 + j;
+                            img[((a >> 2) * 64 + lane) * 4 + (a & 3)] = (float)u;
+                        }
+                }
+        }
+    return dst;
+}
+
+// one-dimensional input transform  (B^T d):  rows of B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ void wino4_in1d(float d0, float d1, float d2, float d3, float d4, float d5, float& r0, float& r1, float& r2, float& r3,
+                                           float& r4, float& r5) {
+    const float a = __builtin_fmaf(-4.f, d2, d4), b = __builtin_fmaf(-4.f, d1, d3);       // d4 - 4 d2,  d3 - 4 d1
+    const float c = d4 - d2, t = d3 - d1;
+    r0 = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+    r1 = a + b;
+    r2 = a - b;
+    r3 = __builtin_fmaf(2.f, t, c);
+    r4 = __builtin_fmaf(-2.f, t, c);
+    r5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+}
+// one-dimensional output transform  (A^T m):  rows of A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void wino4_out1d(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2, float& y3) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = m0 + s1 + s2;
+    y1 = __builtin_fmaf(2.f, d2, d1);
+    y2 = __builtin_fmaf(4.f, s2, s1);
+    y3 = __builtin_fmaf(8.f, d2, d1) + m5;
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p) {
+    using namespace wino4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kk = lane >> 4;
+    const int mh = wave >> 2, tg = wave & 3;       // row half, tile group
+    const int G = gridDim.x;
+    const int lb = xcd_remap(blockIdx.x, G);
+    if (lb >= p.ntasks) return;
+    const int mytasks = (p.ntasks - lb + G - 1) / G;
+    const int nk = p.nks;
+    const int HW = p.H * p.W;
+    constexpr unsigned SB = SUNITS * 16u, RING = NST * SB;
+    const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
+
+    // task L -> (row tile, spatial tile), as conv_wino.h wino_task: 32 consecutive tasks share A images / patches through the XCD's L2
+    auto task_of = [&](int L, int& rt, int& tile) {
+        const int per = p.tbk * p.nrt;
+        const int tgr = L / per;
+        int r = L - tgr * per;
+        const int tgsz = min(p.tbk, p.ntiles - tgr * p.tbk);
+        const int rg = r / (tgsz * p.rb);
+        r -= rg * tgsz * p.rb;
+        const int rgsz = min(p.rb, p.nrt - rg * p.rb);
+        const int tl = r / rgsz;
+        rt = rg * p.rb + (r - tl * rgsz);
+        tile = tgr * p.tbk + tl;
+    };
+
+    // ---- issue side ------------------------------------------------------------------------------------------------------------
+    // patch unit u = tid + 512 i (i = 0, 1; i = 2: waves 0-5): plane u / 340, patch row (u % 340) / 10, unit column (u % 340) % 10
+    unsigned voff[3];
+    const unsigned va = (unsigned)tid * 16u;
+    int it = lb, is = 0;
+    wino_u32x4 d_in, d_a;
+    unsigned so_in = 0, so_a = 0;
+    auto issue_task = [&]() {
+        int irt, tile;
+        task_of(it, irt, tile);
+        const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, ib = tile / (p.ntx * p.nty);
+        const int y0 = ty * TS - 1, x0 = tx * TS - 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int u = i * 512 + tid;
+            const int k4 = u / PPL, rem = u - k4 * PPL;
+            const int py = rem / PUN, ux = rem - py * PUN;
+            const int y = y0 + py, x = x0 + 4 * ux;
+            const bool ok = u < PUNITS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
+        }
+        d_in = wino_rsrc(p.in + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
+        d_a = wino_rsrc(p.wpk + (long long)irt * p.nks * ADW, (unsigned)p.nks * ADW * 4u);
+        so_in = 0;
+        so_a = 0;
+    };
+    issue_task();
+    unsigned islot = lds0;
+    // pieces 0, 1: patch rounds; 2, 3: A rounds (straight-line, spread over the MFMA groups); issue_tail: the third patch round (waves
+    // 0-5) and the third A round (waves 0-1) + advance -- the only branches of the issue side, once per k-step behind the last group
+    auto issue_piece = [&](auto pt) {
+        constexpr int pc = decltype(pt)::value;
+        const unsigned wb = islot + (unsigned)wave * 1024u;
+        if constexpr (pc < 2) wino_dma16(voff[pc], d_in, so_in, wb + (unsigned)pc * 8192u);
+        else wino_dma16(va, d_a, so_a + (unsigned)(pc - 2) * 8192u, wb + PSLOTS * 16u + (unsigned)(pc - 2) * 8192u);
+    };
+    auto issue_tail = [&]() {
+        const unsigned wb = islot + (unsigned)wave * 1024u;
+        if (wave < 6) wino_dma16(voff[2], d_in, so_in, wb + 2u * 8192u);
+        if (wave < 2) wino_dma16(va, d_a, so_a + 2u * 8192u, wb + PSLOTS * 16u + 2u * 8192u);
+        islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
+        so_in += 16u * (unsigned)HW;
+        so_a += (unsigned)ADW * 4u;
+        if (++is == nk) {
+            if (it + G < p.ntasks) {
+                it += G;
+                is = 0;
+                issue_task();
+            } else {                   // past the end: keep re-issuing the last k-step (never read; keeps the vmcnt counting uniform)
+                is = nk - 1;
+                so_in -= 16u * (unsigned)HW;
+                so_a -= (unsigned)ADW * 4u;
+            }
+        }
+    };
+    auto issue_kstep = [&]() {
+        issue_piece(WInt<0>{}); issue_piece(WInt<1>{}); issue_piece(WInt<2>{}); issue_piece(WInt<3>{});
+        issue_tail();
+    };
+    // one k-step's DMAs of this wave (6 / 5 / 4) may still be in flight at the top of a k-step: the two stages it reads were issued before
+    auto wait_ring = [&]() {
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (wave < 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+
+    // ---- consumer side ---------------------------------------------------------------------------------------------------
+    f32x4 acc[36];
+#pragma unroll
+    for (int x = 0; x < 36; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tx = n & 7, tyl = 2 * tg + (n >> 3);
+    const int boff = kk * (PPL * 4) + (4 * tyl) * (PUN * 4) + 4 * tx + 3;      // this lane's patch origin (floats) inside a stage
+    auto stage = [&](unsigned slot) { return reinterpret_cast<const float*>(smem) + (slot - lds0) / 4; };
+    auto load_row = [&](const float* sp, int r, float (&d)[6]) {               // patch row r of the lane's tile: 1 + 4 + 1 floats
+        const float* q = sp + boff + r * (PUN * 4);
+        d[0] = q[0];
+        const f32x4 mid = *reinterpret_cast<const f32x4*>(q + 1);
+        d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w;
+        d[5] = q[5];
+    };
+    auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(stage(slot) + PSLOTS * 4) + 9 * mh * 64 + lane; };
+
+    issue_kstep();
+    issue_kstep();
+    issue_kstep();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float v[36], w[36];
+    {   // B fragments of the first k-step
+        const float* sp = stage(lds0);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float d[6];
+            load_row(sp, r, d);
+            wino4_in1d(d[0], d[1], d[2], d[3], d[4], d[5], v[6 * r], v[6 * r + 1], v[6 * r + 2], v[6 * r + 3], v[6 * r + 4], v[6 * r + 5]);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            wino4_in1d(v[j], v[6 + j], v[12 + j], v[18 + j], v[24 + j], v[30 + j], v[j], v[6 + j], v[12 + j], v[18 + j], v[24 + j], v[30 + j]);
+    }
+    unsigned rslot = lds0;
+    // one k-step: nine groups of four MFMAs on the B fragments `vc`; the next k-step's patch is read and transformed into `vx`
+    auto kstep = [&](float (&vc)[36], float (&vx)[36]) {
+        wait_ring();
+        __syncthreads();
+        const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
+        const f32x4* ap = a_ptr(rslot);
+        const float* spn = stage(nslot);               // (k-step q + 1 was verified together with q)
+        f32x4 F[2];
+        F[0] = ap[0];
+        float d[6];
+        auto group = [&](auto gt) {
+            constexpr int g = decltype(gt)::value;      // xi = 4 g .. 4 g + 3
+            if constexpr (g + 1 < 9) F[(g + 1) & 1] = ap[(g + 1) * 64];
+            if constexpr (g < 6) load_row(spn, g, d);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 c = F[g & 1];
+            acc[4 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, vc[4 * g], acc[4 * g], 0, 0, 0);
+            acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, vc[4 * g + 1], acc[4 * g + 1], 0, 0, 0);
+            acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, vc[4 * g + 2], acc[4 * g + 2], 0, 0, 0);
+            acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, vc[4 * g + 3], acc[4 * g + 3], 0, 0, 0);
+            if constexpr (g < 6)                        // row transform of patch row g (behind the MFMAs: its LDS reads land meanwhile)
+                wino4_in1d(d[0], d[1], d[2], d[3], d[4], d[5], vx[6 * g], vx[6 * g + 1], vx[6 * g + 2], vx[6 * g + 3], vx[6 * g + 4], vx[6 * g + 5]);
+            if constexpr (g >= 6) {                     // column transforms 2 (g - 6), 2 (g - 6) + 1, in place
+#pragma unroll
+                for (int j = 2 * (g - 6); j < 2 * (g - 6) + 2; ++j)
+                    wino4_in1d(vx[j], vx[6 + j], vx[12 + j], vx[18 + j], vx[24 + j], vx[30 + j], vx[j], vx[6 + j], vx[12 + j], vx[18 + j], vx[24 + j],
+                               vx[30 + j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g >= 2 && g < 6) issue_piece(WInt<g - 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(WInt<0>{}); group(WInt<1>{}); group(WInt<2>{}); group(WInt<3>{}); group(WInt<4>{}); group(WInt<5>{});
+        group(WInt<6>{}); group(WInt<7>{}); group(WInt<8>{});
+        issue_tail();
+        rslot = nslot;
+    };
+
+    for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
+        for (int cs = 0; cs < nk; cs += 2) {
+            kstep(v, w);          // (nks is even: the launcher)
+            kstep(w, v);
+        }
+        // ---- epilogue of task ct ---------------------------------------------------------------------------------------------
+        int crt, tile;
+        task_of(ct, crt, tile);
+        const int ttx = tile % p.ntx, tty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
+        const int y = tty * TS + 4 * tyl, x = ttx * TS + 4 * tx;
+        const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = crt * 32 + mh * 16 + 4 * kk + i, rc = row < p.Cout ? row : p.Cout - 1;
+            const float bsv = p.bias ? p.bias[rc] : 0.f;
+            f32x4 rr[4];                                 // residual of the (row, tile): loaded first, consumed after the transforms
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rr[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.res) {
+                const float* rp = p.res + ((long long)b * p.Cout + rc) * rHW;
+                if (p.res_up) {
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const float2 q2 = *reinterpret_cast<const float2*>(rp + ((y >> 1) + r2) * rW + (x >> 1));
+                        rr[2 * r2] = rr[2 * r2 + 1] = (f32x4){q2.x, q2.x, q2.y, q2.y};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rr[r] = *reinterpret_cast<const f32x4*>(rp + (y + r) * rW + x);
+                }
+            }
+            float t[4][6];                               // A^T M: rows 0..3, columns 0..5
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                wino4_out1d(acc[j][i], acc[6 + j][i], acc[12 + j][i], acc[18 + j][i], acc[24 + j][i], acc[30 + j][i], t[0][j], t[1][j], t[2][j], t[3][j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o0, o1, o2, o3;
+                wino4_out1d(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o0, o1, o2, o3);
+                const f32x4 o = {o0 + bsv + rr[r].x, o1 + bsv + rr[r].y, o2 + bsv + rr[r].z, o3 + bsv + rr[r].w};
+                if (row < p.Cout) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Cout + row) * HW + (y + r) * p.W + x) = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);           // (one (row, tile) at a time: the accumulators leave little room)
+        }
+#pragma unroll
+        for (int x2 = 0; x2 < 36; ++x2) acc[x2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's loads / stores share the counter with the ring: drain once per task
+    }
+}
+
+inline bool wino4_supported(int H, int W, int Cin) { return H % wino4::TS == 0 && W % wino4::TS == 0 && Cin % 8 == 0 && Cin >= 16; }
+inline void wino4_fill_launch(Wino4Params& p) {
+    p.nrt = (p.Cout + 31) / 32;
+    p.ntx = p.W / wino4::TS;
+    p.nty = p.H / wino4::TS;
+    p.ntiles = p.B * p.ntx * p.nty;
+    p.ntasks = p.ntiles * p.nrt;
+    p.nks = p.Cin / 4;
+    p.rb = p.nrt >= 4 ? 4 : p.nrt;
+    p.tbk = 32 / p.rb;
+}
+hipError_t conv_wino4_plain(Wino4Params p, hipStream_t s);      // conv_inst_wino4.hip
+
+}  // namespace chk

@@ -19,6 +19,7 @@
 #include "conv_sh16.h"
 #include "conv_pw.h"
 #include "conv_wino.h"
+#include "conv_wino4.h"
 #include "kernels.h"
 #include "sh16.h"
 
@@ -130,6 +131,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             } else {
                 cw.wpk = B.upload(pack_A(r.cout, r.cin, r.ks, r.ks == 3 ? CK_KS3 : CK_KS1, getw));
                 if (wino && r.ks == 3 && r.cin % 8 == 0) cw.wino = B.upload(pack_wino_A(r.cout, r.cin, getw));
+                if (wino >= 2 && r.ks == 3 && r.cin % 8 == 0 && r.cin >= 16) cw.wino4 = B.upload(pack_wino4_A(r.cout, r.cin, getw));
                 if (wino && r.ks == 1 && r.cin % 16 == 0) cw.pw = B.upload(pack_pw_A(r.cout, r.cin, [&](int row, int ci) { return getw(row, ci, 0); }));
             }
             cw.Cout = r.cout;
@@ -1359,6 +1361,26 @@ struct Runner {
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS, cin2 = w2 ? w2->Cin : 0;
+        if (m.wino >= 2 && !m.use_sh16 && w.wino4 && w.KS == 3 && !w2 && wino4_supported(r, r, w.Cin)) {
+            // Winograd F(4x4,3x3) on the exact-f32 matrix cores: 36 MFMA products per 4 x 4 tile and channel instead of 144
+            Wino4Params q{};
+            q.in = in;
+            q.wpk = w.wino4;
+            q.out = out;
+            q.B = B;
+            q.Cin = w.Cin;
+            q.Cout = w.Cout;
+            q.H = r;
+            q.W = r;
+            q.bias = w.bias;
+            q.res = res;
+            q.res_up = res_up;
+            next_flops_exec = 2.0 * w.Cout * w.Cin * 36.0 * npix / 16.0;
+            timed(0, 2.0 * w.Cout * w.Cin * 9.0 * npix,
+                  4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * 36.0),
+                  [&] { check(conv_wino4_plain(q, st), "conv (winograd F(4x4,3x3))"); });
+            return;
+        }
         if (use_wino(w, r) && !w2 && !(r == 16 && res_up)) {      // (16 x 16 sample pairs: residual at the same size only)
             // Winograd F(2x2,3x3) on the exact-f32 matrix cores: 16 MFMA products per quad and channel instead of 36
             WinoParams q{};

@@ -18,6 +18,7 @@ struct ConvW {
     float* bias = nullptr;
     float* wscale = nullptr;                    // f16x3 path: per-row 2^-k undoing the weight scaling (sh16.h)
     float* wino = nullptr;                      // exact-f32 path, 3x3: Winograd F(2x2,3x3) image U = G g G^T (conv_wino.h)
+    float* wino4 = nullptr;                     // exact-f32 path, 3x3, sean.wino = 2: Winograd F(4x4,3x3) image (conv_wino4.h)
     float* pw = nullptr;                        // exact-f32 path, 1x1: pack_pw_A image (conv_pw.h)
     int Cout = 0, Cin = 0, KS = 0;
 };
@@ -112,8 +113,9 @@ struct SeanModel {
     int n_aces = 0;
     // exact SPADE-interior reduction (ace_sparse.h): per resolution level (index = log2(res_div)) the classification buffers
     // and one work list per distinct number of 64-row tiles among the level's ACEs; gtab: [max_batch][19][2][C max]
-    int wino = 1;                              // option "sean.wino": exact-f32 path, 3x3 convs as Winograd F(2x2,3x3) on the f32
-                                               //   matrix cores (conv_wino.h); 0 = direct evaluation (conv_mfma.h)
+    int wino = 2;                              // option "sean.wino": exact-f32 path, 3x3 convs as Winograd on the f32 matrix cores:
+                                               //   1 = F(2x2,3x3) everywhere (conv_wino.h); 2 = the ResBlock convs from 32 x 32 pixels as
+                                               //   F(4x4,3x3) (conv_wino4.h), the rest F(2x2,3x3); 0 = direct evaluation (conv_mfma.h)
     float* zero_page = nullptr;                // 256 bytes of zeros
     // Winograd ACE path (conv_wino.h wino_ace_kernel): per resolution level the boundary quads of every 32 x 16 tile and one task
     // list per distinct row-tile count; per-sample style images of the ACE being run

@@ -250,7 +250,8 @@ def test_golden_batch16_full_size(hip_lib, path, B):
     assert d_ui <= tol and d_b2 <= tol
     for i in (3, 9, B - 1):
         one = _run(gen, labels[i:i + 1], codes[i:i + 1], noise[i:i + 1])
-        # the same f32 sums in another association (split-K follows the grid size, i.e. the batch): measured 0.6e-5 ... 1.1e-5
+        # the same f32 sums in another association (split-K follows the grid size, i.e. the batch; a single sample cannot use the
+        # sample-pair tiles of the 16-pixel level, and what differs there passes through the F(4x4,3x3) convs): measured 0.6e-5 ... 3e-5
         # (bf16 operands: the scale protocol may pick another power of two for another batch)
-        assert np.abs(one[0] - img[i]).max() <= (2e-5 if path != 'bf16' else 2e-2)
+        assert np.abs(one[0] - img[i]).max() <= (1e-4 if path != 'bf16' else 2e-2)
     gen.handle.close()

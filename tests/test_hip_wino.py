@@ -95,6 +95,39 @@ def test_winograd_equals_direct_ngf64(hip_lib):
     wino.handle.close()
 
 
+def test_winograd_f4x4_equals_direct(hip_lib):
+    """Option sean.wino = 2 (the default): the ResBlock 3x3 convs from 32 x 32 pixels as Winograd F(4x4,3x3) (conv_wino4.h; architecture.py:82-91),
+    everything else as with 1.  Its transforms multiply by 2, 4, 5, 8 and amplify rounding where F(2x2,3x3) only adds: measured here
+    against the direct evaluation (sean.wino = 0), against F(2x2,3x3) and against the oracle -- ngf = 64 at 256^2 (levels 32 ... 256 of
+    64 ... 1024 channels), ngf = 16 with a ragged row tile (Cout = 16 / 48), S = 96 (tiles of 32 on a 96-pixel level)."""
+    from ctrlhair_amd import procedural as P
+    from oracle import sean_oracle as O
+    for ngf, S, B in ((64, 256, 2), (16, 128, 3), (16, 96, 2)):
+        sd = P.sean_state_dict(0, ngf)
+        direct, f2, f4 = _gen(sd, B, S, 0), _gen(sd, B, S, 1), _gen(sd, B, S, 2)
+        codes, noise = P.style_codes(B, seed=71), P.noise_planes(B, S, ngf, seed=72)
+        sets = _label_sets(B, S)
+        for name in ('face', 'blocky', 'diag'):
+            a, b, c = _run(direct, sets[name], codes, noise), _run(f2, sets[name], codes, noise), _run(f4, sets[name], codes, noise)
+            d4, d2 = float(np.abs(a - c).max()), float(np.abs(a - b).max())
+            print(f'ngf{ngf} S={S} {name}: max |F(4x4) - direct| = {d4:.3e}, |F(2x2) - direct| = {d2:.3e}')
+            assert np.isfinite(c).all() and d4 <= 2e-4, (ngf, S, name)
+            assert np.array_equal(c, _run(f4, sets[name], codes, noise)), 'repeated call differs'
+        if ngf == 64:
+            ref = O.generator_forward(O.to_torch(sd), sets['face'][:1], codes[:1], noise[:1], ngf).numpy()
+            d = float(np.abs(_run(f4, sets['face'][:1], codes[:1], noise[:1]) - ref).max())
+            print(f'ngf64: max |F(4x4) - oracle| = {d:.3e}')
+            assert d <= 1e-3
+            f4.handle.profile_enable(True)
+            _run(f4, sets['face'], codes, noise)
+            f4.handle.profile_enable(False)
+            plain = f4.handle.profile_read(0)
+            f4.handle.profile_read(-1)
+            assert 0.25 - 1e-9 <= plain['flops_executed'] / plain['flops'] <= 0.45      # 36 / 144 on the F(4x4) levels (+ 1x1 shortcuts, 8 / 16-pixel levels)
+        for g in (direct, f2, f4):
+            g.handle.close()
+
+
 @pytest.mark.parametrize('S,mb', [(64, 8), (256, 9)])
 def test_grouped_style_luts_equal_per_ace_launches(hip_lib, S, mb):
     """Exact-f32 path, more than 64 (sample, label) columns: the style LUTs of all styled ACEs from ONE grouped GEMM launch

@@ -1,0 +1,118 @@
+// tools/wino4_bench.hip -- stand-alone check + timing of the Winograd F(4x4,3x3) exact-f32 MFMA conv (conv_wino4.h) against a naive
+// direct convolution on the GPU (double accumulation), over the ResBlock conv shapes of the ngf = 64 generator at 512^2, B = 16.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino4_bench.hip -o tools/wino4_bench.bin ; run on the GPU box.
+#include "../ctrlhair_amd/csrc/conv_inst_wino4.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace chk;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+static float frand(unsigned& s) {
+    s = s * 1664525u + 1013904223u;
+    return ((s >> 8) & 0xFFFF) / 32768.f - 1.f;
+}
+__global__ void ref_conv_kernel(const float* in, const float* w, const float* bias, const float* res, int res_up, float* out, int B, int Cin, int Cout,
+                                int H, int W) {
+    const long long n = (long long)B * Cout * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), co = (int)((i / ((long long)W * H)) % Cout), b = (int)(i / ((long long)W * H * Cout));
+        double acc = bias ? bias[co] : 0.f;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    acc += (double)w[((long long)co * Cin + ci) * 9 + t] * in[(((long long)b * Cin + ci) * H + yy) * W + xx];
+            }
+        if (res) acc += res[(((long long)b * Cout + co) * (H >> res_up) + (y >> res_up)) * (W >> res_up) + (x >> res_up)];
+        out[i] = (float)acc;
+    }
+}
+struct Shape { int B, Cin, Cout, H, res; const char* name; };   // res: 0 none, 1 same size, 2 upsampled
+
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const Shape all[] = {
+        {2, 16, 16, 32, 0, "tiny"}, {3, 32, 48, 64, 1, "tiny res, ragged rows"}, {1, 24, 32, 32, 2, "tiny res_up"}, {2, 64, 64, 96, 1, "96^2 res"},
+        {16, 1024, 1024, 32, 0, "G_middle conv_0"}, {16, 1024, 1024, 32, 1, "G_middle conv_1 (+x)"},
+        {16, 1024, 512, 64, 0, "up_0 conv_0"}, {16, 512, 512, 64, 1, "up_0 conv_1 (+xs)"},
+        {16, 512, 256, 128, 0, "up_1 conv_0"}, {16, 256, 256, 128, 1, "up_1 conv_1 (+xs)"},
+        {16, 256, 128, 256, 0, "up_2 conv_0"}, {16, 128, 128, 256, 1, "up_2 conv_1 (+xs)"},
+        {16, 128, 64, 512, 0, "up_3 conv_0"}, {16, 64, 64, 512, 1, "up_3 conv_1 (+xs)"},
+    };
+    double tot_ms = 0, tot_fl = 0;
+    for (const Shape& c : all) {
+        if (quick && c.B * (long long)c.H * c.H * c.Cout > (1 << 22)) continue;
+        const int B = c.B, Cin = c.Cin, Cout = c.Cout, H = c.H, W = c.H;
+        if (!wino4_supported(H, W, Cin)) { printf("%-28s not supported\n", c.name); continue; }
+        const size_t nin = (size_t)B * Cin * H * W, nout = (size_t)B * Cout * H * W;
+        const int rh = c.res == 2 ? H / 2 : H;
+        const size_t nres = c.res ? (size_t)B * Cout * rh * rh : 0;
+        unsigned seed = 12345u + Cin * 7 + Cout;
+        std::vector<float> hin(nin), hw((size_t)Cout * Cin * 9), hb(Cout), hres(nres);
+        const float ws = 1.f / sqrtf((float)Cin * 9.f);
+        for (auto& v : hin) v = frand(seed);
+        for (auto& v : hw) v = frand(seed) * ws;
+        for (auto& v : hb) v = frand(seed) * 0.1f;
+        for (auto& v : hres) v = frand(seed);
+        const float* wp = hw.data();
+        std::vector<float> pk = pack_wino4_A(Cout, Cin, [&](int row, int ci, int t) { return wp[((size_t)row * Cin + ci) * 9 + t]; });
+        float *d_in, *d_w, *d_b, *d_pk, *d_out, *d_ref, *d_res = nullptr;
+        CK(hipMalloc(&d_in, nin * 4 + 256)); CK(hipMalloc(&d_w, hw.size() * 4)); CK(hipMalloc(&d_b, Cout * 4));
+        CK(hipMalloc(&d_pk, pk.size() * 4)); CK(hipMalloc(&d_out, nout * 4)); CK(hipMalloc(&d_ref, nout * 4));
+        CK(hipMemcpy(d_in, hin.data(), nin * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_b, hb.data(), Cout * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_pk, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        if (nres) { CK(hipMalloc(&d_res, nres * 4)); CK(hipMemcpy(d_res, hres.data(), nres * 4, hipMemcpyHostToDevice)); }
+        CK(hipMemset(d_out, 0xFF, nout * 4));
+        Wino4Params p{};
+        p.in = d_in; p.wpk = d_pk; p.out = d_out; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+        p.bias = d_b; p.res = d_res; p.res_up = c.res == 2 ? 1 : 0;
+        CK(conv_wino4_plain(p, 0));
+        CK(hipDeviceSynchronize());
+        const bool big = (double)nout * Cin * 9 > 4e11;
+        const int Bref = big ? 1 : B;
+        double maxd = 0, maxr = 0;
+        for (int pass = 0; pass < (big ? 2 : 1); ++pass) {
+            const int b0 = pass == 0 ? 0 : B - 1;
+            hipLaunchKernelGGL(ref_conv_kernel, dim3(4096), dim3(256), 0, 0, d_in + (size_t)b0 * Cin * H * W, d_w, d_b,
+                               d_res ? d_res + (size_t)b0 * Cout * rh * rh : nullptr, p.res_up, d_ref, Bref, Cin, Cout, H, W);
+            CK(hipDeviceSynchronize());
+            const size_t nn = (size_t)Bref * Cout * H * W;
+            std::vector<float> ho(nn), hr(nn);
+            CK(hipMemcpy(ho.data(), d_out + (size_t)b0 * Cout * H * W, nn * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hr.data(), d_ref, nn * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nn; ++i) {
+                const double d = fabs((double)ho[i] - hr[i]);
+                if (!(d <= maxd)) maxd = d;
+                if (fabs(hr[i]) > maxr) maxr = fabs(hr[i]);
+            }
+        }
+        const double fl = 2.0 * B * H * W * (double)Cout * Cin * 9.0;
+        float ms = 0;
+        if (!quick) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            const int it = 5;
+            CK(conv_wino4_plain(p, 0));
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < it; ++i) CK(conv_wino4_plain(p, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= it;
+            if (B == 16) { tot_ms += ms * (strstr(c.name, "G_middle") ? 2 : 1); tot_fl += fl * (strstr(c.name, "G_middle") ? 2 : 1); }
+        }
+        const double exec = 2.0 * B * (H / 4) * (W / 4) * (double)Cout * Cin * 36.0;
+        printf("%-28s B%2d %4d->%4d %3d^2  maxdiff %.3e (max|ref| %.2f)  %s  %8.3f ms  dense %6.1f TF/s  executed %6.1f TF/s\n", c.name, B, Cin, Cout, H, maxd,
+               maxr, maxd <= 2e-4 * (maxr > 1 ? maxr : 1) ? "OK  " : "FAIL", ms, ms > 0 ? fl / ms * 1e-9 : 0.0, ms > 0 ? exec / ms * 1e-9 : 0.0);
+        fflush(stdout);
+        hipFree(d_in); hipFree(d_w); hipFree(d_b); hipFree(d_pk); hipFree(d_out); hipFree(d_ref);
+        if (d_res) hipFree(d_res);
+    }
+    if (!quick) printf("sum over the ResBlock convs of one step from 32^2 up (G_middle x2): %.2f ms, dense-equivalent %.1f TF/s\n", tot_ms, tot_fl / tot_ms * 1e-9);
+    return 0;
+}
