@@ -151,6 +151,9 @@ class GeneratorJob:
             opts['sean.ahead'] = args.ahead
         if args.overlap >= 0:
             opts['sean.overlap'] = args.overlap
+        for kv in (args.opt or []):              # experiments: any ch_set_option pair
+            k, v = kv.split('=')
+            opts[k] = int(v)
         if args.sparse_th:
             opts['sean.sparse_th'] = args.sparse_th
         if args.compact is not None:
@@ -431,6 +434,7 @@ def main():
                          'split-operand f16 MFMA, f32 accumulate; f16 / bf16 = single-term reduced-precision operands (configs[4])')
     ap.add_argument('--dbg', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--ahead', type=int, default=-1, help=argparse.SUPPRESS)       # option sean.ahead (experiments)
+    ap.add_argument('--opt', action='append', help=argparse.SUPPRESS)      # key=value pairs for ch_set_option (experiments)
     ap.add_argument('--overlap', type=int, default=-1, help='exact-f32 path: CUs of the side streams that run the HBM-bound kernels beside the '
                     'convs (option sean.overlap; 0 = serial schedule; default: the library\'s)')
     ap.add_argument('--sparse', type=int, default=1, help='0: every pixel through the SPADE convs (no interior reduction)')

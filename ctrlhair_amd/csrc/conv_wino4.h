@@ -328,6 +328,276 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
     }
 }
 
+// ================================================================================================================================
+// SPADE gamma/beta conv (normalization.py:249-257) + the style convs conv_gamma / conv_beta (:117-153,172-173) + the fused ACE
+// epilogue (:111-112,177-187; architecture.py:95) as F(4x4,3x3) over EVERY tile of a level -- for the levels where (nearly) every
+// tile holds a boundary pixel anyway (64 x 64 and below: sean_model.cpp), where the gather kernel of conv_wino.h runs 64 products
+// per 4 x 4 pixels and this one 36.  Same machinery as wino4_plain_kernel; what differs:
+//   * input = the padded hidden-activation planes of conv_wino.h (WINO_AXOFF: the image sits 32 columns into rows of W + 64
+//     floats, zeros left and right of it), K = 128 hidden channels (+ 20 one-hot planes: five style k-steps whose A images come
+//     from a per-SAMPLE buffer, wino4_style_pack; a sixth, all-zero image makes the k-step count even);
+//   * GEMM rows: a row tile = 16 channels; row r of the 16-row half m is (channel 16 rt + 8 m + 2 (r >> 2) + (r & 1), gamma | beta
+//     = (r >> 1) & 1), so that the four accumulator rows of a lane are gamma and beta of TWO channels;
+//   * the B fragments of a task's first k-step are recomputed from the staged patch after the epilogue instead of being carried
+//     through it (the modulation needs the registers).
+struct Wino4AceParams {
+    const float* actv;      // [B][K][H][wino_apitch(W)]: K = 128 (+ 20 one-hot planes when wsty is set)
+    const float* wpk;       // pack_wino4_A image of the SPADE rows (wino4_ace_row), 32 k-steps per row tile
+    const float* wsty;      // [B][nrt][6][wino4::ADW] per-sample style images (the sixth all zero), or null (unstyled ACE)
+    float* out;             // [B][C][H][W]
+    const float* x;         // [B][C][H >> x_up][W >> x_up]
+    int x_up, act;
+    int B, C, H, W;         // H % 32 == 0, W % 32 == 0, C % 2 == 0
+    const float *bias_g, *bias_b, *bn_a, *bn_d, *nv;
+    const float* noise;     // plane base of this ACE, sample stride noise_bstride, layout [W][H]
+    long long noise_bstride;
+    int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;      // set by the launcher
+};
+// GEMM row R of the packed SPADE image -> (channel, beta)
+__host__ __device__ inline void wino4_ace_row(int R, int& ch, int& beta) {
+    const int rt = R >> 5, m = (R >> 4) & 1, r = R & 15;
+    ch = rt * 16 + m * 8 + (r >> 2) * 2 + (r & 1);
+    beta = (r >> 1) & 1;
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino4_ace_kernel(const Wino4AceParams p) {
+    using namespace wino4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kk = lane >> 4;
+    const int mh = wave >> 2, tg = wave & 3;
+    const int G = gridDim.x;
+    const int lb = xcd_remap(blockIdx.x, G);
+    if (lb >= p.ntasks) return;
+    const int mytasks = (p.ntasks - lb + G - 1) / G;
+    const int nk = p.nks;                          // 32, or 38 with the style images
+    const int HW = p.H * p.W;
+    const int AP = wino_apitch(p.W), APL = p.H * AP;
+    constexpr unsigned SB = SUNITS * 16u, RING = NST * SB;
+    const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;
+    auto task_of = [&](int L, int& rt, int& tile) {
+        const int per = p.tbk * p.nrt;
+        const int tgr = L / per;
+        int r = L - tgr * per;
+        const int tgsz = min(p.tbk, p.ntiles - tgr * p.tbk);
+        const int rg = r / (tgsz * p.rb);
+        r -= rg * tgsz * p.rb;
+        const int rgsz = min(p.rb, p.nrt - rg * p.rb);
+        const int tl = r / rgsz;
+        rt = rg * p.rb + (r - tl * rgsz);
+        tile = tgr * p.tbk + tl;
+    };
+
+    // ---- issue side (as wino4_plain_kernel; rows outside the image: offset beyond num_records; columns: the planes' zero pads) ----
+    unsigned voff[3];
+    const unsigned va = (unsigned)tid * 16u;
+    int it = lb, is = 0;
+    wino_u32x4 d_in, d_a, d_s;
+    unsigned so_in = 0, so_a = 0;
+    auto issue_task = [&]() {
+        int irt, tile;
+        task_of(it, irt, tile);
+        const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, ib = tile / (p.ntx * p.nty);
+        const int y0 = ty * TS - 1, x0 = tx * TS - 4 + WINO_AXOFF;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int u = i * 512 + tid;
+            const int k4 = u / PPL, rem = u - k4 * PPL;
+            const int py = rem / PUN, ux = rem - py * PUN;
+            const int y = y0 + py;
+            const bool ok = u < PUNITS && (unsigned)y < (unsigned)p.H;
+            voff[i] = ok ? (unsigned)(k4 * APL + y * AP + x0 + 4 * ux) * 4u : 0x80000000u;
+        }
+        const int K = 128 + (p.wsty ? 20 : 0);
+        d_in = wino_rsrc(p.actv + (long long)ib * K * APL, (unsigned)K * APL * 4u);
+        d_a = wino_rsrc(p.wpk + (long long)irt * 32 * ADW, 32u * (unsigned)ADW * 4u);
+        if (p.wsty) d_s = wino_rsrc(p.wsty + ((long long)ib * p.nrt + irt) * 6 * ADW, 6u * (unsigned)ADW * 4u);
+        so_in = 0;
+        so_a = 0;
+    };
+    issue_task();
+    unsigned islot = lds0;
+    auto issue_piece = [&](auto pt) {
+        constexpr int pc = decltype(pt)::value;
+        const unsigned wb = islot + (unsigned)wave * 1024u;
+        if constexpr (pc < 2) wino_dma16(voff[pc], d_in, so_in, wb + (unsigned)pc * 8192u);
+        else wino_dma16(va, d_a, so_a + (unsigned)(pc - 2) * 8192u, wb + PSLOTS * 16u + (unsigned)(pc - 2) * 8192u);
+    };
+    auto issue_tail = [&]() {
+        const unsigned wb = islot + (unsigned)wave * 1024u;
+        if (wave < 6) wino_dma16(voff[2], d_in, so_in, wb + 2u * 8192u);
+        if (wave < 2) wino_dma16(va, d_a, so_a + 2u * 8192u, wb + PSLOTS * 16u + 2u * 8192u);
+        islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
+        so_in += 16u * (unsigned)APL;
+        so_a += (unsigned)ADW * 4u;
+        ++is;
+        if (is == 32 && nk > 32) {         // the style images of the task's sample follow the hidden channels
+            d_a = d_s;
+            so_a = 0;
+        }
+        if (is == nk) {
+            if (it + G < p.ntasks) {
+                it += G;
+                is = 0;
+                issue_task();
+            } else {                   // past the end: keep re-issuing the last k-step (never read; keeps the vmcnt counting uniform)
+                is = nk - 1;
+                so_in -= 16u * (unsigned)APL;
+                so_a -= (unsigned)ADW * 4u;
+            }
+        }
+    };
+    auto issue_kstep = [&]() {
+        issue_piece(WInt<0>{}); issue_piece(WInt<1>{}); issue_piece(WInt<2>{}); issue_piece(WInt<3>{});
+        issue_tail();
+    };
+    auto wait_ring = [&]() {
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (wave < 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+
+    // ---- consumer side ---------------------------------------------------------------------------------------------------
+    f32x4 acc[36];
+#pragma unroll
+    for (int x = 0; x < 36; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tx = n & 7, tyl = 2 * tg + (n >> 3);
+    const int boff = kk * (PPL * 4) + (4 * tyl) * (PUN * 4) + 4 * tx + 3;
+    auto stage = [&](unsigned slot) { return reinterpret_cast<const float*>(smem) + (slot - lds0) / 4; };
+    auto load_row = [&](const float* sp, int r, float (&d)[6]) {
+        const float* q = sp + boff + r * (PUN * 4);
+        d[0] = q[0];
+        const f32x4 mid = *reinterpret_cast<const f32x4*>(q + 1);
+        d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w;
+        d[5] = q[5];
+    };
+    auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(stage(slot) + PSLOTS * 4) + 9 * mh * 64 + lane; };
+    auto first_v = [&](unsigned slot, float (&vv)[36]) {          // B fragments of the k-step staged in `slot`
+        const float* sp = stage(slot);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float d[6];
+            load_row(sp, r, d);
+            wino4_in1d(d[0], d[1], d[2], d[3], d[4], d[5], vv[6 * r], vv[6 * r + 1], vv[6 * r + 2], vv[6 * r + 3], vv[6 * r + 4], vv[6 * r + 5]);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            wino4_in1d(vv[j], vv[6 + j], vv[12 + j], vv[18 + j], vv[24 + j], vv[30 + j], vv[j], vv[6 + j], vv[12 + j], vv[18 + j], vv[24 + j], vv[30 + j]);
+    };
+
+    issue_kstep();
+    issue_kstep();
+    issue_kstep();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned rslot = lds0;
+    auto kstep = [&](float (&vc)[36], float (&vx)[36]) {
+        wait_ring();
+        __syncthreads();
+        const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
+        const f32x4* ap = a_ptr(rslot);
+        const float* spn = stage(nslot);
+        f32x4 F[2];
+        F[0] = ap[0];
+        float d[6];
+        auto group = [&](auto gt) {
+            constexpr int g = decltype(gt)::value;
+            if constexpr (g + 1 < 9) F[(g + 1) & 1] = ap[(g + 1) * 64];
+            if constexpr (g < 6) load_row(spn, g, d);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 c = F[g & 1];
+            acc[4 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, vc[4 * g], acc[4 * g], 0, 0, 0);
+            acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, vc[4 * g + 1], acc[4 * g + 1], 0, 0, 0);
+            acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, vc[4 * g + 2], acc[4 * g + 2], 0, 0, 0);
+            acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, vc[4 * g + 3], acc[4 * g + 3], 0, 0, 0);
+            if constexpr (g < 6)
+                wino4_in1d(d[0], d[1], d[2], d[3], d[4], d[5], vx[6 * g], vx[6 * g + 1], vx[6 * g + 2], vx[6 * g + 3], vx[6 * g + 4], vx[6 * g + 5]);
+            if constexpr (g >= 6) {
+#pragma unroll
+                for (int j = 2 * (g - 6); j < 2 * (g - 6) + 2; ++j)
+                    wino4_in1d(vx[j], vx[6 + j], vx[12 + j], vx[18 + j], vx[24 + j], vx[30 + j], vx[j], vx[6 + j], vx[12 + j], vx[18 + j], vx[24 + j],
+                               vx[30 + j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g >= 2 && g < 6) issue_piece(WInt<g - 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(WInt<0>{}); group(WInt<1>{}); group(WInt<2>{}); group(WInt<3>{}); group(WInt<4>{}); group(WInt<5>{});
+        group(WInt<6>{}); group(WInt<7>{}); group(WInt<8>{});
+        issue_tail();
+        rslot = nslot;
+    };
+
+    for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
+        {
+            float v[36], w[36];
+            first_v(rslot, v);            // (the stage was verified by the last barrier: every k-step's barrier covers two stages)
+            for (int cs = 0; cs < nk; cs += 2) {
+                kstep(v, w);              // (nk is even: 32 or 38)
+                kstep(w, v);
+            }
+        }
+        // ---- ACE epilogue of task ct: this lane = tile (tyl, tx) x channels cA, cA + 1 ---------------------------------------------
+        int crt, tile;
+        task_of(ct, crt, tile);
+        const int ttx = tile % p.ntx, tty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
+        const int y = tty * TS + 4 * tyl, x = ttx * TS + 4 * tx;
+        const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
+        f32x4 nz[4];                                  // nz[c] = noise of column x + c, rows y .. y + 3 (plane layout [W][H])
+        const float* nzp = p.noise + (long long)b * p.noise_bstride + (long long)x * p.H + y;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nz[c] = *reinterpret_cast<const f32x4*>(nzp + (long long)c * p.H);
+        const int cA = crt * 16 + mh * 8 + 2 * kk;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                 // the lane's two channels: accumulator rows e (gamma) and 2 + e (beta)
+            const int ch = cA + e, cc = ch < p.C ? ch : p.C - 1;
+            const float gb = 1.f + p.bias_g[cc], bb = p.bias_b[cc], pa = p.bn_a[cc], pd = p.bn_d[cc], pn = p.nv[cc];
+            f32x4 xr[4];                              // x rows y .. y + 3, columns x .. x + 3
+            const float* xp = p.x + ((long long)b * p.C + cc) * xHW;
+            if (p.x_up) {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const float2 q2 = *reinterpret_cast<const float2*>(xp + ((y >> 1) + r2) * xW + (x >> 1));
+                    xr[2 * r2] = xr[2 * r2 + 1] = (f32x4){q2.x, q2.x, q2.y, q2.y};
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[r] = *reinterpret_cast<const f32x4*>(xp + (y + r) * xW + x);
+            }
+            float tg_[4][6], tb_[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                wino4_out1d(acc[j][e], acc[6 + j][e], acc[12 + j][e], acc[18 + j][e], acc[24 + j][e], acc[30 + j][e], tg_[0][j], tg_[1][j], tg_[2][j],
+                            tg_[3][j]);
+                wino4_out1d(acc[j][2 + e], acc[6 + j][2 + e], acc[12 + j][2 + e], acc[18 + j][2 + e], acc[24 + j][2 + e], acc[30 + j][2 + e], tb_[0][j],
+                            tb_[1][j], tb_[2][j], tb_[3][j]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float g0, g1, g2, g3, e0, e1, e2, e3;
+                wino4_out1d(tg_[r][0], tg_[r][1], tg_[r][2], tg_[r][3], tg_[r][4], tg_[r][5], g0, g1, g2, g3);
+                wino4_out1d(tb_[r][0], tb_[r][1], tb_[r][2], tb_[r][3], tb_[r][4], tb_[r][5], e0, e1, e2, e3);
+                const float nr[4] = {nz[0][r], nz[1][r], nz[2][r], nz[3][r]};
+                float o0 = (pa * xr[r].x + pn * nr[0] + pd) * (gb + g0) + (bb + e0);
+                float o1 = (pa * xr[r].y + pn * nr[1] + pd) * (gb + g1) + (bb + e1);
+                float o2 = (pa * xr[r].z + pn * nr[2] + pd) * (gb + g2) + (bb + e2);
+                float o3 = (pa * xr[r].w + pn * nr[3] + pd) * (gb + g3) + (bb + e3);
+                if (p.act != ACT_NONE) {
+                    o0 = apply_act(o0, p.act); o1 = apply_act(o1, p.act);
+                    o2 = apply_act(o2, p.act); o3 = apply_act(o3, p.act);
+                }
+                if (ch < p.C) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.C + ch) * HW + (y + r) * p.W + x) = (f32x4){o0, o1, o2, o3};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int x2 = 0; x2 < 36; ++x2) acc[x2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 inline bool wino4_supported(int H, int W, int Cin) { return H % wino4::TS == 0 && W % wino4::TS == 0 && Cin % 8 == 0 && Cin >= 16; }
 inline void wino4_fill_launch(Wino4Params& p) {
     p.nrt = (p.Cout + 31) / 32;
@@ -340,5 +610,9 @@ inline void wino4_fill_launch(Wino4Params& p) {
     p.tbk = 32 / p.rb;
 }
 hipError_t conv_wino4_plain(Wino4Params p, hipStream_t s);      // conv_inst_wino4.hip
+inline bool wino4_ace_supported(int H, int W, int C) { return H % wino4::TS == 0 && W % wino4::TS == 0 && C % 2 == 0; }
+hipError_t conv_wino4_ace(Wino4AceParams p, hipStream_t s);
+// wsty[b][rt][6][ADW] <- F(4x4,3x3) transform (G P G^T, f32) of the style LUT lut[(b*19 + j)][tap][gamma|beta][C]; rows as wino4_ace_row
+hipError_t wino4_style_pack(const float* lut, float* wsty, int B, int C, hipStream_t s);
 
 }  // namespace chk

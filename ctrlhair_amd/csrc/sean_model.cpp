@@ -288,6 +288,16 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                         return (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t] * (beta ? sb : sg);
                     };
                     a.spade_wino = B.upload(pack_wino_A(((C + 15) / 16) * 32, HID, getw));
+                    if (wino >= 2 && wino4_ace_max_r >= 32 && C % 2 == 0) {      // (any level can fall to <= wino4_ace_max_r pixels at a smaller image size)
+                        // F(4x4,3x3) image for the low-resolution levels: rows interleaved so that a lane holds gamma and beta of two channels
+                        auto getw4 = [&](int row, int ci, int t) {
+                            int c, beta;
+                            wino4_ace_row(row, c, beta);
+                            if (c >= C) return 0.f;
+                            return (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t] * (beta ? sb : sg);
+                        };
+                        a.spade_wino4 = B.upload(pack_wino4_A(((C + 15) / 16) * 32, HID, getw4));
+                    }
                 }
             }
             if (a.styled) {
@@ -578,9 +588,9 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         actv_lvl[k] = nullptr;
     }
     pad_state.clear();
-    wsty = nullptr;
+    wsty = wsty4 = nullptr;
     if (wino && !use_sh16) {
-        size_t wsty_max = 0;
+        size_t wsty_max = 0, wsty4_max = 0;
         for (const auto& b : blocks)
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a || !a->spade_wino) continue;
@@ -614,8 +624,10 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     L.works.push_back(w);
                 }
                 if (a->styled) wsty_max = std::max(wsty_max, (size_t)mb * nrt * 5 * 2048);
+                if (a->styled && a->spade_wino4) wsty4_max = std::max(wsty4_max, (size_t)mb * nrt * 6 * wino4::ADW);
             }
         if (wsty_max) wsty = B.falloc(wsty_max);
+        if (wsty4_max) wsty4 = B.falloc(wsty4_max);
         for (int k = 0; k < 6; ++k)
             if (wq_level[k].qlist) {
                 const size_t r = (size_t)ms >> k;
@@ -891,7 +903,7 @@ struct Runner {
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a) continue;
                 const int r = S / a->res_div;
-                if (use_wino_ace(*a, r)) (void)wino_prepare(*a, labels_at(labfull, a->res_div), r);
+                if (use_wino_ace(*a, r) && !use_wino4_ace(*a, r)) (void)wino_prepare(*a, labels_at(labfull, a->res_div), r);
             }
     }
 
@@ -920,6 +932,11 @@ struct Runner {
     }
     // u5 (Winograd ACE path): the level's interior map when the SPADE-interior reduction serves it -- the label-table kernel then
     // writes the hidden activations only where a boundary quad's patch reads them (nullptr: everywhere)
+    // SPADE conv of this ACE as F(4x4,3x3) over every tile of the level (conv_wino4.h): the low-resolution levels, where nearly every
+    // tile holds a boundary pixel -- no classification, no interior pass, hidden activations at every pixel
+    bool use_wino4_ace(const AceW& a, int r) const {
+        return use_wino_ace(a, r) && m.wino >= 2 && a.spade_wino4 && r <= m.wino4_ace_max_r && wino4_ace_supported(r, r, a.C) && (!a.styled || m.wsty4);
+    }
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
                         float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr,
                         const uint8_t* u5 = nullptr) {
@@ -1042,7 +1059,8 @@ struct Runner {
                 if (!a || (!full && !a->styled)) continue;
                 const int ra = S / a->res_div;
                 AcePrep e = ace_prepare(*a, labfull, codes, m.side, m.actv_ahead[a->index], m.lut_ahead[a->index], m.splitk_side, false,
-                                        full ? (luts_ready ? 2 : 3) : 1, nullptr, nullptr, use_wino_ace(*a, ra) ? level_u5(*a, ra) : nullptr);
+                                        full ? (luts_ready ? 2 : 3) : 1, nullptr, nullptr,
+                                        (use_wino_ace(*a, ra) && !use_wino4_ace(*a, ra)) ? level_u5(*a, ra) : nullptr);
                 if (luts_ready && a->styled) lut_entry(*a, e);          // (the grouped launch on the main stream built it)
                 prepared[a->index] = e;
                 check(hipEventRecord(m.ev_join[a->index], m.side), "join record");
@@ -1080,10 +1098,10 @@ struct Runner {
         const double npix = (double)B * r * r;
         // exact SPADE-interior reduction (ace_sparse.h): classification of the level + work list of this layer's row tiles.
         // f16x3 path: tile-skip mode, honoured by the wave-specialised kernel only (conv_sh16.h)
-        const bool wino_ace = use_wino_ace(a, r);
+        const bool wino_ace = use_wino_ace(a, r), f4_ace = use_wino4_ace(a, r);
         WinoPrep wp;
-        if (wino_ace) wp = wino_prepare(a, lab, r);
-        const SparseWork* sw = (wino_ace && wp.L) ? nullptr : sparse_prepare(a, lab, r);
+        if (wino_ace && !f4_ace) wp = wino_prepare(a, lab, r);
+        const SparseWork* sw = (wino_ace && (wp.L || f4_ace)) ? nullptr : sparse_prepare(a, lab, r);
         if (sw && m.use_sh16) {
             ConvParams t{};
             t.C = a.C;
@@ -1108,7 +1126,7 @@ struct Runner {
         if (compact) need = SL->need;
         const int* tile_cnt = (SL && m.use_sh16 && !compact) ? SL->cnt : nullptr;
         AcePrep q;
-        const uint8_t* u5 = (wino_ace && wp.L && wp.S) ? wp.S->u5 : nullptr;
+        const uint8_t* u5 = (wino_ace && wp.L && wp.S) ? wp.S->u5 : nullptr;      // (F(4x4,3x3) levels: every pixel is read)
         float* abuf = m.actv;                      // hidden activations: the Winograd ACE levels own padded buffers (pads zeroed once per size)
         if (wino_ace) {
             int lk = 0;
@@ -1129,6 +1147,34 @@ struct Runner {
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else {
             q = ace_prepare(a, labfull, codes, st, abuf, m.lut, m.splitk_ws, true, 3, need, tile_cnt, u5);
+        }
+        if (f4_ace) {
+            Wino4AceParams w{};
+            w.actv = q.actv;
+            w.wpk = a.spade_wino4;
+            w.wsty = (a.styled && q.lut) ? m.wsty4 : nullptr;
+            w.out = hout;
+            w.x = x;
+            w.x_up = x_up;
+            w.act = act;
+            w.B = B;
+            w.C = a.C;
+            w.H = r;
+            w.W = r;
+            w.bias_g = a.bias_g;
+            w.bias_b = a.bias_b;
+            w.bn_a = a.bn_a;
+            w.bn_d = a.bn_d;
+            w.nv = a.nv;
+            w.noise = noise + noff;
+            w.noise_bstride = (long long)nf;
+            const int ktot = w.wsty ? 152 : 128;             // (38 / 32 k-steps of four channels)
+            next_flops_exec = 2.0 * 32.0 * ((a.C + 15) / 16) * ktot * 36.0 * npix / 16.0;
+            timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * (HID + (a.styled ? 20 : 0)) + npix * a.C / (x_up ? 4.0 : 1.0) + npix * a.C), [&] {
+                if (w.wsty) check(wino4_style_pack(q.lut, m.wsty4, B, a.C, st), "wino4_style_pack");
+                check(conv_wino4_ace(w, st), "spade conv (winograd F(4x4,3x3), every tile)");
+            });
+            return;
         }
         if (wino_ace && wp.L) {
             const double xpp = 4.0 * a.C / (x_up ? 4.0 : 1.0), opp = 4.0 * a.C;

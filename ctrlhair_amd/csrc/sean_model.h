@@ -40,6 +40,7 @@ struct AceW {
                                                 //   shortcut's ace_s carries the 2^D aligning conv_s with conv_1, sean_model.cpp)
     float actv_scale = 1.f;                     // f16x3 path: SH16 scale of the SPADE hidden activations (from a table bound)
     float* spade_wino = nullptr;                // exact-f32 Winograd path: pack_wino_A image of the (gamma | beta) rows, 16-channel row tiles
+    float* spade_wino4 = nullptr;               // sean.wino = 2: the same rows as an F(4x4,3x3) image (conv_wino4.h wino4_ace_row), levels <= wino4_ace_max_r
     float* gconst = nullptr;                    // [19][gamma|beta][C]: SPADE gamma/beta of a pixel whose 5x5 label neighbourhood
                                                 //   is uniformly j (blend factor folded in, biases not) -- ace_sparse.h
 };
@@ -150,6 +151,8 @@ struct SeanModel {
     float* actv_lvl[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per Winograd ACE level: hidden activations in the padded layout (conv_wino.h WINO_AXOFF)
     std::map<const float*, long long> pad_state;   // geometry (size, planes) a padded buffer's zero columns were last cleared for
     float* wsty = nullptr;
+    float* wsty4 = nullptr;                    // per-sample F(4x4,3x3) style images of the ACE being run (conv_wino4.h)
+    int wino4_ace_max_r = 64;                  // option "sean.wino4_ace": largest level whose SPADE convs run as F(4x4,3x3) over EVERY tile (0 = none)
     int* prof_stats = nullptr;                 // profiling: snapshots of the work-list statistics of sparse launches (16 B each)
     int prof_stats_cap = 0, prof_stats_used = 0;
     int sparse = 1;                            // option "sean.sparse" (0 = every pixel through the conv)
