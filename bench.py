@@ -69,7 +69,7 @@ def csrc_sha():
     a mismatch means the committed traffic figure is stale and is not reported."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'ctrlhair_amd', 'csrc')
-    for f in ('conv_mfma.h', 'conv_wino.h', 'conv_ace_sparse.h', 'ace_sparse.h', 'conv_sh16.h', 'sh16.h'):
+    for f in ('conv_mfma.h', 'conv_wino.h', 'conv_wino4.h', 'conv_ace_sparse.h', 'ace_sparse.h', 'conv_sh16.h', 'sh16.h'):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
@@ -202,6 +202,7 @@ class PipelineJob:
         self.img = torch.from_numpy(P.synthetic_images(B, S, seed=11 + rank * B)).to(dev)
         self.handle = self.pipe.models.generator.handle
         self.images = B
+        self.scale = (S / 512.0) ** 2          # the per-image GFLOP figures below are quoted at 512 x 512; every stage is convolutional
         self.out_shape = (B, 3, S, S)
 
     def step(self, out):
@@ -233,7 +234,7 @@ class PipelineJob:
         for k, t in ms.items():
             row = {'ms': round(t, 3)}
             if k in self.STAGE_GFLOP:
-                dense = self.STAGE_GFLOP[k] * self.images / t            # GFLOP per ms = TFLOP/s
+                dense = self.STAGE_GFLOP[k] * self.scale * self.images / t            # GFLOP per ms = TFLOP/s
                 f16 = path != 'f32'          # every stage's convs run on the f16 matrix cores unless the strict-f32 path is on
                 share = gen_share if k == 'generator' else (1.0 if f16 else self.F32_EXECUTED_SHARE[k])
                 row.update({'dense_tflops': round(dense, 1), 'bound': 'mfma', 'peak_tflops': PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS})
@@ -335,8 +336,8 @@ def roofline_block(path, prof, value, B, sustained):
     else:
         executed, peak, pk = useful, PEAK_F32_MFMA_TFLOPS, 'f32'
         kname = ('wino_ace_gather_kernel (SPADE gamma/beta conv + style convs as Winograd F(2x2,3x3) on the exact-f32 matrix cores over '
-                 'tasks of 64 boundary quads, fused ACE epilogue; --wino 0: conv_ace_sparse_kernel) + conv_mfma_kernel<KS=3,...,EPI_ACE> '
-                 'for the ACEs below 32 pixels')
+                 'tasks of 64 boundary quads, fused ACE epilogue: the levels above 64 pixels) + wino4_ace_kernel (the same conv as F(4x4,3x3) over '
+                 'every tile: 32 / 64 pixels) + conv_mfma_kernel<KS=3,...,EPI_ACE> for the ACEs below 32 pixels; --wino 0: conv_ace_sparse_kernel')
     traffic = traffic_raw = detail = note = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes

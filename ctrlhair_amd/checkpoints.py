@@ -81,7 +81,8 @@ def _load_dirs(d: str) -> List[np.ndarray]:
 
 def reference_checkpoints(root: str = '.') -> Dict[str, object]:
     """-> {'sean','shape','color_gen','color_dis','color_rgb','bisenet': state dicts; 'texture_dirs','shape_dirs': lists;
-    '_origin': 'reference' -- HairEditor / EditPipeline default to the exact-f32 path for a dict that carries this tag}."""
+    '_origin': 'reference' -- HairEditor / EditPipeline default to the exact-f32 path for a dict that carries this tag; save_npz / load_npz keep it,
+    a caller that rebuilds the dict by hand must carry it over or pass f16x3 explicitly}."""
     import torch
     ct = load_checkpoint(os.path.join(experiment_dir(root, 'color_texture'), 'checkpoints'))
     sh = load_checkpoint(os.path.join(experiment_dir(root, 'shape'), 'checkpoints'))
@@ -198,6 +199,8 @@ def save_npz(path: str, weights: Dict[str, object]) -> None:
     for name in ('texture_dirs', 'shape_dirs'):
         for i, v in enumerate(weights.get(name, ())):
             flat[f'{name}/{i:02d}'] = np.asarray(v, dtype=np.float32)
+    if weights.get('_origin') is not None:      # the tag that decides the default arithmetic (exact f32 for a released checkpoint) survives the round trip
+        flat['_origin'] = np.asarray(str(weights['_origin']))
     np.savez(path, **flat)
 
 
@@ -206,6 +209,9 @@ def load_npz(path: str) -> Dict[str, object]:
     out: Dict[str, object] = {m: {} for m in MODELS}
     out['texture_dirs'], out['shape_dirs'] = [], []
     for key in sorted(d.files):
+        if key == '_origin':
+            out['_origin'] = str(d[key])
+            continue
         m, k = key.split('/', 1)
         if m in ('texture_dirs', 'shape_dirs'):
             out[m].append(d[key])

@@ -192,7 +192,7 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
                 dec[w][l].Cin = ci;
                 dec[w][l].KS = 3;
             } else {
-                dec[w][l] = make_conv(B, wv, B.vec(p + ".conv.bias", co), co, ci, 3, 1, 1);
+                dec[w][l] = make_conv(B, wv, B.vec(p + ".conv.bias", co), co, ci, 3, 1, 1, wino && (4 << l) >= 16);      // (output side 4 << l)
             }
             dec_ln[w][l].gamma = B.upload(gam);
             dec_ln[w][l].beta = B.upload(bet);
@@ -451,7 +451,7 @@ namespace {
 // conv (no bias) + eval BN folded: w' = w * s[co], b' = shift[co]
 // sh16: packed for the f16x3 kernels instead (stride 2: in the space-to-depth form)
 ConvLayer conv_bn(Builder& B, const std::string& conv, const std::string& bn, int cout, int cin, int ks, int stride,
-                  int pad, bool sh16 = false) {
+                  int pad, bool sh16 = false, bool want_wino = true) {
     auto w = B.vec(conv + ".weight", (size_t)cout * cin * ks * ks);
     std::vector<float> sc, sh;
     bn_fold(B, bn, cout, sc, sh);
@@ -459,7 +459,7 @@ ConvLayer conv_bn(Builder& B, const std::string& conv, const std::string& bn, in
         for (size_t i = 0; i < (size_t)cin * ks * ks; ++i) w[(size_t)o * cin * ks * ks + i] *= sc[o];
     if (sh16 && stride == 1) return make_conv_sh16(B, w, sh, cout, cin, ks, pad);
     if (sh16) return make_conv_s2d(B, w, sh, cout, cin, ks);        // stride 2: space-to-depth form
-    return make_conv(B, w, sh, cout, cin, ks, stride, pad);
+    return make_conv(B, w, sh, cout, cin, ks, stride, pad, want_wino);
 }
 }  // namespace
 
@@ -485,15 +485,15 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
             const int cin = i == 0 ? chans[L - 1] : chans[L], cout = chans[L];
             const int stride = (i == 0 && L > 1) ? 2 : 1;
             const std::string p = "cp.resnet.layer" + std::to_string(L) + "." + std::to_string(i);
-            bb.c1 = conv_bn(B, p + ".conv1", p + ".bn1", cout, cin, 3, stride, 1, use_sh16);
-            bb.c2 = conv_bn(B, p + ".conv2", p + ".bn2", cout, cout, 3, 1, 1, use_sh16);
+            bb.c1 = conv_bn(B, p + ".conv1", p + ".bn1", cout, cin, 3, stride, 1, use_sh16, wino != 0);
+            bb.c2 = conv_bn(B, p + ".conv2", p + ".bn2", cout, cout, 3, 1, 1, use_sh16, wino != 0);
             bb.has_down = (cin != cout || stride != 1);
-            if (bb.has_down) bb.down = conv_bn(B, p + ".downsample.0", p + ".downsample.1", cout, cin, 1, stride, 0, use_sh16);
+            if (bb.has_down) bb.down = conv_bn(B, p + ".downsample.0", p + ".downsample.1", cout, cin, 1, stride, 0, use_sh16, wino != 0);
         }
-    arm16_conv = conv_bn(B, "cp.arm16.conv.conv", "cp.arm16.conv.bn", 128, 256, 3, 1, 1, use_sh16);
-    arm32_conv = conv_bn(B, "cp.arm32.conv.conv", "cp.arm32.conv.bn", 128, 512, 3, 1, 1, use_sh16);
-    head32 = conv_bn(B, "cp.conv_head32.conv", "cp.conv_head32.bn", 128, 128, 3, 1, 1, use_sh16);
-    head16 = conv_bn(B, "cp.conv_head16.conv", "cp.conv_head16.bn", 128, 128, 3, 1, 1, use_sh16);
+    arm16_conv = conv_bn(B, "cp.arm16.conv.conv", "cp.arm16.conv.bn", 128, 256, 3, 1, 1, use_sh16, wino != 0);
+    arm32_conv = conv_bn(B, "cp.arm32.conv.conv", "cp.arm32.conv.bn", 128, 512, 3, 1, 1, use_sh16, wino != 0);
+    head32 = conv_bn(B, "cp.conv_head32.conv", "cp.conv_head32.bn", 128, 128, 3, 1, 1, use_sh16, wino != 0);
+    head16 = conv_bn(B, "cp.conv_head16.conv", "cp.conv_head16.bn", 128, 128, 3, 1, 1, use_sh16, wino != 0);
     {   // FFM convblk (1x1, 256 -> 256 on cat[fsp, fcp]) split into the two 128-channel halves (no concat buffer)
         auto w = B.vec("ffm.convblk.conv.weight", 256 * 256);
         std::vector<float> sc, sh;
@@ -507,7 +507,7 @@ std::string BiSeNetModel::build(const TensorStore& ts, int mb, int ms) {
         ffm_a = use_sh16 ? make_conv_sh16(B, wa, std::vector<float>(), 256, 128, 1, 0) : make_conv(B, wa, std::vector<float>(), 256, 128, 1, 1, 0);
         ffm_b = use_sh16 ? make_conv_sh16(B, wb, sh, 256, 128, 1, 0) : make_conv(B, wb, sh, 256, 128, 1, 1, 0);
     }
-    out_conv = conv_bn(B, "conv_out.conv.conv", "conv_out.conv.bn", 256, 256, 3, 1, 1, use_sh16);
+    out_conv = conv_bn(B, "conv_out.conv.conv", "conv_out.conv.bn", 256, 256, 3, 1, 1, use_sh16, wino != 0);
     {   // classifier: 19 rows (f16x3 path: padded to 20 with a zero row, C4 output of 5 groups)
         const auto wc = B.vec("conv_out.conv_out.weight", 19 * 256);
         out_cls = use_sh16 ? make_conv_sh16(B, wc, std::vector<float>(), 19, 256, 1, 0) : make_conv(B, wc, std::vector<float>(), 19, 256, 1, 1, 0);

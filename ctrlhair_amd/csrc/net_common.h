@@ -181,8 +181,11 @@ struct ConvLayer {
 };
 
 // w: [Cout][Cin][KS][KS] (already folded: BN / spectral norm / flips), bias may be empty
+// want_wino: also pack the Winograd F(2x2,3x3) image (16 / 9 of the weights, packed through a transient host copy in double) -- only
+// for layers that can reach a Winograd-sized output (>= 16 x 16) on a handle with aux.wino on (the 4 x 4 layer of the
+// shape decoder, 2048 -> 2048, carried 268 MB that no launch ever read)
 inline ConvLayer make_conv(Builder& B, const std::vector<float>& w, const std::vector<float>& bias, int cout, int cin,
-                           int ks, int stride, int pad) {
+                           int ks, int stride, int pad, bool want_wino = true) {
     ConvLayer L;
     L.Cout = cout;
     L.Cin = cin;
@@ -195,7 +198,7 @@ inline ConvLayer make_conv(Builder& B, const std::vector<float>& w, const std::v
         return wp[((size_t)row * cin + ci) * ks * ks + t];
     }));
     if (!bias.empty()) L.bias = B.upload(bias);
-    if (ks == 3 && stride == 1 && pad == 1 && cin % 8 == 0 && cout >= 16) {
+    if (want_wino && ks == 3 && stride == 1 && pad == 1 && cin % 8 == 0 && cout >= 16) {
         // the same conv as Winograd F(2x2,3x3) on the f32 matrix cores (run_conv takes it where the shape fits the kernel's tiles)
         L.wino = B.upload(pack_wino_A(cout, cin, [&](int row, int ci, int t) { return wp[((size_t)row * cin + ci) * 9 + t]; }));
         L.zero = B.upload(std::vector<float>(64, 0.f));

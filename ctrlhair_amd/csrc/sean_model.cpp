@@ -370,7 +370,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     has_zencoder = false;
     if (ts.find("Zencoder.model.1.weight") != ts.end()) {
         auto plain = [&](const std::string& p, int cout, int cin, int stride, ConvLayer& L) {
-            L = make_conv(B, B.vec(p + ".weight", (size_t)cout * cin * 9), B.vec(p + ".bias", cout), cout, cin, 3, stride, 1);
+            L = make_conv(B, B.vec(p + ".weight", (size_t)cout * cin * 9), B.vec(p + ".bias", cout), cout, cin, 3, stride, 1, false);      // (z14: its own reflect-padded image)
         };
         plain("Zencoder.model.1", 32, 3, 1, z1);
         z1_w = B.upload(B.vec("Zencoder.model.1.weight", (size_t)32 * 3 * 9));      // raw [32][3][3][3] for the direct stem conv
@@ -383,7 +383,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             for (int co = 0; co < 256; ++co)
                 for (int ci = 0; ci < 128; ++ci)
                     for (int t = 0; t < 9; ++t) w[((size_t)co * 128 + ci) * 9 + t] = wt[((size_t)ci * 256 + co) * 9 + (8 - t)];
-            z10 = make_conv(B, w, B.vec("Zencoder.model.10.bias", 256), 256, 128, 3, 1, 1);
+            z10 = make_conv(B, w, B.vec("Zencoder.model.10.bias", 256), 256, 128, 3, 1, 1, false);      // (its Winograd form is z10_wino: four phase convs)
         }
         plain("Zencoder.model.14", 512, 256, 1, z14);
         z14_wino = z10_wino = nullptr;

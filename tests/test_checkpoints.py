@@ -68,6 +68,7 @@ def test_npz_container_roundtrip(tree, tmp_path):
     root, w, _, _, r = tree
     C.save_npz(str(tmp_path / 'all.npz'), r)
     back = C.load_npz(str(tmp_path / 'all.npz'))
+    assert back.get('_origin') == r.get('_origin') == 'reference'      # the arithmetic default of a released checkpoint survives
     for m in C.MODELS:
         assert sorted(back[m]) == sorted(w[m])
         assert all(np.array_equal(back[m][k], np.asarray(w[m][k])) for k in w[m])

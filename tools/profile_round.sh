@@ -14,7 +14,7 @@ for P in f16x3 f32; do
   python $R/tools/rocprof_pmc.py $D > $OUT/${TAG}_${P}_pmc.md 2>> $OUT/${P}_run.log
   # the launches bench.py's roofline block averages over: every SPADE conv + fused ACE epilogue of a step
   if [ $P = f16x3 ]; then K='conv_sh16_ws_kernel<3, 32, 16, 1, 1, 3|conv_sh16_kernel<3, 16, 16, 2, 1, 3|conv_sh16_kernel<3, 32, 16, 1, 1, 3'
-  else K='wino_ace_gather_kernel|wino_ace_kernel|conv_ace_sparse_kernel|conv_mfma_kernel<3, 1, 2, 32, 8, 1, 16, 1,|conv_mfma_kernel<3, 1, 2, 16, 16, 1, 16, 1,'; fi
+  else K='wino_ace_gather_kernel|wino4_ace_kernel|wino_ace_kernel|conv_ace_sparse_kernel|conv_mfma_kernel<3, 1, 2, 32, 8, 1, 16, 1,|conv_mfma_kernel<3, 1, 2, 16, 16, 1, 16, 1,'; fi
   python $R/tools/make_traffic.py $D $P "$K" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/${TAG}_${P}_pmc.md" >> $OUT/${P}_run.log 2>&1
   grep '^{' $D/trace.log | tail -1 > $OUT/${TAG}_${P}_bench_line.json      # (rocprofv3 logs after the JSON line)
   cp $D/peak.log $OUT/${TAG}_${P}_mfma_peak.log 2>/dev/null
