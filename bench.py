@@ -55,7 +55,7 @@ PATH_OPTION = {'f32': 0, 'f16x3': 1, 'f16': 2, 'bf16': 3}
 
 DTYPE = {
     'f32': 'f32 (every product and sum an IEEE f32 operation on the f32 matrix cores, v_mfma_f32_16x16x4_f32 / 32x32x2_f32; 3x3 convs as '
-           'Winograd: ResBlock convs F(4x4,3x3), SPADE / style convs F(2x2,3x3) -- f32 operands and accumulation over TRANSFORMED operands, '
+           'Winograd: ResBlock convs and the <= 64-pixel SPADE / style convs F(4x4,3x3), SPADE / style convs above F(2x2,3x3) -- f32 operands and accumulation over TRANSFORMED operands, '
            'not a re-association of the direct sum: <= 3e-5 from the reference fixtures on the benchmarked call; --wino 1 / 0 for F(2x2,3x3) / direct)',
     'f16x3': 'f32 storage + f32 accumulate; conv products as 3-term f16 split on MFMA with power-of-two operand scaling '
              '(2^-22 per product: f32-class, not the fp32 number of record; csrc/sh16.h)',
@@ -534,7 +534,10 @@ def main():
                     r2, p2 = run_leg(job, a2, dist, dev, world, steps=max(5, args.steps // 3), warmup=max(2, args.warmup // 3))
                     rb = roofline_block(vpath, p2, r2['value'] / world, a2.batch, sustained)
                     side[name] = {'value': r2['value'], 'unit': 'images/s', 'ms_per_step': r2['ms_per_step'], 'steps': r2['steps'],
-                                  'batch_per_gpu': a2.batch, 'global_batch': world * a2.batch, 'dtype': DTYPE[vpath],
+                                  'batch_per_gpu': a2.batch, 'global_batch': world * a2.batch,
+                                  'dtype': DTYPE[vpath] if (vpath != 'f32' or a2.wino == 2) else
+                                  ('f32, IEEE f32 products and sums on the f32 matrix cores; ' +
+                                   {0: 'direct 3x3 convs (no Winograd: the fmaf chains of the reference)', 1: 'every 3x3 conv as Winograd F(2x2,3x3)'}[min(max(a2.wino, 0), 1)]),
                                   'all_mfma_convs': rb['all_mfma_convs'], 'dominant_kernel_tflops': rb['achieved'],
                                   'dominant_kernel_frac': rb['frac'], 'executed_over_dense_spade': rb['executed_over_dense']}
                     if vpath == 'bf16':
@@ -558,7 +561,7 @@ def main():
                     'no checkpoint ships with the reference)',
             'config': {'workload': f'SEAN generator forward only, batch {gen_batch}/GPU, {S}x{S}, ngf={ngf} (BASELINE.json {cfgn})',
                        'global_batch': world * gen_batch, 'conv_path': args.path, 'parallelism': par, 'labels': args.labels,
-                       'spade_interior_reduction': bool(args.sparse), 'winograd': ({0: 'off', 1: 'F(2x2,3x3)', 2: 'ResBlock convs F(4x4,3x3), SPADE convs F(2x2,3x3)'}[min(max(args.wino, 0), 2)] if args.path == 'f32' else 'n/a')},
+                       'spade_interior_reduction': bool(args.sparse), 'winograd': ({0: 'off', 1: 'F(2x2,3x3)', 2: 'ResBlock convs and the SPADE convs up to 64 pixels F(4x4,3x3), SPADE convs above F(2x2,3x3) over boundary quads'}[min(max(args.wino, 0), 2)] if args.path == 'f32' else 'n/a')},
             'roofline': head['roofline'], 'sustained_peaks': sustained,
         }
         res.update(side)
