@@ -26,9 +26,13 @@
 // Everything else -- task order, stage layout, DMA ring as one flat sequence across tasks, weight images, epilogue arithmetic -- is
 // conv_wino4.h's; the two kernels produce bit-identical results (same operations per output in the same order).
 #pragma once
-#include "conv_wino4.h"
+#include "../../ctrlhair_amd/csrc/conv_wino4.h"
 
 namespace chk {
+
+#ifdef W4W_STAMP
+__device__ unsigned long long w4w_stamps[4 * 64 * 12];      // [wave][k-step][stamp]: tools/w4w_timeline.hip
+#endif
 
 template <bool AG>
 __device__ __forceinline__ void w4w_mfma(f32x4& acc, float a, float b) {
@@ -206,6 +210,9 @@ __global__ __launch_bounds__(256, 1) void wino4_plain_w_kernel(const Wino4Params
         for (int j = 0; j < 6; ++j)
             wino4_in1d(v[j], v[6 + j], v[12 + j], v[18 + j], v[24 + j], v[30 + j], v[j], v[6 + j], v[12 + j], v[18 + j], v[24 + j], v[30 + j]);
     }
+#ifdef W4W_STAMP
+    int kcnt = 0;
+#endif
     unsigned rslot = lds0;
     // A fragments of group 0 of the first k-step (later ones are read during the previous k-step's last group)
     f32x4 F[2][2];      // [ring][half]
@@ -223,8 +230,15 @@ __global__ __launch_bounds__(256, 1) void wino4_plain_w_kernel(const Wino4Params
     //   DMA:      piece g in slot 8 g + 3
     auto kstep = [&](auto Pt, float (&vc)[36], float (&vx)[36]) {
         constexpr int P = decltype(Pt)::value;          // parity of the A ring at group 0 (nine groups per k-step: it alternates)
+#ifdef W4W_STAMP
+        unsigned long long ts[11];
+        asm volatile("s_memtime %0" : "=s"(ts[0]));
+#endif
         wait_ring();
         __syncthreads();
+#ifdef W4W_STAMP
+        asm volatile("s_memtime %0" : "=s"(ts[1]));
+#endif
         const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
         const f32x4* ap = a_ptr(rslot);
         const f32x4* apn = a_ptr(nslot);
@@ -261,11 +275,24 @@ __global__ __launch_bounds__(256, 1) void wino4_plain_w_kernel(const Wino4Params
             }
             if constexpr (s == 5 && g < 5) load_row(spn, g + 1, dr[(g + 1) & 1]);
             if constexpr (s == 3) issue_piece(WInt<g>{});
+#ifdef W4W_STAMP
+            if constexpr (s == 7) asm volatile("s_memtime %0" : "=s"(ts[2 + g]));
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         w4w_for<0, 72>(slot);
         issue_tail();
         rslot = nslot;
+#ifdef W4W_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (blockIdx.x == 0 && kcnt < 64 && lane < 11) {
+            unsigned long long tv = 0;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) tv = lane == i ? ts[i] : tv;
+            w4w_stamps[(wave * 64 + kcnt) * 12 + lane] = tv;
+        }
+        ++kcnt;
+#endif
     };
 
     for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
