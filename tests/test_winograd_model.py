@@ -111,3 +111,75 @@ def test_centre_tap_kernel_is_a_1x1_conv():
     U = G @ g @ G.T
     nz = np.argwhere(U != 0)
     assert sorted(map(tuple, nz)) == [(1, 1), (1, 2), (2, 1), (2, 2)] and np.allclose(np.abs(U[1:3, 1:3]), 0.5)
+
+
+# ---- F(4x4, 3x3): the ResBlock convs and the low-resolution SPADE convs of the exact-f32 path (csrc/conv_wino4.h) -------------------
+BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+              dtype=np.float64)
+AT4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+
+
+def winograd4_conv(x, w, dtype):
+    """conv_wino4.h's order of operations: U = G g G^T in double, rounded once to `dtype`; V = B^T d B, M accumulated over the channels and
+    Y = A^T M A all in `dtype` (the kernel's transforms are fma chains with these small-integer coefficients: one rounding per operation;
+    here one rounding per matrix product entry -- the same error level, not the same bits)."""
+    C, H, W = x.shape
+    K = w.shape[0]
+    U = np.einsum('ia,kcab,jb->ijkc', G4, w.astype(np.float64), G4).astype(dtype)
+    xp = np.zeros((C, H + 2, W + 2), dtype)
+    xp[:, 1:-1, 1:-1] = x
+    out = np.empty((K, H, W), dtype)
+    bt, at = BT4.astype(dtype), AT4.astype(dtype)
+    for ty in range(H // 4):
+        for tx in range(W // 4):
+            d = xp[:, 4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6]                            # [C, 6, 6]
+            V = np.einsum('ia,cab,jb->ijc', bt, d, bt).astype(dtype)
+            M = np.zeros((6, 6, K), dtype)
+            for c in range(C):
+                M += U[:, :, :, c] * V[:, :, c][:, :, None]
+            out[:, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4] = np.einsum('ia,abk,jb->kij', at, M, at).astype(dtype)
+    return out
+
+
+def test_f4_transform_matrices():
+    """A^T [(G g G^T) .* (B^T d B)] A == the 4x4 valid correlation of a 6x6 patch with a 3x3 kernel, for every basis pair (float64)."""
+    for t in range(9):
+        g = np.zeros((3, 3))
+        g[t // 3, t % 3] = 1.0
+        for e in range(36):
+            d = np.zeros((6, 6))
+            d[e // 6, e % 6] = 1.0
+            y = AT4 @ ((G4 @ g @ G4.T) * (BT4 @ d @ BT4.T)) @ AT4.T
+            ref = np.array([[(d[a:a + 3, b:b + 3] * g).sum() for b in range(4)] for a in range(4)])
+            assert np.abs(y - ref).max() < 1e-12, (t, e)
+
+
+def test_f4_conv_is_exact_in_double_and_f32_class_in_float():
+    """Whole conv, zero padding: identical to the direct sum in float64; in float32 the error is a small multiple of the direct f32
+    evaluation's own (the transformed operands span a wider range than F(2x2)'s: DESIGN.md section 2, item 10), far inside the 1e-3
+    the contract allows and inside the 5e-4 budget the HIP tests give a whole generator."""
+    rng = np.random.default_rng(7)
+    C, K, H = 24, 8, 16
+    x = rng.standard_normal((C, H, H))
+    w = rng.standard_normal((K, C, 3, 3)) / np.sqrt(9 * C)
+    ref = direct_conv(x, w, np.float64)
+    assert np.abs(winograd4_conv(x, w, np.float64) - ref).max() < 1e-12
+    e_dir = np.abs(direct_conv(x.astype(np.float32), w.astype(np.float32), np.float32) - ref).max()
+    e_w4 = np.abs(winograd4_conv(x.astype(np.float32), w.astype(np.float32), np.float32) - ref).max()
+    e_w2 = np.abs(winograd_conv(x.astype(np.float32), w.astype(np.float32), np.float32) - ref).max()
+    print(f'max abs error vs float64: direct f32 {e_dir:.2e}, F(2x2,3x3) f32 {e_w2:.2e}, F(4x4,3x3) f32 {e_w4:.2e} (max |ref| {np.abs(ref).max():.2f})')
+    assert e_w4 < 2e-5 and e_w4 < 40 * max(e_dir, 1e-7)
+
+
+def test_f4_position_layout_of_the_weight_image():
+    """pack_wino4_A's fragment order: a = 36 m + 6 i + j for the 16-row half m (conv_wino4.h) -- every (half, position) once, nine
+    16-byte units per half."""
+    seen = set()
+    for m in range(2):
+        for i in range(6):
+            for j in range(6):
+                a = m * 36 + 6 * i + j
+                seen.add((a >> 2, a & 3))
+    assert len(seen) == 72 and max(u for u, _ in seen) == 17
