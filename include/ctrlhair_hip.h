@@ -55,11 +55,12 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
 
 /* Options, set before ch_finalize.  "sean.f16x3" (default 0) selects the arithmetic of the SEAN generator's MFMA convs:
  *   0  f32 throughout on the f32 matrix cores (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: every product and every sum an IEEE f32
- *      operation); with "sean.wino" = 1 (default) the 3x3 convs are evaluated as Winograd F(2x2,3x3)
- *      (ctrlhair_amd/csrc/conv_wino.h: f32 operands and f32 accumulation, but TRANSFORMED operands -- U = G g G^T is computed in
- *      double and rounded once to f32, the input / output transforms are f32 adds -- so this is not a re-association of the
- *      direct sum and carries its own, slightly larger rounding error: <= ~4e-6 measured against the direct evaluation on the
- *      generator output, 2e-5 asserted), with 0 directly (conv_mfma.h: the reference conv2d's products and sums);
+ *      operation); with "sean.wino" >= 1 the 3x3 convs are evaluated as Winograd convolutions (ctrlhair_amd/csrc/conv_wino.h,
+ *      conv_wino4.h: f32 operands and f32 accumulation, but TRANSFORMED operands -- U = G g G^T is computed in double and rounded
+ *      once to f32, the input / output transforms are f32 adds / fmas -- so this is not a re-association of the direct sum and
+ *      carries its own rounding error: F(2x2,3x3) <= ~4e-6 against the direct evaluation on the generator output, F(4x4,3x3)
+ *      (the default for the ResBlock convs and the SPADE convs up to 64 pixels) <= ~3e-5; the contract tolerance is 1e-3),
+ *      with 0 directly (conv_mfma.h: the reference conv2d's products and sums);
  *   1  f16 matrix cores with the 3-term split-operand scheme of ctrlhair_amd/csrc/conv_sh16.h: f32-class accuracy, f32
  *      accumulation, activations between ACE and conv stored as f16 hi/lo pairs;
  *   2  f16 matrix cores, single term: operands rounded to f16, f32 accumulation and f32 normalisation / modulation
@@ -79,8 +80,14 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   (The Zencoder follows "sean.f16x3".)
  * "aux.wino" (default 1): the exact-f32 kernels of the shape VAE and BiSeNet ("shape.f16x3" / "bisenet.f16x3" = 0, and the layers those
  *   options leave on them) run their 3x3 stride-1 convs as Winograd F(2x2,3x3) wherever the output fits the kernel's tiles; 0 = direct.
- * "sean.wino" (default 1; "sean.f16x3" = 0 only): the ResBlock 3x3 convs, the SPADE gamma/beta convs and the style convs as
- *   Winograd F(2x2,3x3) on the f32 matrix cores, the learned 1x1 shortcuts on the pointwise kernel of conv_pw.h.
+ * "sean.wino" (default 2; "sean.f16x3" = 0 only): 1 = the ResBlock 3x3 convs, the SPADE gamma/beta convs and the style convs as
+ *   Winograd F(2x2,3x3) on the f32 matrix cores, the learned 1x1 shortcuts on the pointwise kernel of conv_pw.h; 2 = in addition the
+ *   ResBlock convs from 32 pixels up as Winograd F(4x4,3x3) (conv_wino4.h: 36 instead of 64 products per 4 x 4 pixels); 0 = direct.
+ * "sean.wino4_ace" (default 64; with "sean.wino" = 2): the SPADE / style convs of the levels up to this many pixels (multiples of 32)
+ *   run as dense F(4x4,3x3) over every tile instead of F(2x2,3x3) over the boundary quads; 0 = never.
+ * "sean.overlap" (default 0; before ch_finalize): number of CUs given to CU-masked side streams on which the interior passes and
+ *   label-table kernels run beside the convs (with dynamic task claiming in the Winograd kernels).  Bit-identical results; measured
+ *   SLOWER than the serial order at every setting on MI355X: kept as an option, not used.
  * "sean.lut_grouped" (default 1; exact-f32 path, calls with more than 64 (sample, label) columns): the style LUTs of all styled ACEs
  *   of a chunk come from ONE grouped GEMM launch at its start (csrc/conv_pw.h); 0 = one launch of the generic 1x1 kernel per ACE.
  * "sean.hidden_wq" (default 1; any time): Winograd ACE levels of 128 pixels and more take the SPADE hidden activations and the one-hot
