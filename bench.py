@@ -522,7 +522,9 @@ def main():
             variants = [('configs3_b32_per_gpu', {'batch': 32}), ('configs4_bf16_b32_per_gpu', {'batch': 32, '_path': 'bf16'})]
             if extras:
                 variants += [('winograd_f2x2_only', {'wino': 1}), ('direct_convs_no_winograd', {'wino': 0}),
-                             ('dense_worst_case_no_interior_reduction', {'sparse': 0})]
+                             ('dense_worst_case_no_interior_reduction', {'sparse': 0}),
+                             # the label-INDEPENDENT path: every level's SPADE convs as dense F(4x4,3x3) (what an adversarial label map costs at most)
+                             ('dense_all_levels_f4x4', {'sparse': 0, 'opt': (args.opt or []) + ['sean.wino4_ace=512']})]
             for name, over in variants:
                 a2 = argparse.Namespace(**vars(args))
                 vpath = over.get('_path', 'f32')
