@@ -4,7 +4,7 @@
 namespace chk {
 
 hipError_t conv_wino4_plain(Wino4Params p, hipStream_t s) {
-    if (!wino4_supported(p.H, p.W, p.Cin) || !p.in || !p.wpk || !p.out) return hipErrorInvalidValue;
+    if (!wino4_supported(p.H, p.W, p.Cin) || !p.in || !p.wpk || !p.out || (p.reflect && (p.res_up || p.H < 2 || p.W < 2))) return hipErrorInvalidValue;
     wino4_fill_launch(p);
     static bool done[64] = {};
     static int cus[64] = {};
@@ -13,13 +13,16 @@ hipError_t conv_wino4_plain(Wino4Params p, hipStream_t s) {
     if (!done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_plain_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, wino4::LDS_BYTES);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_plain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, wino4::LDS_BYTES);
+        if (e != hipSuccess) return e;
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus[dev] = v;
         done[dev] = true;
     }
     const int grid = p.ntasks < cus[dev] ? p.ntasks : cus[dev];
-    hipLaunchKernelGGL(wino4_plain_kernel<0>, dim3(grid), dim3(512), wino4::LDS_BYTES, s, p);
+    if (p.reflect) hipLaunchKernelGGL(wino4_plain_kernel<1>, dim3(grid), dim3(512), wino4::LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(wino4_plain_kernel<0>, dim3(grid), dim3(512), wino4::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -52,6 +52,8 @@ struct Wino4Params {
     const float* bias;      // [Cout] or null
     const float* res;       // [B][Cout][H >> res_up][W >> res_up] or null
     int res_up;
+    int act;                // ACT_* applied to conv + bias + residual
+    int reflect;            // 1 = reflection padding (pad 1: row -1 is row 1, row H is row H - 2; columns alike) instead of zeros
     // set by the launcher
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
 };
@@ -108,9 +110,14 @@ __device__ __forceinline__ void wino4_out1d(float m0, float m1, float m2, float 
     y3 = __builtin_fmaf(8.f, d2, d1) + m5;
 }
 
-template <int DUMMY>
+// MODE bit 0: reflection padding (the Zencoder's 256 -> 512 conv, architecture.py:174).  Rows: a reflected row is a source offset like any
+// other.  Columns: the patch arrives as aligned 4-pixel units, so the unit left of column 0 (right of column W - 1) holds zeros; the one
+// element of it a block reads -- its column 0 at the image's left edge, column 5 at the right edge -- is replaced in registers by the
+// block's own column 2 / 3 (pixel +1 / W - 2): two selects per patch row, in this instantiation only.
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p) {
     using namespace wino4;
+    constexpr bool REFL = (MODE & 1) != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,7 +163,9 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
             const int u = i * 512 + tid;
             const int k4 = u / PPL, rem = u - k4 * PPL;
             const int py = rem / PUN, ux = rem - py * PUN;
-            const int y = y0 + py, x = x0 + 4 * ux;
+            int y = y0 + py;
+            const int x = x0 + 4 * ux;
+            if constexpr (REFL) y = y < 0 ? -y : (y >= p.H ? 2 * p.H - 2 - y : y);
             const bool ok = u < PUNITS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             voff[i] = ok ? (unsigned)(k4 * HW + y * p.W + x) * 4u : 0x80000000u;
         }
@@ -212,12 +221,24 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
     const int tx = n & 7, tyl = 2 * tg + (n >> 3);
     const int boff = kk * (PPL * 4) + (4 * tyl) * (PUN * 4) + 4 * tx + 3;      // this lane's patch origin (floats) inside a stage
     auto stage = [&](unsigned slot) { return reinterpret_cast<const float*>(smem) + (slot - lds0) / 4; };
+    bool eL = false, eR = false;                  // REFL: this lane's block sits at the left / right image edge (for the patch being transformed)
+    auto edge_of = [&](int L, bool& l, bool& r) {
+        int rt_, tile_;
+        task_of(L < p.ntasks ? L : p.ntasks - 1, rt_, tile_);
+        const int ttx_ = tile_ % p.ntx;
+        l = ttx_ == 0 && tx == 0;
+        r = ttx_ == p.ntx - 1 && tx == 7;
+    };
     auto load_row = [&](const float* sp, int r, float (&d)[6]) {               // patch row r of the lane's tile: 1 + 4 + 1 floats
         const float* q = sp + boff + r * (PUN * 4);
         d[0] = q[0];
         const f32x4 mid = *reinterpret_cast<const f32x4*>(q + 1);
         d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w;
         d[5] = q[5];
+        if constexpr (REFL) {
+            d[0] = eL ? d[2] : d[0];
+            d[5] = eR ? d[3] : d[5];
+        }
     };
     auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(stage(slot) + PSLOTS * 4) + 9 * mh * 64 + lane; };
 
@@ -227,6 +248,7 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float v[36], w[36];
+    if constexpr (REFL) edge_of(lb, eL, eR);
     {   // B fragments of the first k-step
         const float* sp = stage(lds0);
 #pragma unroll
@@ -283,6 +305,8 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
     for (int k = 0, ct = lb; k < mytasks; ++k, ct += G) {
         for (int cs = 0; cs < nk; cs += 2) {
             kstep(v, w);          // (nks is even: the launcher)
+            if constexpr (REFL)
+                if (cs + 2 >= nk) edge_of(ct + G, eL, eR);      // the task's last k-step transforms the NEXT task's first patch
             kstep(w, v);
         }
         // ---- epilogue of task ct ---------------------------------------------------------------------------------------------
@@ -319,7 +343,11 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
             for (int r = 0; r < 4; ++r) {
                 float o0, o1, o2, o3;
                 wino4_out1d(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o0, o1, o2, o3);
-                const f32x4 o = {o0 + bsv + rr[r].x, o1 + bsv + rr[r].y, o2 + bsv + rr[r].z, o3 + bsv + rr[r].w};
+                f32x4 o = {o0 + bsv + rr[r].x, o1 + bsv + rr[r].y, o2 + bsv + rr[r].z, o3 + bsv + rr[r].w};
+                if (p.act != ACT_NONE) {
+                    o.x = apply_act(o.x, p.act); o.y = apply_act(o.y, p.act);
+                    o.z = apply_act(o.z, p.act); o.w = apply_act(o.w, p.act);
+                }
                 if (row < p.Cout) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Cout + row) * HW + (y + r) * p.W + x) = o;
             }
             __builtin_amdgcn_sched_barrier(0);           // (one (row, tile) at a time: the accumulators leave little room)

@@ -386,11 +386,13 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             z10 = make_conv(B, w, B.vec("Zencoder.model.10.bias", 256), 256, 128, 3, 1, 1, false);      // (its Winograd form is z10_wino: four phase convs)
         }
         plain("Zencoder.model.14", 512, 256, 1, z14);
-        z14_wino = z10_wino = nullptr;
+        z14_wino = z10_wino = z14_wino4 = nullptr;
         if (!use_sh16 && wino) {   // exact-f32 path: the 256 -> 512 conv (91 % of the Zencoder FLOPs) as Winograd F(2x2,3x3), reflection-padded
             auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
             const float* wp = w14.data();
             z14_wino = B.upload(pack_wino_A(512, 256, [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; }));
+            // "sean.wino" = 2: the same conv as F(4x4,3x3) (conv_wino4.h, reflection instantiation) where the half-resolution grid is a multiple of 32
+            if (wino >= 2) z14_wino4 = B.upload(pack_wino4_A(512, 256, [&](int row, int ci, int t) { return wp[((size_t)row * 256 + ci) * 9 + t]; }));
             // ConvTranspose2d(128, 256, k3, s2, p1, op1) (architecture.py:167-170) as four phase convs of the INPUT grid:
             //   out[2y+py][2x+px] = sum over dy, dx in {0, 1} of x[y+dy][x+dx] * Wt[ci][co][py+1-2dy][px+1-2dx]   (taps outside 0..2 absent)
             // each a 3x3 kernel with non-zero taps at offsets 0 / +1 only; as Winograd F(2x2,3x3) that is 4 products per output pixel,
@@ -1723,7 +1725,21 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             ck(conv_sh16_plain(p, 3, st), "zenc conv5 (f16x3)");
         } else {
             ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
-            if (z14_wino && wino_supported(h2, h2, 256)) {
+            if (z14_wino4 && wino4_supported(h2, h2, 256)) {
+                Wino4Params q{};
+                q.in = hs;
+                q.wpk = z14_wino4;
+                q.out = h0;
+                q.B = B;
+                q.Cin = 256;
+                q.Cout = 512;
+                q.H = h2;
+                q.W = h2;
+                q.bias = z14.bias;
+                q.act = ACT_TANH;
+                q.reflect = 1;
+                ck(conv_wino4_plain(q, st), "zenc conv5 (winograd F(4x4,3x3))");
+            } else if (z14_wino && wino_supported(h2, h2, 256)) {
                 WinoParams q{};
                 q.in = hs;
                 q.wpk = z14_wino;

@@ -82,6 +82,7 @@ struct SeanModel {
     float *z14_sh = nullptr, *z10_sh = nullptr;        // z14 / the ConvTranspose packed for the f16x3 kernel
     float* z10_wino = nullptr;                         // exact-f32 path: the ConvTranspose as four Winograd phase convs of the input grid (rows 4 co + phase)
     float* z14_wino = nullptr;                         // exact-f32 path: z14 as Winograd A images (conv_wino.h, reflection padding)
+    float* z14_wino4 = nullptr;                        // ... and as F(4x4,3x3) images (conv_wino4.h), sean.wino = 2
     float *z14_ws = nullptr, *z10_ws = nullptr;        // their per-row inverse weight scales
     float *z10_d2s = nullptr, *z10_d2s_ws = nullptr;   // the ConvTranspose in its 2x2-tap depth-to-space form (rows = phase * 256 + co)
     ConvLayer z4_s2d, z7_s2d;                          // the two stride-2 convs in the space-to-depth form (conv_sh16.h S2D)

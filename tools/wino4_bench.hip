@@ -15,27 +15,32 @@ static float frand(unsigned& s) {
     return ((s >> 8) & 0xFFFF) / 32768.f - 1.f;
 }
 __global__ void ref_conv_kernel(const float* in, const float* w, const float* bias, const float* res, int res_up, float* out, int B, int Cin, int Cout,
-                                int H, int W) {
+                                int H, int W, int refl) {
     const long long n = (long long)B * Cout * H * W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % W), y = (int)((i / W) % H), co = (int)((i / ((long long)W * H)) % Cout), b = (int)(i / ((long long)W * H * Cout));
         double acc = bias ? bias[co] : 0.f;
         for (int ci = 0; ci < Cin; ++ci)
             for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (refl) {
+                    yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+                    xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+                }
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
                     acc += (double)w[((long long)co * Cin + ci) * 9 + t] * in[(((long long)b * Cin + ci) * H + yy) * W + xx];
             }
         if (res) acc += res[(((long long)b * Cout + co) * (H >> res_up) + (y >> res_up)) * (W >> res_up) + (x >> res_up)];
-        out[i] = (float)acc;
+        out[i] = refl ? (float)tanh(acc) : (float)acc;
     }
 }
-struct Shape { int B, Cin, Cout, H, res; const char* name; };   // res: 0 none, 1 same size, 2 upsampled
+struct Shape { int B, Cin, Cout, H, res; const char* name; };   // res: 0 none, 1 same size, 2 upsampled, 3 = reflection padding + tanh
 
 int main(int argc, char** argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
     const Shape all[] = {
         {2, 16, 16, 32, 0, "tiny"}, {3, 32, 48, 64, 1, "tiny res, ragged rows"}, {1, 24, 32, 32, 2, "tiny res_up"}, {2, 64, 64, 96, 1, "96^2 res"},
+        {3, 16, 40, 64, 3, "tiny reflect + tanh"}, {8, 256, 512, 256, 3, "Zencoder 256->512 reflect + tanh"},
         {16, 1024, 1024, 32, 0, "G_middle conv_0"}, {16, 1024, 1024, 32, 1, "G_middle conv_1 (+x)"},
         {16, 1024, 512, 64, 0, "up_0 conv_0"}, {16, 512, 512, 64, 1, "up_0 conv_1 (+xs)"},
         {16, 512, 256, 128, 0, "up_1 conv_0"}, {16, 256, 256, 128, 1, "up_1 conv_1 (+xs)"},
@@ -70,7 +75,8 @@ int main(int argc, char** argv) {
         CK(hipMemset(d_out, 0xFF, nout * 4));
         Wino4Params p{};
         p.in = d_in; p.wpk = d_pk; p.out = d_out; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
-        p.bias = d_b; p.res = d_res; p.res_up = c.res == 2 ? 1 : 0;
+        p.bias = d_b; p.res = c.res == 3 ? nullptr : d_res; p.res_up = c.res == 2 ? 1 : 0;
+        p.reflect = c.res == 3; p.act = c.res == 3 ? ACT_TANH : ACT_NONE;
         CK(conv_wino4_plain(p, 0));
         CK(hipDeviceSynchronize());
         const bool big = (double)nout * Cin * 9 > 4e11;
@@ -79,7 +85,7 @@ int main(int argc, char** argv) {
         for (int pass = 0; pass < (big ? 2 : 1); ++pass) {
             const int b0 = pass == 0 ? 0 : B - 1;
             hipLaunchKernelGGL(ref_conv_kernel, dim3(4096), dim3(256), 0, 0, d_in + (size_t)b0 * Cin * H * W, d_w, d_b,
-                               d_res ? d_res + (size_t)b0 * Cout * rh * rh : nullptr, p.res_up, d_ref, Bref, Cin, Cout, H, W);
+                               (d_res && c.res != 3) ? d_res + (size_t)b0 * Cout * rh * rh : nullptr, p.res_up, d_ref, Bref, Cin, Cout, H, W, c.res == 3 ? 1 : 0);
             CK(hipDeviceSynchronize());
             const size_t nn = (size_t)Bref * Cout * H * W;
             std::vector<float> ho(nn), hr(nn);
