@@ -362,6 +362,10 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.overlap = value < 0 ? 0 : value;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.wino4_force") == 0) {  // 1 = F(4x4,3x3) wherever the shape allows, even with fewer tasks than CUs (tests / measurements)
+        h->sean.wino4_force = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.wino4_ace") == 0) {    // largest level (pixels) whose SPADE convs run as F(4x4,3x3) over every tile; 0 = none
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino4_ace) must precede ch_finalize");
         h->sean.wino4_ace_max_r = value < 0 ? 0 : value;

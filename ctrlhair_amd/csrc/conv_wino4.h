@@ -631,6 +631,15 @@ __global__ __launch_bounds__(512, 1) void wino4_ace_kernel(const Wino4AceParams 
 }
 
 inline bool wino4_supported(int H, int W, int Cin) { return H % wino4::TS == 0 && W % wino4::TS == 0 && Cin % 8 == 0 && Cin >= 16; }
+// Does F(4x4,3x3) beat F(2x2,3x3) on this launch?  Both kernels run one task per CU at a time; an F(4x4) task (32 x 32 pixels x 32 rows) is
+// 36 MFMAs per wave and k-step at ~58 % of the matrix pipe, the two F(2x2) tasks covering the same pixels (32 x 16 each) are 32 each at
+// ~68 %.  With many tasks per CU F(4x4) wins 36 : 64; with fewer tasks than CUs both take one round and the smaller F(2x2) task is the
+// shorter one (batch-1 rendering: 4.54 -> 4.21 ms at 256^2, 6.34 -> 5.92 ms at 512^2 with F(2x2) everywhere, tools/lat_b1.py).
+inline bool wino4_pays(long long ntasks4, int cus) {
+    if (cus <= 0) cus = 256;
+    const long long r4 = (ntasks4 + cus - 1) / cus, r2 = (2 * ntasks4 + cus - 1) / cus;
+    return r4 * 36 * 68 < r2 * 32 * 58;
+}
 inline void wino4_fill_launch(Wino4Params& p) {
     p.nrt = (p.Cout + 31) / 32;
     p.ntx = p.W / wino4::TS;

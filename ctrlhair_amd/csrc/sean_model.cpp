@@ -453,6 +453,11 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     // Larger jobs keep the (HBM-write-bound) label-table kernels inline and run only the style LUT builds -- small,
     // latency-bound GEMMs -- ahead (ahead_full = false) -- unless the overlap mode serves them (sean_model.h): then the label
     // tables of every ACE run ahead too, on a side stream confined to a few CUs.
+    {
+        int ncu = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) num_cus = ncu;
+    }
     overlap_on = false;
     if (overlap > 0 && !use_sh16 && wino && (long long)mb * ms * ms > ahead_pixels && ms >= 128) {
         int ncu = 0, dev = 0;
@@ -937,7 +942,8 @@ struct Runner {
     // SPADE conv of this ACE as F(4x4,3x3) over every tile of the level (conv_wino4.h): the low-resolution levels, where nearly every
     // tile holds a boundary pixel -- no classification, no interior pass, hidden activations at every pixel
     bool use_wino4_ace(const AceW& a, int r) const {
-        return use_wino_ace(a, r) && m.wino >= 2 && a.spade_wino4 && r <= m.wino4_ace_max_r && wino4_ace_supported(r, r, a.C) && (!a.styled || m.wsty4);
+        return use_wino_ace(a, r) && m.wino >= 2 && a.spade_wino4 && r <= m.wino4_ace_max_r && wino4_ace_supported(r, r, a.C) && (!a.styled || m.wsty4) &&
+               (m.wino4_force || wino4_pays((long long)B * (r / 32) * (r / 32) * ((a.C + 15) / 16), m.num_cus));      // (few tasks per CU -- single images -- : the gather kernel)
     }
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
                         float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr,
@@ -1409,7 +1415,8 @@ struct Runner {
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS, cin2 = w2 ? w2->Cin : 0;
-        if (m.wino >= 2 && !m.use_sh16 && w.wino4 && w.KS == 3 && !w2 && wino4_supported(r, r, w.Cin)) {
+        if (m.wino >= 2 && !m.use_sh16 && w.wino4 && w.KS == 3 && !w2 && wino4_supported(r, r, w.Cin) &&
+            (!use_wino(w, r) || m.wino4_force || wino4_pays((long long)B * (r / 32) * (r / 32) * ((w.Cout + 31) / 32), m.num_cus))) {
             // Winograd F(4x4,3x3) on the exact-f32 matrix cores: 36 MFMA products per 4 x 4 tile and channel instead of 144
             Wino4Params q{};
             q.in = in;
@@ -1725,7 +1732,7 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             ck(conv_sh16_plain(p, 3, st), "zenc conv5 (f16x3)");
         } else {
             ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
-            if (z14_wino4 && wino4_supported(h2, h2, 256)) {
+            if (z14_wino4 && wino4_supported(h2, h2, 256) && (wino4_force || wino4_pays((long long)B * (h2 / 32) * (h2 / 32) * 16, num_cus))) {
                 Wino4Params q{};
                 q.in = hs;
                 q.wpk = z14_wino4;

@@ -153,6 +153,8 @@ struct SeanModel {
     std::map<const float*, long long> pad_state;   // geometry (size, planes) a padded buffer's zero columns were last cleared for
     float* wsty = nullptr;
     float* wsty4 = nullptr;                    // per-sample F(4x4,3x3) style images of the ACE being run (conv_wino4.h)
+    int num_cus = 256;                         // compute units of the handle's device (build())
+    int wino4_force = 0;                       // option "sean.wino4_force": 1 = F(4x4,3x3) wherever the shape allows, whatever the task count (tests)
     int wino4_ace_max_r = 64;                  // option "sean.wino4_ace": largest level whose SPADE convs run as F(4x4,3x3) over EVERY tile (0 = none)
     int* prof_stats = nullptr;                 // profiling: snapshots of the work-list statistics of sparse launches (16 B each)
     int prof_stats_cap = 0, prof_stats_used = 0;

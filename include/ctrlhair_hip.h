@@ -85,6 +85,9 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   ResBlock convs from 32 pixels up as Winograd F(4x4,3x3) (conv_wino4.h: 36 instead of 64 products per 4 x 4 pixels); 0 = direct.
  * "sean.wino4_ace" (default 64; with "sean.wino" = 2): the SPADE / style convs of the levels up to this many pixels (multiples of 32)
  *   run as dense F(4x4,3x3) over every tile instead of F(2x2,3x3) over the boundary quads; 0 = never.
+ *   Both F(4x4,3x3) choices are made per call: with fewer tasks of 32 x 32 pixels than a round of F(2x2,3x3) tasks would need CUs (single
+ *   images, small batches of small images) the F(2x2,3x3) kernels run instead (wino4_pays, conv_wino4.h); "sean.wino4_force" = 1 (any
+ *   time) switches that rule off.
  * "sean.overlap" (default 0; before ch_finalize): number of CUs given to CU-masked side streams on which the interior passes and
  *   label-table kernels run beside the convs (with dynamic task claiming in the Winograd kernels).  Bit-identical results; measured
  *   SLOWER than the serial order at every setting on MI355X: kept as an option, not used.

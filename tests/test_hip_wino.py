@@ -104,7 +104,8 @@ def test_winograd_f4x4_equals_direct(hip_lib):
     from oracle import sean_oracle as O
     for ngf, S, B in ((64, 256, 2), (16, 128, 3), (16, 96, 2)):
         sd = P.sean_state_dict(0, ngf)
-        direct, f2, f4 = _gen(sd, B, S, 0), _gen(sd, B, S, 1), _gen(sd, B, S, 2)
+        # (sean.wino4_force: these small calls have fewer F(4x4) tasks than CUs, where the library would pick the F(2x2) kernels by itself)
+        direct, f2, f4 = _gen(sd, B, S, 0), _gen(sd, B, S, 1), _gen(sd, B, S, 2, {'sean.wino4_force': 1})
         codes, noise = P.style_codes(B, seed=71), P.noise_planes(B, S, ngf, seed=72)
         sets = _label_sets(B, S)
         for name in ('face', 'blocky', 'diag'):
@@ -126,6 +127,25 @@ def test_winograd_f4x4_equals_direct(hip_lib):
             assert 0.25 - 1e-9 <= plain['flops_executed'] / plain['flops'] <= 0.45      # 36 / 144 on the F(4x4) levels (+ 1x1 shortcuts, 8 / 16-pixel levels)
         for g in (direct, f2, f4):
             g.handle.close()
+
+
+def test_f4x4_task_count_rule_only_changes_the_kernels(hip_lib):
+    """Small calls (fewer tasks of 32 x 32 pixels than CUs) take the F(2x2,3x3) kernels on their own (wino4_pays, conv_wino4.h): the result of
+    a single-image call at the default options equals the sean.wino = 1 result bit for bit where every layer falls back, and stays within the
+    F(4x4) tolerance of the forced F(4x4) evaluation."""
+    from ctrlhair_amd import procedural as P
+    ngf, S, B = 64, 128, 1
+    sd = P.sean_state_dict(0, ngf)
+    auto, f2, forced = _gen(sd, B, S, 2), _gen(sd, B, S, 1), _gen(sd, B, S, 2, {'sean.wino4_force': 1})
+    codes, noise = P.style_codes(B, seed=5), P.noise_planes(B, S, ngf, seed=6)
+    lab = _label_sets(B, S)['face']
+    a, b, c = _run(auto, lab, codes, noise), _run(f2, lab, codes, noise), _run(forced, lab, codes, noise)
+    assert np.array_equal(a, b), 'a 128 x 128 single image has at most 16 x 2 ... 1 x 32 tasks per layer: every layer falls back'
+    d = float(np.abs(a - c).max())
+    print(f'B=1 S=128: max |auto - forced F(4x4)| = {d:.3e}')
+    assert 0 < d <= 2e-4
+    for g in (auto, f2, forced):
+        g.handle.close()
 
 
 @pytest.mark.parametrize('S,mb', [(64, 8), (256, 9)])

@@ -1,5 +1,5 @@
 """Single-image render latency (the call behind Backend.output), eager launches vs hipGraph replay:
-    python tools/lat_b1.py [S]"""
+    python tools/lat_b1.py [S] [key=value ...]      (ch_set_option pairs, e.g. sean.wino=1)"""
 import os
 import sys
 
@@ -24,8 +24,9 @@ def timeit(fn, n=30):
 
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+OPTS = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in sys.argv[2:]}
 for mode, name in ((1, 'f16x3'), (0, 'f32')):
-    g = SeanGenerator(0, f16x3=mode).load_state_dict(P.sean_state_dict(0, 64), max_batch=1, max_size=S)
+    g = SeanGenerator(0, f16x3=mode, options=OPTS).load_state_dict(P.sean_state_dict(0, 64), max_batch=1, max_size=S)
     dev = g.device
     l = torch.from_numpy(P.blocky_labels(1, S)).to(dev)
     c = torch.from_numpy(P.style_codes(1)).to(dev)
