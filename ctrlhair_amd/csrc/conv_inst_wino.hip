@@ -1,5 +1,6 @@
 // conv_inst_wino.hip -- instantiations + launchers of the Winograd F(2x2,3x3) exact-f32 MFMA kernels (conv_wino.h)
 #include "conv_pw.h"
+#include <algorithm>
 #include "conv_wino.h"
 
 namespace chk {
@@ -28,12 +29,53 @@ static hipError_t wino_attr(K kern, int bytes, bool (&done)[64]) {
     return hipSuccess;
 }
 
+// out = act(sum over the K slices (in slice order) + bias + residual): the second pass of a split-K launch of wino_plain_kernel
+__global__ __launch_bounds__(256) void wino_splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, int res_up, int act, int ks, int B, int C, int H, int W) {
+    const long long n4 = (long long)B * C * H * W / 4, slab = n4 * 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(partial)[i];
+        for (int k = 1; k < ks; ++k) {
+            const float4 t = reinterpret_cast<const float4*>(partial + k * slab)[i];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        const long long e = 4 * i;
+        const int x = (int)(e % W), y = (int)((e / W) % H);
+        const long long bc = e / ((long long)W * H);
+        const float bv = bias ? bias[bc % C] : 0.f;
+        a.x += bv; a.y += bv; a.z += bv; a.w += bv;
+        if (res) {
+            if (res_up) {
+                const float* rp = res + bc * (long long)(H >> 1) * (W >> 1) + (long long)(y >> 1) * (W >> 1) + (x >> 1);
+                a.x += rp[0]; a.y += rp[0]; a.z += rp[1]; a.w += rp[1];
+            } else {
+                const float4 r = reinterpret_cast<const float4*>(res)[i];
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            }
+        }
+        if (act != ACT_NONE) { a.x = apply_act(a.x, act); a.y = apply_act(a.y, act); a.z = apply_act(a.z, act); a.w = apply_act(a.w, act); }
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
+}
+
 hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
     if ((!wino_supported(p.H, p.W, p.Cin) && !(wino_supported_pair16(p.B, p.H, p.W, p.Cin) && !p.reflect && !p.res_up)) || !p.zero) return hipErrorInvalidValue;
     if (p.d2s && (p.Cout % 4 || p.res || p.reflect || p.in_up || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;
     if (p.in_up && (p.reflect || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;      // (H, W: the conv's own = 2 x stored size)
     wino_fill_launch(p);
-    if (p.nks < wino::NST) p.claim = nullptr;     // (the issue side may run two tasks ahead: static split only)
+    p.ksplit = 1;
+    if (p.partial && !p.d2s && !p.in_up && p.W % 4 == 0) {        // far fewer tasks than CUs and a long k-loop: slices of the input channels
+        const int cus = wino_num_cus();
+        int ks = 1;
+        while (ks < 8 && 2 * ks * p.ntasks <= cus && p.nks % (2 * ks) == 0 && p.nks / (2 * ks) >= 16 &&
+               (long long)2 * ks * p.B * p.Cout * p.H * p.W <= p.partial_cap)
+            ks *= 2;
+        if (ks > 1) {
+            p.ksplit = ks;
+            p.ntasks *= ks;
+        }
+    }
+    if (p.nks / p.ksplit < wino::NST) p.claim = nullptr;     // (the issue side may run two tasks ahead: static split only)
     const int grid = p.ntasks < wino_num_cus() ? p.ntasks : wino_num_cus();
     static bool d0[64] = {}, d1[64] = {}, d2[64] = {};
     if (p.d2s) {
@@ -51,6 +93,12 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
     hipError_t e = wino_attr(wino_plain_kernel<0>, wino::LDS_BYTES, d0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(wino_plain_kernel<0>, dim3(grid), dim3(512), wino::LDS_BYTES, s, p);
+    if (p.ksplit > 1) {
+        const long long n4 = (long long)p.B * p.Cout * p.H * p.W / 4;
+        const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
+        hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.out, p.bias, p.res, p.res_up, p.act, p.ksplit, p.B, p.Cout, p.H,
+                           p.W);
+    }
     return hipGetLastError();
 }
 

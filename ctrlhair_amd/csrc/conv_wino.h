@@ -75,8 +75,13 @@ struct WinoParams {
     int pair16;             // set by the launcher for 16 x 16 images (B even): two samples side by side fill a tile of 32 x 16 pixels
     const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image patch elements)
     unsigned* claim;        // eight zeroed counters: dynamic task claiming (below; Cin >= 24), or null: static split
+    float* partial;         // split-K workspace of partial_cap floats, or null.  Launches with far fewer tasks than CUs (single images on the deep
+    long long partial_cap;  //   levels: 64 tasks of 256 k-steps each) are split over the input channels: `ksplit` slices, each a task of its own
+                            //   that writes its raw output-transformed sums to partial[slice][B][Cout][H][W]; wino_splitk_reduce adds the
+                            //   slices in order (deterministic) and applies bias / residual / activation
     // set by the launcher
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
+    int ksplit;             // 1, or the number of K slices (ntasks counts every (slice, task))
 };
 
 // ---- host: weight transform + packing -------------------------------------------------------------------------------------
@@ -243,7 +248,9 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
     }
     if (lb >= p.ntasks) return;
     int ct = lb;                                   // the task the consumers work on
-    const int nk = p.nks;
+    const int KSP = (D2S == 0 && p.ksplit > 1) ? p.ksplit : 1;            // K slices: task index = slice * nbase + (row tile, tile) index
+    const int nbase = p.ntasks / KSP;
+    const int nk = p.nks / KSP;
     const int HW = p.H * p.W;
     const int Ws = UP ? p.W >> 1 : p.W, HWs = UP ? HW >> 2 : HW;          // the input planes as stored
     constexpr unsigned SB = SDW * 4, RING = NST * SB;
@@ -257,7 +264,8 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
     unsigned so_in = 0, so_a = 0;
     auto issue_task = [&]() {
         int irt, tile;
-        wino_task(p, it, irt, tile);
+        const int isp = it / nbase;            // K slice of the task
+        wino_task(p, it - isp * nbase, irt, tile);
         const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty, ib = tile / (p.ntx * p.nty);
         const int y0 = ty * TH - 1, x0 = tx * TW - 1;
 #pragma unroll
@@ -278,9 +286,10 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             const bool ok = k4 < 4 && rem < PROWS * PWP && (p.pair16 || px < TW + 2) && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             voff[i] = ok ? (unsigned)((sub * p.Cin + k4) * HWs + (UP ? (y >> 1) * Ws + (x >> 1) : y * p.W + x)) * 4u : 0x80000000u;
         }
-        d_in = p.pair16 ? wino_rsrc(p.in + (long long)ib * 2 * p.Cin * HWs, 2u * (unsigned)p.Cin * HWs * 4u)
-                        : wino_rsrc(p.in + (long long)ib * p.Cin * HWs, (unsigned)p.Cin * HWs * 4u);
-        d_a = wino_rsrc(p.wpk + (long long)irt * p.nks * 2048, (unsigned)p.nks * 8192u);
+        const long long c0 = (long long)isp * nk * 4;                       // first input channel of the slice
+        d_in = p.pair16 ? wino_rsrc(p.in + ((long long)ib * 2 * p.Cin + c0) * HWs, (unsigned)(2 * p.Cin - c0) * HWs * 4u)
+                        : wino_rsrc(p.in + ((long long)ib * p.Cin + c0) * HWs, (unsigned)(p.Cin - c0) * HWs * 4u);
+        d_a = wino_rsrc(p.wpk + ((long long)irt * p.nks + (long long)isp * nk) * 2048, (unsigned)nk * 8192u);
         so_in = 0;
         so_a = 0;
     };
@@ -466,7 +475,13 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             after_epi = true;
         } else {
             int crt, tile;
-            wino_task(p, ct, crt, tile);
+            const int csp = ct / nbase;
+            wino_task(p, ct - csp * nbase, crt, tile);
+            const bool slice = KSP > 1;                  // a K slice: raw sums into its slab (bias / residual / activation: wino_splitk_reduce)
+            float* const obase = slice ? p.partial + (long long)csp * p.B * p.Cout * HW : p.out;
+            const float* const rbase = slice ? nullptr : p.res;
+            const float* const bbase = slice ? nullptr : p.bias;
+            const int eact = slice ? ACT_NONE : p.act;
             const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty;
             const int b = p.pair16 ? 2 * (tile / (p.ntx * p.nty)) + (n >> 3) : tile / (p.ntx * p.nty);
             const int y = ty * TH + 2 * wave, x = p.pair16 ? 2 * (n & 7) : tx * TW + 2 * n;
@@ -478,10 +493,10 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = crt * 32 + m * 16 + 4 * kk + i, rc = row < p.Cout ? row : p.Cout - 1;
-                    bs[m][i] = p.bias ? p.bias[rc] : 0.f;
+                    bs[m][i] = bbase ? bbase[rc] : 0.f;
                     r0[m][i] = r1[m][i] = make_float2(0.f, 0.f);
-                    if (p.res) {
-                        const float* rp = p.res + ((long long)b * p.Cout + rc) * rHW;
+                    if (rbase) {
+                        const float* rp = rbase + ((long long)b * p.Cout + rc) * rHW;
                         if (p.res_up) {
                             const float r = rp[(y >> 1) * rW + (x >> 1)];
                             r0[m][i] = r1[m][i] = make_float2(r, r);
@@ -503,12 +518,12 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
                     wino_out_transform(M, y00, y01, y10, y11);
                     y00 += bs[m][i] + r0[m][i].x; y01 += bs[m][i] + r0[m][i].y;
                     y10 += bs[m][i] + r1[m][i].x; y11 += bs[m][i] + r1[m][i].y;
-                    if (p.act != ACT_NONE) {
-                        y00 = apply_act(y00, p.act); y01 = apply_act(y01, p.act);
-                        y10 = apply_act(y10, p.act); y11 = apply_act(y11, p.act);
+                    if (eact != ACT_NONE) {
+                        y00 = apply_act(y00, eact); y01 = apply_act(y01, eact);
+                        y10 = apply_act(y10, eact); y11 = apply_act(y11, eact);
                     }
                     if (row < p.Cout) {
-                        float* op = p.out + ((long long)b * p.Cout + row) * HW + y * p.W + x;
+                        float* op = obase + ((long long)b * p.Cout + row) * HW + y * p.W + x;
                         *reinterpret_cast<float2*>(op) = make_float2(y00, y01);
                         *reinterpret_cast<float2*>(op + p.W) = make_float2(y10, y11);
                     }
@@ -1227,7 +1242,7 @@ inline void wino_fill_launch(WinoParams& p) {
     p.tbk = 32 / p.rb;
 }
 
-hipError_t conv_wino_plain(WinoParams p, hipStream_t s);     // conv_inst_wino.hip
+hipError_t conv_wino_plain(WinoParams p, hipStream_t s);     // conv_inst_wino.hip (chooses the K split and runs the reduce pass itself)
 hipError_t conv_wino_ace(WinoAceParams p, hipStream_t s);
 // wsty[b][rt][s][idx][lane][4] <- Winograd transform of the style LUT lut[(b*19 + j)][tap][gamma|beta][C] (exact-f32 layout)
 hipError_t wino_style_pack(const float* lut, float* wsty, int B, int C, hipStream_t s);

@@ -1453,6 +1453,8 @@ struct Runner {
             q.act = ACT_NONE;
             q.zero = m.zero_page;
             q.claim = next_claim();
+            q.partial = m.splitk_ws;               // (launches with far fewer tasks than CUs split K: conv_wino_plain)
+            q.partial_cap = m.splitk_cap;
             next_flops_exec = 2.0 * w.Cout * w.Cin * 16.0 * npix / 4.0;
             timed(0, 2.0 * w.Cout * w.Cin * 9.0 * npix,
                   4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * 16.0),
