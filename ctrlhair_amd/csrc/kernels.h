@@ -81,6 +81,8 @@ hipError_t shape_inputs_sh16(const uint8_t* lab, const float* pos, void* hair_in
                              hipStream_t s);      // SH16, 48 / 64 channels
 hipError_t linear(const float* x, const float* W, const float* bias, const float* scale, const float* shift, float* out,
                   int B, int K, int O, int ldx, int ldo, int act, hipStream_t s);
+// out[n][rows] = W[rows][512] x[n][:]: the style LUT of one ACE for N <= 64 (sample, label) columns on the f32 matrix cores (misc_kernels.hip)
+hipError_t lut_gemv_mfma(const float* x, const float* W, float* out, int N, int rows, hipStream_t s);
 hipError_t subspace_add(float* h, const float* z, int zld, const float* U, const float* L, const float* mu, int B, int D,
                         int Z, hipStream_t s);
 // poisson_kernels.hip: blending step after the generator (hair_editor.py:285-310, poisson_blending.py:29-87)

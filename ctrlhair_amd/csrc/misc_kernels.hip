@@ -1259,6 +1259,90 @@ hipError_t linear(const float* x, const float* W, const float* bias, const float
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Style LUT of ONE ACE at interactive batch sizes (normalization.py:117-153,172-173: conv_gamma / conv_beta of the projected codes):
+//   out[n][row] = sum_k W[row][k] x[n][k],   N <= 64 (sample, label) columns, K = 512, rows = 18 C (up to 18 432).
+// Weight-bandwidth bound (37.7 MB of W at C = 1024): W must stream once, at full width.  linear_kernel re-reads the N vectors from L1 for
+// every pair of rows and runs at 0.6 TB/s; here the vectors sit in LDS and the sums run on the f32 matrix cores: wave = 16 rows x all N
+// columns, lane (row i = lane & 15, g = lane >> 4) loads W[row][16 j + 4 g .. + 3] as ONE 16-byte load = the A operands of four MFMAs
+// (k-step e of the four takes element e: the k order inside the sum is a permutation, the B operand uses the same one), the B
+// operands x[n][16 j + 4 g + e] are one ds_read_b128 per 16-column tile.  Eight loads in flight per lane.
+constexpr int LUTG_K = 512;
+typedef float lutg_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int LUTG_XP = LUTG_K + 4;              // LDS row pitch of x (floats): rows 16 bytes apart in the banks
+template <int NT>
+__global__ __launch_bounds__(256) void lut_gemv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ out, int N, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // [NT * 16][LUTG_XP]
+    for (int i = threadIdx.x; i < NT * 16 * (LUTG_K / 4); i += 256) {
+        const int n = i / (LUTG_K / 4), k4 = i - n * (LUTG_K / 4);
+        const float4 v = n < N ? reinterpret_cast<const float4*>(x + (size_t)n * LUTG_K)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xs + n * LUTG_XP + 4 * k4) = v;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    const int ntile = (rows + 15) / 16;
+    for (int rt = blockIdx.x * 4 + wave; rt < ntile; rt += gridDim.x * 4) {
+        const int row = rt * 16 + i16, rc = row < rows ? row : rows - 1;
+        const float* wp = W + (size_t)rc * LUTG_K + 4 * g;
+        lutg_f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (lutg_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int j0 = 0; j0 < LUTG_K / 16; j0 += 8) {
+            float4 a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const float4*>(wp + 16 * (j0 + j));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 b = *reinterpret_cast<const float4*>(xs + (t * 16 + i16) * LUTG_XP + 16 * (j0 + j) + 4 * g);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b.w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // accumulator element r of lane (n = lane & 15, g): row 16 rt + 4 g + r, column n of the tile -> out[n][rows]: four consecutive rows
+        const int r0 = rt * 16 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = t * 16 + i16;
+            if (n < N && r0 + 3 < rows) *reinterpret_cast<float4*>(out + (size_t)n * rows + r0) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            else if (n < N)
+                for (int r = 0; r < 4; ++r)
+                    if (r0 + r < rows) out[(size_t)n * rows + r0 + r] = acc[t][r];
+        }
+    }
+}
+hipError_t lut_gemv_mfma(const float* x, const float* W, float* out, int N, int rows, hipStream_t s) {
+    if (N < 1 || N > 64 || rows < 1) return hipErrorInvalidValue;
+    const int nt = (N + 15) / 16;
+    const size_t lds = (size_t)nt * 16 * LUTG_XP * sizeof(float);
+    const int ntile = (rows + 15) / 16;
+    const int grid = (ntile + 3) / 4 < 1024 ? (ntile + 3) / 4 : 1024;
+    static bool attr_done[4][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+#define LUTG_LAUNCH(NT_)                                                                                                                          \
+    {                                                                                                                                             \
+        if (!attr_done[NT_ - 1][dev]) {                                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lut_gemv_mfma_kernel<NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)(NT_ * 16 * LUTG_XP * sizeof(float)));                                                        \
+            if (e != hipSuccess) return e;                                                                                                        \
+            attr_done[NT_ - 1][dev] = true;                                                                                                       \
+        }                                                                                                                                         \
+        hipLaunchKernelGGL(lut_gemv_mfma_kernel<NT_>, dim3(grid), dim3(256), lds, s, x, W, out, N, rows);                                         \
+    }
+    if (nt == 1) LUTG_LAUNCH(1)
+    else if (nt == 2) LUTG_LAUNCH(2)
+    else if (nt == 3) LUTG_LAUNCH(3)
+    else LUTG_LAUNCH(4)
+#undef LUTG_LAUNCH
+    return hipGetLastError();
+}
+
 // EigenGAN subspace injection (model_eigengan.py:27-31,76-81): h[b,:] = lrelu(h[b,:] + U (L * z[b,:]) + mu), z 2-d
 __global__ void subspace_add_kernel(float* __restrict__ h, const float* __restrict__ z, int zld, const float* __restrict__ U,
                                     const float* __restrict__ L, const float* __restrict__ mu, int B, int D, int Z) {

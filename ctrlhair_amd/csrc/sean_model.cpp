@@ -968,8 +968,7 @@ struct Runner {
                 // interactive batch sizes: P[n][row] = sum_k W[row][k] mu[n][k] as a batched GEMV (weight-bandwidth bound)
                 check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s, m.mu_img, 0, bs), "fc_mu");
                 tm(fl, by, [&] {
-                    check(linear(m.mu_img, a.lut_rows, nullptr, nullptr, nullptr, lut_buf, N, STYLE, 18 * a.C, STYLE, 18 * a.C,
-                                 ACT_NONE, s), "lut gemv");
+                    check(lut_gemv_mfma(m.mu_img, a.lut_rows, lut_buf, N, 18 * a.C, s), "lut gemv");
                 });
             } else if (m.use_sh16) {
                 // f16x3 LUT GEMM: 1x1 conv over the [npad/32 x 32] "image" of (sample, label) columns, C4 output
