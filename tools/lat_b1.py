@@ -25,7 +25,8 @@ def timeit(fn, n=30):
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 OPTS = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in sys.argv[2:]}
-for mode, name in ((1, 'f16x3'), (0, 'f32')):
+LEGS = [l for l in ((1, 'f16x3'), (0, 'f32')) if os.environ.get('LEG', l[1]) == l[1]]
+for mode, name in LEGS:
     g = SeanGenerator(0, f16x3=mode, options=OPTS).load_state_dict(P.sean_state_dict(0, 64), max_batch=1, max_size=S)
     dev = g.device
     l = torch.from_numpy(P.blocky_labels(1, S)).to(dev)
