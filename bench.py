@@ -130,6 +130,63 @@ def cpu_baseline(ngf, S, sd_np, budget_s=120.0, weights=None, b16=False):
     return out
 
 
+def interactive_b1(ngf, S, sd_np, weights, dev):
+    """BASELINE.json configs[0] on the GPU: ONE image at a time, the reference's own mode of use (hair_editor.py:159-179, ui/backend.py:147-175).
+    Generator render latency (batch 1, S x S, inputs resident) on both arithmetic paths, and one whole Config-1 edit on the HIP Backend --
+    the call sequence the CPU baseline times (cpu_baseline.config1_edit)."""
+    import numpy as np
+    import torch
+    from ctrlhair_amd import procedural as P
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    out = {'what': f'one {S}x{S} image per call (batch 1), median of 30 calls after 5 warm-up calls, inputs resident in HBM', 'unit': 'ms per image'}
+    for path, mode in (('f32', 0), ('f16x3', 1)):
+        g = SeanGenerator(dev.index or 0, f16x3=mode).load_state_dict(sd_np, max_batch=1, max_size=S)
+        l = torch.from_numpy(P.blocky_labels(1, S)).to(dev)
+        c = torch.from_numpy(P.style_codes(1)).to(dev)
+        n = torch.from_numpy(P.noise_planes(1, S, ngf)).to(dev)
+        for _ in range(5):
+            g.generate(l, c, n)
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(30):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.generate(l, c, n)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        out[path] = {'render_ms': round(float(np.median(ts)), 3), 'p10': round(float(np.percentile(ts, 10)), 3), 'p90': round(float(np.percentile(ts, 90)), 3)}
+        g.handle.close()
+        del g
+        torch.cuda.empty_cache()
+    if weights is not None:
+        try:
+            from ctrlhair_amd.ui.backend import Backend
+            img = np.ascontiguousarray(P.synthetic_images(1, 256, seed=11)[0].transpose(1, 2, 0))
+            img = np.clip((img * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
+            for path, f16 in (('f32', False), ('f16x3', True)):
+                be = Backend(2.5, blending=False, weights=weights, device=dev.index or 0, f16x3=f16)
+                ts = []
+                for rep in range(4):
+                    torch.cuda.synchronize(dev)
+                    t = time.time()
+                    be.set_input_img(img_rgb=img)
+                    be.change_curliness(1.0)
+                    be.change_texture(1.5, 0)
+                    be.change_shape(-1.0, 0)
+                    be.output()
+                    torch.cuda.synchronize(dev)
+                    ts.append((time.time() - t) * 1e3)
+                out[path]['config1_edit_ms'] = round(float(np.median(ts[1:])), 2)       # (first repetition: warm-up)
+                del be
+                torch.cuda.empty_cache()
+            out['config1_edit'] = ('one 256x256 portrait: set_input_img (parse, shape / style / colour encoders) + three slider moves + output() on the HIP '
+                                   'Backend, host wall-clock incl. the cv2-equivalent host code; the same calls as cpu_baseline.config1_edit')
+        except Exception as e:
+            out['config1_edit'] = {'error': f'{type(e).__name__}: {e}'}
+    return out
+
+
 def make_labels(kind, B, S, first):
     import numpy as np
     from ctrlhair_amd import procedural as P
@@ -619,6 +676,11 @@ def main():
             for path, r in pb.items():
                 res['pipeline'][path] = r
 
+    if rank == 0 and do_gen and extras and world == 1 and user_batch == 0:
+        try:
+            res['interactive_b1'] = interactive_b1(ngf, S, sd, all_weights, dev)
+        except Exception as e:          # never lose the line over a side block
+            res['interactive_b1'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and do_gen and not args.no_cpu_baseline and world == 1:
         res['cpu_baseline'] = cpu_baseline(ngf, S, sd, weights=all_weights, b16=args.cpu_b16)
     if dist is not None:

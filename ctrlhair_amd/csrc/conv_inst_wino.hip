@@ -64,7 +64,7 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
     if (p.in_up && (p.reflect || !wino_supported(p.H, p.W, p.Cin))) return hipErrorInvalidValue;      // (H, W: the conv's own = 2 x stored size)
     wino_fill_launch(p);
     p.ksplit = 1;
-    if (p.partial && !p.d2s && !p.in_up && p.W % 4 == 0) {        // far fewer tasks than CUs and a long k-loop: slices of the input channels
+    if (p.partial && !p.d2s && p.W % 4 == 0) {        // far fewer tasks than CUs and a long k-loop: slices of the input channels
         const int cus = wino_num_cus();
         int ks = 1;
         while (ks < 8 && 2 * ks * p.ntasks <= cus && p.nks % (2 * ks) == 0 && p.nks / (2 * ks) >= 16 &&
@@ -88,11 +88,11 @@ hipError_t conv_wino_plain(WinoParams p, hipStream_t s) {
         hipError_t e = wino_attr(wino_plain_kernel<2>, wino::LDS_BYTES, d2);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(wino_plain_kernel<2>, dim3(grid), dim3(512), wino::LDS_BYTES, s, p);
-        return hipGetLastError();
+    } else {
+        hipError_t e = wino_attr(wino_plain_kernel<0>, wino::LDS_BYTES, d0);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino_plain_kernel<0>, dim3(grid), dim3(512), wino::LDS_BYTES, s, p);
     }
-    hipError_t e = wino_attr(wino_plain_kernel<0>, wino::LDS_BYTES, d0);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wino_plain_kernel<0>, dim3(grid), dim3(512), wino::LDS_BYTES, s, p);
     if (p.ksplit > 1) {
         const long long n4 = (long long)p.B * p.Cout * p.H * p.W / 4;
         const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);

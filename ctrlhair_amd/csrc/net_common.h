@@ -305,6 +305,8 @@ inline hipError_t run_conv(const ConvLayer& L, const float* in, float* out, int 
             q.reflect = refl ? 1 : 0;
             q.in_up = up ? 1 : 0;
             q.zero = L.zero;
+            q.partial = o.partial;             // (few tasks, long k-loop: conv_wino_plain splits K)
+            q.partial_cap = o.partial_cap;
             return conv_wino_plain(q, st);
         }
     }
