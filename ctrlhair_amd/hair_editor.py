@@ -86,6 +86,7 @@ class HairEditor:
         True / False to choose explicitly."""
         if f16x3 is None:
             f16x3 = not is_released_checkpoint(weights)
+        U.cap_threads_to_cpu_quota()       # (a CPU thread pool larger than the container's CFS quota stalls every other edit for ~85 ms)
         if models is None:
             if weights == 'procedural':
                 weights = procedural_weights()
@@ -236,7 +237,7 @@ class HairEditor:
                              blender=None):
         def from_tensor_order_to_cv2(tensor_img, is_mask=False):
             if isinstance(tensor_img, torch.Tensor):
-                tensor_img = tensor_img.detach().cpu().numpy()
+                tensor_img = U.to_host(tensor_img)
             if len(tensor_img.shape) == 4:
                 tensor_img = tensor_img[0]
             if len(tensor_img.shape) == 2:
@@ -267,7 +268,7 @@ class HairEditor:
             if face_img.shape[:2] != res_img.shape[:2]:
                 face_img = U.resize_bilinear(face_img, res_img.shape[:2])
             out = blender(face_img, res_img, 1 - res_mask_dilated, with_gamma=True)
-            return out, res_mask_dilated.cpu().numpy()[..., None]
+            return out, U.to_host(res_mask_dilated)[..., None]
         # injected reference blender (`blender=poisson_blending.poisson_blending`): needs cv2 for the dilations
         cv2 = U._cv2()
         if blender is None or cv2 is None:

@@ -16,12 +16,74 @@ PARSING_LABEL_LIST = ['background', 'skin_other', 'nose', 'eye_g', 'l_eye', 'r_e
 TEMP_FOLDER = 'temp_folder'
 
 
+_CV2 = [False, None]          # [probed, module]: a failed import costs ~6 ms of path search, and output() asks on every call
+
+
 def _cv2():
+    if not _CV2[0]:
+        try:
+            import cv2
+            _CV2[1] = cv2 if hasattr(cv2, 'cvtColor') else None      # (an import-only stub module is not cv2)
+        except Exception:
+            _CV2[1] = None
+        _CV2[0] = True
+    return _CV2[1]
+
+
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup CFS quota (cpu.max / cfs_quota_us) if one is set, else os.cpu_count()."""
+    n = os.cpu_count() or 1
     try:
-        import cv2
-        return cv2 if hasattr(cv2, 'cvtColor') else None      # (an import-only stub module is not cv2)
+        with open('/sys/fs/cgroup/cpu.max') as f:                       # cgroup v2
+            q, per = f.read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
     except Exception:
-        return None
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:      # cgroup v1
+                q = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def cap_threads_to_cpu_quota():
+    """torch sizes its CPU thread pool by the visible cores (256 on the MI355X box) even when the container's CFS quota is 16 CPUs: the pool's
+    spin-waits around the tiny host-side tensor ops of an edit then exhaust the quota and the whole process is descheduled for the rest of
+    the 100 ms period -- every second or third Backend.output() took 90 ms instead of 5 (tools/spike_probe.py).  Never raises the count."""
+    import torch
+    q = cpu_quota()
+    if torch.get_num_threads() > q:
+        torch.set_num_threads(q)
+    return q
+
+
+_PINNED = {}
+
+
+def to_host(t):
+    """Device tensor -> numpy array through a cached PINNED staging buffer per (shape, dtype).  A plain `.cpu()` allocates fresh pageable
+    memory for every call, which the runtime has to lock page by page before the DMA: on the ROCm 7 stack of the target box that path
+    stalls for ~85 ms on every second or third 0.8 MB image (tools/spike_probe.py), i.e. more than the whole edit.  The result is a
+    private copy (the staging buffer is reused by the next call)."""
+    import torch
+    if not isinstance(t, torch.Tensor):
+        return np.asarray(t)
+    t = t.detach()
+    if not t.is_cuda:
+        return t.numpy()
+    key = (tuple(t.shape), t.dtype)
+    buf = _PINNED.get(key)
+    if buf is None:
+        if len(_PINNED) > 64:
+            _PINNED.clear()
+        buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    buf.copy_(t.contiguous())          # synchronous: the data has landed when copy_ returns
+    return buf.numpy().copy()
 
 
 def _linear_taps(n_out: int, n_in: int):

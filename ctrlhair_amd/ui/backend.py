@@ -70,19 +70,19 @@ class Backend(HairEditor):
         mask_batch = self.preprocess_mask(mask)
         mask_tensor = torch.tensor(mask256[None], dtype=torch.uint8, device=self.device)
         lr.shape, lr.face = self.mask_generator.encode_labels(mask_tensor)   # == one-hot, split, two encoders (:81-86)
-        decoded = self.mask_generator.decode_labels(lr.shape, lr.face).cpu().numpy()[0]      # :87-90
+        decoded = U.to_host(self.mask_generator.decode_labels(lr.shape, lr.face))[0]      # :87-90
         # hair appearance: Zencoder code of the hair region -> colour statistics and texture / curliness latents (:93-105)
         codes = self.get_code(self.preprocess_img(img_rgb), mask_batch)
         hair = codes[:, HAIR_IDX]
         stats = self.feature_rgb_predictor({'code': hair})
-        rgb_u8 = np.clip(stats['rgb_mean'].detach().cpu().numpy(), 0, 255).astype('uint8')
+        rgb_u8 = np.clip(U.to_host(stats['rgb_mean']), 0, 255).astype('uint8')
         lr.color = {'hsv': torch.tensor(U.rgb_to_hsv_u8(rgb_u8[None, ...])).to(self.device)[0], 'pca_std': stats['pca_std']}
         latents = self.feature_encoder({'code': hair})
         lr.curliness, lr.texture = latents['noise_curliness'], latents['noise']
         return img_ts, decoded, lr, mask, codes, hair
 
     def _convert_u8(self, t, fn):
-        arr = t.detach().cpu().numpy().astype('uint8')            # the reference truncates to uint8 before cv2.cvtColor
+        arr = U.to_host(t).astype('uint8')            # the reference truncates to uint8 before cv2.cvtColor
         return torch.tensor(fn(arr[None, ...])).to(self.device)[0]
 
     def tensor_hsv_to_rgb(self, hsv):             # :108-115
@@ -149,7 +149,7 @@ class Backend(HairEditor):
         feature = self.feature_generator(data)['code']                               # [N,512]
         codes = self.input_sean_code.expand(n, -1, -1).clone()
         codes[:, HAIR_IDX] = feature
-        masks_np = masks.cpu().numpy()
+        masks_np = U.to_host(masks)
         lab = np.stack([self._mask_for_sean(m) for m in masks_np])
         if noise is None and self.noise is not None:                                 # pinned planes: same draw for every image
             noise = self.noise.expand(n, -1).contiguous() if self.noise.shape[0] == 1 else self.noise
@@ -212,7 +212,7 @@ class Backend(HairEditor):
         return self.cur_latent.curliness[0]
 
     def get_color_be2fe(self):
-        hsv = self.cur_latent.color['hsv'].detach().cpu().numpy()[0]
+        hsv = U.to_host(self.cur_latent.color['hsv'])[0]
         sliders = [self.dist_translation.val_to_gaussian(i, hsv[i]) for i in range(3)]
         spread = (self.cur_latent.color['pca_std'][0] - 20) / 100            # inverse of change_color(.., 3)
         return (*sliders, spread * 2 * self.maximum_value_fe - self.maximum_value_fe)
@@ -248,7 +248,7 @@ class Backend(HairEditor):
 
     def refresh_cur_mask(self, target_latent=None):      # :304-315
         lat = self.cur_latent if target_latent is None else target_latent
-        self.cur_mask = self.mask_generator.decode_labels(lat.shape, lat.face).cpu().numpy()[0]
+        self.cur_mask = U.to_host(self.mask_generator.decode_labels(lat.shape, lat.face))[0]
         return self.cur_mask, mask_to_rgb(self.cur_mask, draw_type=1)
 
     def get_cur_mask(self):
@@ -301,7 +301,7 @@ class Backend(HairEditor):
         # a hair "logit" that beats every face logit inside the drawn region (hi + 1) and loses everywhere else (lo - 1)
         drawn = torch.tensor(hair_mask == HAIR_IDX)[None, None, ...].type_as(face).to(self.device)
         hair = drawn * (hi - lo + 2) + lo - 1
-        self.cur_mask = mask_one_hot_to_label(self.mask_generator.forward_decoder(hair, face)).cpu().numpy()[0]
+        self.cur_mask = U.to_host(mask_one_hot_to_label(self.mask_generator.forward_decoder(hair, face)))[0]
 
     def get_random_texture(self):
         self.cur_latent.texture = generate_noise(1, 8).to(self.device)

@@ -19,7 +19,7 @@ img = np.ascontiguousarray(P.synthetic_images(1, 256, seed=11)[0].transpose(1, 2
 img = np.clip((img * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
 steps = [('set_input_img', lambda: be.set_input_img(img_rgb=img)), ('change_curliness', lambda: be.change_curliness(1.0)),
          ('change_texture', lambda: be.change_texture(1.5, 0)), ('change_shape', lambda: be.change_shape(-1.0, 0)), ('output', lambda: be.output())]
-for rep in range(4):
+for rep in range(14):
     ts = []
     for name, fn in steps:
         torch.cuda.synchronize()
