@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'slow: long CPU oracle runs')
+    # the CPU oracles run on torch's thread pool: sized by the visible cores (256 on the GPU box) it spins the container's 16-CPU CFS
+    # quota away and every oracle forward runs throttled (4-5x slower): keep the pool inside the quota
+    try:
+        from ctrlhair_amd.hostutil import cap_threads_to_cpu_quota
+        cap_threads_to_cpu_quota()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope='session')
