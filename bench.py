@@ -532,6 +532,10 @@ def main():
         raise SystemExit(f'rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    # host thread pool: torch sizes it by the visible cores; under a container CPU quota (16 CPUs on the 1-GPU box) the pool's spin-waits get
+    # the process descheduled for most of a 100 ms period -- with N ranks on one node each rank gets its share of the quota
+    from ctrlhair_amd.hostutil import cpu_quota
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_quota() // max(1, world))))
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
