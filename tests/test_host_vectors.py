@@ -41,3 +41,27 @@ def test_structuring_elements():
     for k in (5, 13, 19):
         assert np.array_equal(PO.ellipse_kernel(k), Z[f'ellipse{k}'])
     assert Z['ellipse5'].tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+
+
+def test_cpu_quota_and_thread_cap():
+    """hostutil.cpu_quota: between 1 and the visible cores; cap_threads_to_cpu_quota never raises torch's thread count."""
+    import os
+    import torch
+    from ctrlhair_amd import hostutil as U
+    q = U.cpu_quota()
+    assert 1 <= q <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    assert U.cap_threads_to_cpu_quota() == q
+    assert torch.get_num_threads() == min(before, q)
+
+
+def test_to_host_returns_private_copies():
+    """hostutil.to_host: numpy in, numpy out; CPU tensors as arrays; (device tensors: a private copy per call, checked on the GPU box by the
+    Backend tests, which compare successive output() results)."""
+    import numpy as np
+    import torch
+    from ctrlhair_amd import hostutil as U
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    assert np.array_equal(U.to_host(a), a)
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    assert np.array_equal(U.to_host(t), a)
