@@ -18,6 +18,13 @@ hipError_t label_onehot_planes(const uint8_t* lab, float* out, int B, int H, int
 // (pitch = 0: plain [H][W] planes; xoff > 0: the padded layout of the Winograd ACE kernels, conv_wino.h WINO_AXOFF -- the columns
 // left and right of the image must hold zeros, the kernel never writes them: the caller clears them).  Shapes: spade_hidden_wq_supported (H, W multiples of 32).
 bool spade_hidden_wq_supported(int H, int W);
+// Second half of an ACE whose SPADE gamma / beta conv ran as a PLAIN conv (tiny levels at small batches: sean_model.cpp ace()):
+//   gb [B][rowsP][H*W] holds the raw conv sums in the row order of the direct kernels' packed image (wave tile of 64 rows = gamma rows |
+//   beta rows of 32 channels); adds the blended biases and the style-LUT gathers (lut [B*19][9][2][C] or null), modulates
+//   act((bn_a x + nv noise + bn_d)(1 + gamma) + beta) -- normalization.py:111-112,117-153,172-187; the arithmetic of ace_epilogue_f32.
+hipError_t ace_finish_f32(const float* gb, int rowsP, const float* x, int x_up, const float* bias_g, const float* bias_b, const float* bn_a,
+                          const float* bn_d, const float* nv, const float* noise, long long noise_bstride, const uint8_t* lab, const float* lut,
+                          float* out, int B, int C, int H, int W, int act, hipStream_t s);
 hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* table, const float* bias, float* out, int B, int H, int W,
                            int kout, int onehot, hipStream_t s, int pitch = 0, int xoff = 0);
 // `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)

@@ -6,6 +6,73 @@
 namespace chk {
 
 // ---------------------------------------------------------------------------------------------------------
+// ace_finish_f32 (kernels.h): one thread = one pixel x AF_CG channels; block = 256 consecutive pixels of a sample.
+constexpr int AF_CG = 8;
+__global__ __launch_bounds__(256) void ace_finish_f32_kernel(const float* __restrict__ gb, int rowsP, const float* __restrict__ x, int x_up,
+                                                             const float* __restrict__ bias_g, const float* __restrict__ bias_b,
+                                                             const float* __restrict__ bn_a, const float* __restrict__ bn_d,
+                                                             const float* __restrict__ nv, const float* __restrict__ noise, long long noise_bstride,
+                                                             const uint8_t* __restrict__ lab, const float* __restrict__ lut, float* __restrict__ out,
+                                                             int B, int C, int H, int W, int act) {
+    const int HW = H * W, ppb = (HW + 255) / 256;
+    const int b = blockIdx.x / ppb, pix = (blockIdx.x - b * ppb) * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int y = pix / W, xx = pix - y * W;
+    const int c0 = blockIdx.y * AF_CG;
+    const int xW = W >> x_up, xHW = xW * (H >> x_up);
+    const float nz = noise[(long long)b * noise_bstride + (long long)xx * H + y];          // plane layout [W][H]
+    const float* xp = x + ((long long)b * C + c0) * xHW + (y >> x_up) * xW + (xx >> x_up);
+    const float* gp = gb + (long long)b * rowsP * HW + pix;
+    float* op = out + ((long long)b * C + c0) * HW + pix;
+    unsigned lo[9];
+    unsigned lmask = 0;                   // bit t: the tap carries a style term (inside the image, label < 19)
+    const float* Lb = lut ? lut + (long long)b * 19 * 9 * 2 * C : nullptr;
+    if (Lb) {
+        const uint8_t* lb = lab + (long long)b * HW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, x2 = xx + t % 3 - 1;
+            const bool in = (unsigned)yy < (unsigned)H && (unsigned)x2 < (unsigned)W;
+            const unsigned jv = lb[in ? yy * W + x2 : 0];
+            const bool on = in && jv < 19u;
+            lmask |= on ? 1u << t : 0u;
+            lo[t] = ((on ? jv : 0u) * 9u + (unsigned)t) * 2u * (unsigned)C;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < AF_CG; ++i) {
+        const int c = c0 + i;
+        if (c >= C) break;
+        const int rg = (c >> 5) * 64 + (c & 31);           // gamma row of channel c in the packed image's order; beta: + 32
+        float sg = 0.f, sb = 0.f;
+        if (Lb) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float w = ((lmask >> t) & 1u) ? 1.f : 0.f;
+                sg += w * Lb[lo[t] + c];
+                sb += w * Lb[lo[t] + C + c];
+            }
+        }
+        const float gam = gp[(long long)rg * HW] + (bias_g[c] + sg);
+        const float bet = gp[(long long)(rg + 32) * HW] + (bias_b[c] + sb);
+        const float nrm = bn_a[c] * xp[(long long)i * xHW] + nv[c] * nz + bn_d[c];
+        float o = nrm * (1.f + gam) + bet;
+        if (act == 1) o = fmaxf(o, 0.2f * o);              // ACT_LRELU
+        else if (act == 2) o = fmaxf(o, 0.f);              // ACT_RELU
+        op[(long long)i * HW] = o;
+    }
+}
+hipError_t ace_finish_f32(const float* gb, int rowsP, const float* x, int x_up, const float* bias_g, const float* bias_b, const float* bn_a,
+                          const float* bn_d, const float* nv, const float* noise, long long noise_bstride, const uint8_t* lab, const float* lut,
+                          float* out, int B, int C, int H, int W, int act, hipStream_t s) {
+    if (act < 0 || act > 2) return hipErrorInvalidValue;
+    const int ppb = (H * W + 255) / 256;
+    hipLaunchKernelGGL(ace_finish_f32_kernel, dim3((unsigned)(B * ppb), (unsigned)((C + AF_CG - 1) / AF_CG)), dim3(256), 0, s, gb, rowsP, x, x_up, bias_g, bias_b,
+                       bn_a, bn_d, nv, noise, noise_bstride, lab, lut, out, B, C, H, W, act);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // F.interpolate(seg, size, mode='nearest') on the label map (generator.py:75, normalization.py:115):
 // src = floor(dst * in/out); in/out is an integer here (S / r).
 __global__ void label_down_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int S, int r) {

@@ -443,6 +443,12 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     if (zero_page) (void)hipMemset(zero_page, 0, 256);
     splitk_cap = (long long)16 << 20;     // 64 MiB of split-K slabs (low-resolution layers only)
     splitk_ws = B.falloc((size_t)splitk_cap);
+    gb_small = nullptr;
+    gb_small_cap = 0;
+    if (!use_sh16) {
+        gb_small_cap = (long long)4 << 20;      // 16 MiB: rows x pixels of the tiny ACE launches that take the plain split-K route
+        gb_small = B.falloc((size_t)gb_small_cap);
+    }
     n_aces = ace_index;
     // Run-ahead mode of small jobs (Runner::prepare_all_ahead): a side stream, one join event and one set of buffers per ACE.
     // Only when the handle is sized for interactive work -- for large batches the convs own every CU and nothing co-schedules.
@@ -1362,6 +1368,31 @@ struct Runner {
                 check(conv_sh16_ace(p, st), "spade conv (second pass)");
             }
             return;
+        }
+        if (!m.use_sh16 && m.gb_small) {
+            // Tiny levels at small batches (one image at 16 x 16: 16 blocks of the fused kernel, 8 % of the CUs, 200 us): the SPADE conv as a
+            // PLAIN conv over the same packed image -- which splits K over blocks when its grid is small (conv_mfma.h launch_conv) -- into
+            // a scratch of gamma | beta sums, then ace_finish_f32 (style-LUT gathers, biases, modulation).  Same sums per element, the
+            // split-K slabs added in order: deterministic.
+            const int rowsP = ((a.C + 31) / 32) * 64;
+            const long long tiles = ((long long)B * r * r + 255) / 256;
+            if (((rowsP + 127) / 128) * tiles < 128 && (long long)rowsP * B * r * r <= m.gb_small_cap) {
+                ConvParams c = p;
+                c.out = m.gb_small;
+                c.Mrows = rowsP;
+                c.bias = nullptr;
+                c.res = nullptr;
+                c.act = ACT_NONE;
+                c.partial = m.splitk_ws;
+                c.partial_cap = m.splitk_cap;
+                c.dbg &= ~256;
+                timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] {
+                    check(conv_plain3(c, st), "spade conv (plain, split-K)");
+                    check(ace_finish_f32(m.gb_small, rowsP, x, x_up, a.bias_g, a.bias_b, a.bn_a, a.bn_d, a.nv, noise + noff, (long long)nf, lab, q.lut,
+                                         static_cast<float*>(hout), B, a.C, r, r, act, st), "ace finish");
+                });
+                return;
+            }
         }
         timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * HID + xin + npix * a.C + 2.0 * a.C * HID * 9), [&] {
             if (!m.use_sh16) {

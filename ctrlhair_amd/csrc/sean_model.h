@@ -66,6 +66,8 @@ struct ProfRec {
 
 struct SeanModel {
     int ngf = 0, max_batch = 0, max_size = 0;
+    float* gb_small = nullptr;                  // exact-f32 path: gamma | beta sums of a tiny ACE level whose SPADE conv runs as a plain split-K conv (ace())
+    long long gb_small_cap = 0;
     float* splitk_ws = nullptr;
     long long splitk_cap = 0;
     int dbg = 0;               // perf experiments (conv_mfma.h ConvParams::dbg)
