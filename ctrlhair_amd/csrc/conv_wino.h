@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             voff[i] = ok ? (unsigned)((sub * p.Cin + k4) * HWs + (UP ? (y >> 1) * Ws + (x >> 1) : y * p.W + x)) * 4u : 0x80000000u;
         }
         const long long c0 = (long long)isp * nk * 4;                       // first input channel of the slice
-        d_in = p.pair16 ? wino_rsrc(p.in + ((long long)ib * 2 * p.Cin + c0) * HWs, (unsigned)(2 * p.Cin - c0) * HWs * 4u)
+        d_in = p.pair16 ? wino_rsrc(p.in + ((long long)ib * 2 * p.Cin + c0) * HWs, (unsigned)((2 * ib + 1 < p.B ? 2 : 1) * p.Cin - c0) * HWs * 4u)
                         : wino_rsrc(p.in + ((long long)ib * p.Cin + c0) * HWs, (unsigned)(p.Cin - c0) * HWs * 4u);
         d_a = wino_rsrc(p.wpk + ((long long)irt * p.nks + (long long)isp * nk) * 2048, (unsigned)nk * 8192u);
         so_in = 0;
@@ -483,7 +483,9 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
             const float* const bbase = slice ? nullptr : p.bias;
             const int eact = slice ? ACT_NONE : p.act;
             const int tx = tile % p.ntx, ty = (tile / p.ntx) % p.nty;
-            const int b = p.pair16 ? 2 * (tile / (p.ntx * p.nty)) + (n >> 3) : tile / (p.ntx * p.nty);
+            const int b0 = p.pair16 ? 2 * (tile / (p.ntx * p.nty)) + (n >> 3) : tile / (p.ntx * p.nty);
+            const bool bval = b0 < p.B;                  // (pair16 with an odd batch: the last tile's second sample does not exist)
+            const int b = bval ? b0 : p.B - 1;
             const int y = ty * TH + 2 * wave, x = p.pair16 ? 2 * (n & 7) : tx * TW + 2 * n;
             const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
             float bs[2][4];
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(512, 1) void wino_plain_kernel(const WinoParams p) 
                         y00 = apply_act(y00, eact); y01 = apply_act(y01, eact);
                         y10 = apply_act(y10, eact); y11 = apply_act(y11, eact);
                     }
-                    if (row < p.Cout) {
+                    if (row < p.Cout && bval) {
                         float* op = obase + ((long long)b * p.Cout + row) * HW + y * p.W + x;
                         *reinterpret_cast<float2*>(op) = make_float2(y00, y01);
                         *reinterpret_cast<float2*>(op + p.W) = make_float2(y10, y11);
@@ -1228,14 +1230,15 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
 
 inline bool wino_supported(int H, int W, int Cin) { return H % wino::TH == 0 && W % wino::TW == 0 && Cin % 8 == 0 && H >= 16; }
 // 16 x 16 images (the generator's head block at 512^2): pairs of samples share a tile
-inline bool wino_supported_pair16(int B, int H, int W, int Cin) { return H == 16 && W == 16 && B % 2 == 0 && Cin % 8 == 0; }
+// (an odd batch leaves the last tile's second half empty: its patch reads fall behind the tensor's end and return zeros, its stores are skipped)
+inline bool wino_supported_pair16(int B, int H, int W, int Cin) { return H == 16 && W == 16 && B >= 1 && Cin % 8 == 0; }
 
 inline void wino_fill_launch(WinoParams& p) {
     p.nrt = (p.Cout + 31) / 32;
     p.pair16 = (p.W == 16 && p.H == 16) ? 1 : 0;
     p.ntx = p.pair16 ? 1 : p.W / wino::TW;
     p.nty = p.H / wino::TH;
-    p.ntiles = (p.pair16 ? p.B / 2 : p.B) * p.ntx * p.nty;
+    p.ntiles = (p.pair16 ? (p.B + 1) / 2 : p.B) * p.ntx * p.nty;
     p.ntasks = p.ntiles * p.nrt;
     p.nks = p.Cin / 4;
     p.rb = p.nrt >= 4 ? 4 : p.nrt;

@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
         {2, 16, 16, 32, 0, 0, "tiny"}, {3, 32, 48, 64, 0, 1, "tiny res, ragged rows"}, {1, 28, 32, 32, 0, 2, "tiny res_up, odd k-steps"},
         {2, 64, 64, 64, 0, 1, "small res"}, {4, 32, 48, 16, 0, 1, "16^2 sample pairs, ragged rows"}, {16, 1024, 1024, 16, 0, 1, "G_head conv (+x), 16^2 pairs"},
         {1, 1024, 1024, 32, 0, 1, "B=1 G_middle conv_1 (+x): split-K"}, {1, 1024, 512, 64, 0, 0, "B=1 up_0 conv_0: split-K"},
-        {1, 512, 512, 64, 0, 2, "B=1 512->512 64^2 res_up: split-K"}, {2, 256, 64, 16, 0, 1, "B=2 16^2 pair: split-K"},
+        {1, 512, 512, 64, 0, 2, "B=1 512->512 64^2 res_up: split-K"}, {2, 256, 64, 16, 0, 1, "B=2 16^2 pair: split-K"}, {1, 1024, 1024, 16, 0, 1, "B=1 16^2 lone sample in a pair tile: split-K"}, {3, 64, 48, 16, 0, 1, "B=3 16^2: odd batch"},
         {16, 1024, 1024, 32, 0, 0, "G_middle conv_0"}, {16, 1024, 1024, 32, 0, 1, "G_middle conv_1 (+x)"},
         {16, 1024, 512, 64, 0, 0, "up_0 conv_0"}, {16, 512, 512, 64, 0, 1, "up_0 conv_1 (+xs)"},
         {16, 512, 256, 128, 0, 0, "up_1 conv_0"}, {16, 256, 256, 128, 0, 1, "up_1 conv_1 (+xs)"},
