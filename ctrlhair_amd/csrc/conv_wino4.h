@@ -110,6 +110,33 @@ __device__ __forceinline__ void wino4_out1d(float m0, float m1, float m2, float 
     y3 = __builtin_fmaf(8.f, d2, d1) + m5;
 }
 
+// The two halo columns of a patch row (q[0]: dword 3 of a 16-byte unit, q[5]: dword 0 of the unit after next).  As 4-byte reads every
+// lane's address is = 3 (= 0) mod 4 and the 32 lanes of a ds_read_b32 group fall on 8 of its 32 banks (4-way conflict: 53 % of the
+// LDS pipe's active cycles in rocprof's SQ_LDS_BANK_CONFLICT, round 5).  Round 6 tried the zero-vector-instruction remedy (-DCH_W4_HALO64):
+// aligned 8-byte reads of (q[-1], q[0]) and (q[5], q[6]) -- bank modulus 64, 32 lanes of a group on 32 of 64 banks (2-way), the unused
+// halves kept alive by an empty asm so that the compiler does not narrow the reads, the right halo addressed from its own base
+// register so that the pair is not fused into one ds_read2_b64 (groups of 16 lanes on 32 banks again).  Measured 2.4 % SLOWER on every
+// ResBlock conv shape (profiles/r06_wino4_halo64.txt: 16.64 vs 16.26 ms over the twelve convs of a step, two alternating runs): the
+// conflict cycles are not on the critical path of this kernel, the doubled return data is.  The 4-byte reads stay.
+typedef float wino4_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const wino4_f32x2 wino4_lds_f2;
+__device__ __forceinline__ wino4_lds_f2* wino4_halo_base(const float* right_halo_row0) {
+    wino4_lds_f2* b = (wino4_lds_f2*)right_halo_row0;
+    asm volatile("" : "+v"(b));
+    return b;
+}
+__device__ __forceinline__ void wino4_halo(const float* q, wino4_lds_f2* hb, int r, float& d0, float& d5) {
+#ifndef CH_W4_HALO64
+    d0 = q[0];
+    d5 = q[5];
+#else
+    const wino4_f32x2 lo = *reinterpret_cast<const wino4_f32x2*>(q - 1), hi = hb[r * (wino4::PUN * 2)];
+    asm volatile("" ::"v"(lo.x), "v"(hi.y));
+    d0 = lo.y;
+    d5 = hi.x;
+#endif
+}
+
 // MODE bit 0: reflection padding (the Zencoder's 256 -> 512 conv, architecture.py:174).  Rows: a reflected row is a source offset like any
 // other.  Columns: the patch arrives as aligned 4-pixel units, so the unit left of column 0 (right of column W - 1) holds zeros; the one
 // element of it a block reads -- its column 0 at the image's left edge, column 5 at the right edge -- is replaced in registers by the
@@ -229,12 +256,11 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
         l = ttx_ == 0 && tx == 0;
         r = ttx_ == p.ntx - 1 && tx == 7;
     };
-    auto load_row = [&](const float* sp, int r, float (&d)[6]) {               // patch row r of the lane's tile: 1 + 4 + 1 floats
+    auto load_row = [&](const float* sp, wino4_lds_f2* hb, int r, float (&d)[6]) {      // patch row r of the lane's tile: 1 + 4 + 1 floats
         const float* q = sp + boff + r * (PUN * 4);
-        d[0] = q[0];
         const f32x4 mid = *reinterpret_cast<const f32x4*>(q + 1);
         d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w;
-        d[5] = q[5];
+        wino4_halo(q, hb, r, d[0], d[5]);
         if constexpr (REFL) {
             d[0] = eL ? d[2] : d[0];
             d[5] = eR ? d[3] : d[5];
@@ -251,10 +277,11 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
     if constexpr (REFL) edge_of(lb, eL, eR);
     {   // B fragments of the first k-step
         const float* sp = stage(lds0);
+        wino4_lds_f2* hb = wino4_halo_base(sp + boff + 5);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             float d[6];
-            load_row(sp, r, d);
+            load_row(sp, hb, r, d);
             wino4_in1d(d[0], d[1], d[2], d[3], d[4], d[5], v[6 * r], v[6 * r + 1], v[6 * r + 2], v[6 * r + 3], v[6 * r + 4], v[6 * r + 5]);
         }
 #pragma unroll
@@ -269,13 +296,14 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
         const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
         const f32x4* ap = a_ptr(rslot);
         const float* spn = stage(nslot);               // (k-step q + 1 was verified together with q)
+        wino4_lds_f2* hbn = wino4_halo_base(spn + boff + 5);
         f32x4 F[2];
         F[0] = ap[0];
         float d[6];
         auto group = [&](auto gt) {
             constexpr int g = decltype(gt)::value;      // xi = 4 g .. 4 g + 3
             if constexpr (g + 1 < 9) F[(g + 1) & 1] = ap[(g + 1) * 64];
-            if constexpr (g < 6) load_row(spn, g, d);
+            if constexpr (g < 6) load_row(spn, hbn, g, d);
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 c = F[g & 1];
             __builtin_amdgcn_s_setprio(1);              // the SIMD's other wave is in its vector section: the matrix pipe goes first (-1.5 % measured)
@@ -496,20 +524,20 @@ __global__ __launch_bounds__(512, 1) void wino4_ace_kernel(const Wino4AceParams 
     const int tx = n & 7, tyl = 2 * tg + (n >> 3);
     const int boff = kk * (PPL * 4) + (4 * tyl) * (PUN * 4) + 4 * tx + 3;
     auto stage = [&](unsigned slot) { return reinterpret_cast<const float*>(smem) + (slot - lds0) / 4; };
-    auto load_row = [&](const float* sp, int r, float (&d)[6]) {
+    auto load_row = [&](const float* sp, wino4_lds_f2* hb, int r, float (&d)[6]) {
         const float* q = sp + boff + r * (PUN * 4);
-        d[0] = q[0];
         const f32x4 mid = *reinterpret_cast<const f32x4*>(q + 1);
         d[1] = mid.x; d[2] = mid.y; d[3] = mid.z; d[4] = mid.w;
-        d[5] = q[5];
+        wino4_halo(q, hb, r, d[0], d[5]);
     };
     auto a_ptr = [&](unsigned slot) { return reinterpret_cast<const f32x4*>(stage(slot) + PSLOTS * 4) + 9 * mh * 64 + lane; };
     auto first_v = [&](unsigned slot, float (&vv)[36]) {          // B fragments of the k-step staged in `slot`
         const float* sp = stage(slot);
+        wino4_lds_f2* hb = wino4_halo_base(sp + boff + 5);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             float d[6];
-            load_row(sp, r, d);
+            load_row(sp, hb, r, d);
             wino4_in1d(d[0], d[1], d[2], d[3], d[4], d[5], vv[6 * r], vv[6 * r + 1], vv[6 * r + 2], vv[6 * r + 3], vv[6 * r + 4], vv[6 * r + 5]);
         }
 #pragma unroll
@@ -529,13 +557,14 @@ __global__ __launch_bounds__(512, 1) void wino4_ace_kernel(const Wino4AceParams 
         const unsigned nslot = rslot + SB == lds0 + RING ? lds0 : rslot + SB;
         const f32x4* ap = a_ptr(rslot);
         const float* spn = stage(nslot);
+        wino4_lds_f2* hbn = wino4_halo_base(spn + boff + 5);
         f32x4 F[2];
         F[0] = ap[0];
         float d[6];
         auto group = [&](auto gt) {
             constexpr int g = decltype(gt)::value;
             if constexpr (g + 1 < 9) F[(g + 1) & 1] = ap[(g + 1) * 64];
-            if constexpr (g < 6) load_row(spn, g, d);
+            if constexpr (g < 6) load_row(spn, hbn, g, d);
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 c = F[g & 1];
             __builtin_amdgcn_s_setprio(1);

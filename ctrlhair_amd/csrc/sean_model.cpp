@@ -1026,6 +1026,10 @@ struct Runner {
             }
         }
         if (!(what & 2)) return q;
+        // a buffer that held the padded planes of a Winograd level (zero columns cleared once per geometry) and now receives the
+        // direct [B][HID][r][r] layout -- the same ACE at another image size on a run-ahead handle -- must have its pads cleared again
+        // before the next padded use: the direct kernels write over them
+        if (m.use_sh16 || !use_wino_ace(a, r)) m.pad_state.erase(actv_buf);
         if (m.use_sh16)
             check(onehot_conv3x3_sh16(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, a.actv_scale, s, m.terms == 2, need, tile_cnt,
                                       (m.dbg & 33554432) ? 1 : 0), "mlp_shared");

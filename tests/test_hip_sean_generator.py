@@ -255,3 +255,24 @@ def test_golden_batch16_full_size(hip_lib, path, B):
         # (bf16 operands: the scale protocol may pick another power of two for another batch)
         assert np.abs(one[0] - img[i]).max() <= (1e-4 if path != 'bf16' else 2e-2)
     gen.handle.close()
+
+
+@pytest.mark.parametrize('sizes', [(512, 64, 512), (256, 128, 512, 256)])
+def test_alternating_sizes_on_a_run_ahead_handle(hip_lib, sizes):
+    """One max_batch=1 handle (the interactive one: every ACE's prepare step runs ahead into per-ACE buffers) rendering images of
+    alternating sizes.  The per-ACE hidden-activation buffer holds the PADDED planes of a Winograd level at one size and the direct
+    [B][128][r][r] layout at another; the zero columns of the padded layout are cleared once per geometry, so a direct-layout write in
+    between must invalidate that state (stale pads = wrong gamma/beta at the left / right image borders)."""
+    from ctrlhair_amd import procedural as P
+    ngf = 64
+    sd = _sds.setdefault((ngf, 0), P.sean_state_dict(0, ngf))
+    gen = _gen(sd, 1, 512)
+    inputs = {S: (P.blocky_labels(1, S, seed=40 + S), P.style_codes(1, seed=41 + S), P.noise_planes(1, S, ngf, seed=42 + S)) for S in set(sizes)}
+    seq = [_run(gen, *inputs[S]) for S in sizes]
+    gen.handle.close()
+    for S, got in zip(sizes, seq):
+        fresh = _gen(sd, 1, 512)
+        want = _run(fresh, *inputs[S])
+        fresh.handle.close()
+        d = np.abs(got - want)
+        assert d.max() == 0.0, f'S={S} after other sizes differs from a fresh handle: {d.max():.3e}; border columns {d[..., :2].max():.3e} / {d[..., -2:].max():.3e}'
