@@ -1,5 +1,5 @@
 // conv_inst_wino4.hip -- instantiation + launcher of the Winograd F(4x4,3x3) exact-f32 MFMA kernel (conv_wino4.h)
-#include "conv_wino4.h"
+#include "conv_wino4v.h"
 
 namespace chk {
 
@@ -90,6 +90,62 @@ hipError_t wino4_style_pack(const float* lut, float* wsty, int B, int C, hipStre
     const int nrt = (C + 15) / 16;
     const long long n = (long long)B * nrt * 6 * 1152;
     hipLaunchKernelGGL(wino4_style_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lut, wsty, B, C, nrt);
+    return hipGetLastError();
+}
+
+
+// ---- pre-transformed input route (conv_wino4v.h) ---------------------------------------------------------------------------------------
+static hipError_t wino4v_device(int& cus) {
+    static bool done[64] = {};
+    static int ncu[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4v_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, wino4v::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4v_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, wino4v::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        ncu[dev] = v;
+        done[dev] = true;
+    }
+    cus = ncu[dev];
+    return hipSuccess;
+}
+hipError_t wino4v_pack(const Wino4vPackParams& p, hipStream_t s) {
+    if (!p.in || !p.v || p.H % 32 || p.W % 32 || p.H < 32 || p.W < 32 || p.nks <= 0 || p.pitch % 4 || p.xoff % 4 || (p.reflect && p.padded)) return hipErrorInvalidValue;
+    const long long blocks = (long long)p.B * (p.H / 32) * (p.W / 32) * p.nks;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(wino4v_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t conv_wino4v_plain(Wino4Params p, hipStream_t s) {
+    if (!wino4_supported(p.H, p.W, p.Cin) || !p.v || !p.wpk || !p.out) return hipErrorInvalidValue;
+    wino4_fill_launch(p);
+    if (p.nks & 1) return hipErrorInvalidValue;
+    int cus = 0;
+    hipError_t e = wino4v_device(cus);
+    if (e != hipSuccess) return e;
+    const int grid = p.ntasks < cus ? p.ntasks : cus;
+    hipLaunchKernelGGL(wino4v_kernel<0>, dim3(grid), dim3(512), wino4v::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+hipError_t conv_wino4v_ace(Wino4AceParams p, hipStream_t s) {
+    if (!wino4_ace_supported(p.H, p.W, p.C) || !p.v || !p.wpk || !p.out || !p.x || !p.noise) return hipErrorInvalidValue;
+    p.nrt = (p.C + 15) / 16;
+    p.ntx = p.W / wino4::TS;
+    p.nty = p.H / wino4::TS;
+    p.ntiles = p.B * p.ntx * p.nty;
+    p.ntasks = p.ntiles * p.nrt;
+    p.nks = p.wsty ? 38 : 32;
+    p.rb = p.nrt >= 4 ? 4 : p.nrt;
+    p.tbk = 32 / p.rb;
+    int cus = 0;
+    hipError_t e = wino4v_device(cus);
+    if (e != hipSuccess) return e;
+    const int grid = p.ntasks < cus ? p.ntasks : cus;
+    hipLaunchKernelGGL(wino4v_kernel<1>, dim3(grid), dim3(512), wino4v::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -54,6 +54,7 @@ struct Wino4Params {
     int res_up;
     int act;                // ACT_* applied to conv + bias + residual
     int reflect;            // 1 = reflection padding (pad 1: row -1 is row 1, row H is row H - 2; columns alike) instead of zeros
+    const float* v;         // conv_wino4v.h only: the pre-transformed input (wino4v_pack) -- `in` is then unused
     // set by the launcher
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;
 };
@@ -121,9 +122,13 @@ __device__ __forceinline__ void wino4_out1d(float m0, float m1, float m2, float 
 typedef float wino4_f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const wino4_f32x2 wino4_lds_f2;
 __device__ __forceinline__ wino4_lds_f2* wino4_halo_base(const float* right_halo_row0) {
+#ifdef CH_W4_HALO64
     wino4_lds_f2* b = (wino4_lds_f2*)right_halo_row0;
     asm volatile("" : "+v"(b));
     return b;
+#else
+    return nullptr;
+#endif
 }
 __device__ __forceinline__ void wino4_halo(const float* q, wino4_lds_f2* hb, int r, float& d0, float& d5) {
 #ifndef CH_W4_HALO64
@@ -135,6 +140,54 @@ __device__ __forceinline__ void wino4_halo(const float* q, wino4_lds_f2* hb, int
     d0 = lo.y;
     d5 = hi.x;
 #endif
+}
+
+// Epilogue of one (row tile, spatial tile) task of the plain conv: output transform in registers, bias / residual / activation, 16-byte
+// stores.  Lane = tile (tyl, tx) of the 8 x 8 tiles x accumulator rows 32 crt + 16 mh + 4 kk + (0..3).  Shared by wino4_plain_kernel
+// and the pre-transformed-input kernel of conv_wino4v.h.
+__device__ __forceinline__ void wino4_plain_epilogue(const Wino4Params& p, f32x4 (&acc)[36], int crt, int tile, int mh, int kk, int tyl, int tx) {
+    using namespace wino4;
+    const int HW = p.H * p.W;
+    const int ttx = tile % p.ntx, tty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
+    const int y = tty * TS + 4 * tyl, x = ttx * TS + 4 * tx;
+    const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = crt * 32 + mh * 16 + 4 * kk + i, rc = row < p.Cout ? row : p.Cout - 1;
+        const float bsv = p.bias ? p.bias[rc] : 0.f;
+        f32x4 rr[4];                                 // residual of the (row, tile): loaded first, consumed after the transforms
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.res) {
+            const float* rp = p.res + ((long long)b * p.Cout + rc) * rHW;
+            if (p.res_up) {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const float2 q2 = *reinterpret_cast<const float2*>(rp + ((y >> 1) + r2) * rW + (x >> 1));
+                    rr[2 * r2] = rr[2 * r2 + 1] = (f32x4){q2.x, q2.x, q2.y, q2.y};
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rr[r] = *reinterpret_cast<const f32x4*>(rp + (y + r) * rW + x);
+            }
+        }
+        float t[4][6];                               // A^T M: rows 0..3, columns 0..5
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            wino4_out1d(acc[j][i], acc[6 + j][i], acc[12 + j][i], acc[18 + j][i], acc[24 + j][i], acc[30 + j][i], t[0][j], t[1][j], t[2][j], t[3][j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float o0, o1, o2, o3;
+            wino4_out1d(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o0, o1, o2, o3);
+            f32x4 o = {o0 + bsv + rr[r].x, o1 + bsv + rr[r].y, o2 + bsv + rr[r].z, o3 + bsv + rr[r].w};
+            if (p.act != ACT_NONE) {
+                o.x = apply_act(o.x, p.act); o.y = apply_act(o.y, p.act);
+                o.z = apply_act(o.z, p.act); o.w = apply_act(o.w, p.act);
+            }
+            if (row < p.Cout) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Cout + row) * HW + (y + r) * p.W + x) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);           // (one (row, tile) at a time: the accumulators leave little room)
+    }
 }
 
 // MODE bit 0: reflection padding (the Zencoder's 256 -> 512 conv, architecture.py:174).  Rows: a reflected row is a source offset like any
@@ -340,46 +393,7 @@ __global__ __launch_bounds__(512, 1) void wino4_plain_kernel(const Wino4Params p
         // ---- epilogue of task ct ---------------------------------------------------------------------------------------------
         int crt, tile;
         task_of(ct, crt, tile);
-        const int ttx = tile % p.ntx, tty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
-        const int y = tty * TS + 4 * tyl, x = ttx * TS + 4 * tx;
-        const int rW = p.W >> p.res_up, rHW = rW * (p.H >> p.res_up);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = crt * 32 + mh * 16 + 4 * kk + i, rc = row < p.Cout ? row : p.Cout - 1;
-            const float bsv = p.bias ? p.bias[rc] : 0.f;
-            f32x4 rr[4];                                 // residual of the (row, tile): loaded first, consumed after the transforms
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rr[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.res) {
-                const float* rp = p.res + ((long long)b * p.Cout + rc) * rHW;
-                if (p.res_up) {
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2) {
-                        const float2 q2 = *reinterpret_cast<const float2*>(rp + ((y >> 1) + r2) * rW + (x >> 1));
-                        rr[2 * r2] = rr[2 * r2 + 1] = (f32x4){q2.x, q2.x, q2.y, q2.y};
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rr[r] = *reinterpret_cast<const f32x4*>(rp + (y + r) * rW + x);
-                }
-            }
-            float t[4][6];                               // A^T M: rows 0..3, columns 0..5
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                wino4_out1d(acc[j][i], acc[6 + j][i], acc[12 + j][i], acc[18 + j][i], acc[24 + j][i], acc[30 + j][i], t[0][j], t[1][j], t[2][j], t[3][j]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float o0, o1, o2, o3;
-                wino4_out1d(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o0, o1, o2, o3);
-                f32x4 o = {o0 + bsv + rr[r].x, o1 + bsv + rr[r].y, o2 + bsv + rr[r].z, o3 + bsv + rr[r].w};
-                if (p.act != ACT_NONE) {
-                    o.x = apply_act(o.x, p.act); o.y = apply_act(o.y, p.act);
-                    o.z = apply_act(o.z, p.act); o.w = apply_act(o.w, p.act);
-                }
-                if (row < p.Cout) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Cout + row) * HW + (y + r) * p.W + x) = o;
-            }
-            __builtin_amdgcn_sched_barrier(0);           // (one (row, tile) at a time: the accumulators leave little room)
-        }
+        wino4_plain_epilogue(p, acc, crt, tile, mh, kk, tyl, tx);
 #pragma unroll
         for (int x2 = 0; x2 < 36; ++x2) acc[x2] = (f32x4){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's loads / stores share the counter with the ring: drain once per task
@@ -409,6 +423,7 @@ struct Wino4AceParams {
     const float *bias_g, *bias_b, *bn_a, *bn_d, *nv;
     const float* noise;     // plane base of this ACE, sample stride noise_bstride, layout [W][H]
     long long noise_bstride;
+    const float* v;         // conv_wino4v.h only: the pre-transformed hidden activations (wino4v_pack) -- `actv` is then unused
     int nrt, ntx, nty, ntiles, ntasks, nks, rb, tbk;      // set by the launcher
 };
 // GEMM row R of the packed SPADE image -> (channel, beta)
@@ -416,6 +431,64 @@ __host__ __device__ inline void wino4_ace_row(int R, int& ch, int& beta) {
     const int rt = R >> 5, m = (R >> 4) & 1, r = R & 15;
     ch = rt * 16 + m * 8 + (r >> 2) * 2 + (r & 1);
     beta = (r >> 1) & 1;
+}
+
+// ACE epilogue of one (row tile, spatial tile) task: output transform of gamma (accumulator rows 0, 1) and beta (rows 2, 3) of the
+// lane's two channels 16 crt + 8 mh + 2 kk + (0, 1), noise + eval-BN + modulation + activation, 16-byte stores.  Shared by
+// wino4_ace_kernel and the pre-transformed-input kernel of conv_wino4v.h.
+__device__ __forceinline__ void wino4_ace_epilogue(const Wino4AceParams& p, f32x4 (&acc)[36], int crt, int tile, int mh, int kk, int tyl, int tx) {
+    using namespace wino4;
+    const int HW = p.H * p.W;
+    const int ttx = tile % p.ntx, tty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
+    const int y = tty * TS + 4 * tyl, x = ttx * TS + 4 * tx;
+    const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
+    f32x4 nz[4];                                  // nz[c] = noise of column x + c, rows y .. y + 3 (plane layout [W][H])
+    const float* nzp = p.noise + (long long)b * p.noise_bstride + (long long)x * p.H + y;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nz[c] = *reinterpret_cast<const f32x4*>(nzp + (long long)c * p.H);
+    const int cA = crt * 16 + mh * 8 + 2 * kk;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                 // the lane's two channels: accumulator rows e (gamma) and 2 + e (beta)
+        const int ch = cA + e, cc = ch < p.C ? ch : p.C - 1;
+        const float gb = 1.f + p.bias_g[cc], bb = p.bias_b[cc], pa = p.bn_a[cc], pd = p.bn_d[cc], pn = p.nv[cc];
+        f32x4 xr[4];                              // x rows y .. y + 3, columns x .. x + 3
+        const float* xp = p.x + ((long long)b * p.C + cc) * xHW;
+        if (p.x_up) {
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const float2 q2 = *reinterpret_cast<const float2*>(xp + ((y >> 1) + r2) * xW + (x >> 1));
+                xr[2 * r2] = xr[2 * r2 + 1] = (f32x4){q2.x, q2.x, q2.y, q2.y};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xr[r] = *reinterpret_cast<const f32x4*>(xp + (y + r) * xW + x);
+        }
+        float tg_[4][6], tb_[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            wino4_out1d(acc[j][e], acc[6 + j][e], acc[12 + j][e], acc[18 + j][e], acc[24 + j][e], acc[30 + j][e], tg_[0][j], tg_[1][j], tg_[2][j],
+                        tg_[3][j]);
+            wino4_out1d(acc[j][2 + e], acc[6 + j][2 + e], acc[12 + j][2 + e], acc[18 + j][2 + e], acc[24 + j][2 + e], acc[30 + j][2 + e], tb_[0][j],
+                        tb_[1][j], tb_[2][j], tb_[3][j]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float g0, g1, g2, g3, e0, e1, e2, e3;
+            wino4_out1d(tg_[r][0], tg_[r][1], tg_[r][2], tg_[r][3], tg_[r][4], tg_[r][5], g0, g1, g2, g3);
+            wino4_out1d(tb_[r][0], tb_[r][1], tb_[r][2], tb_[r][3], tb_[r][4], tb_[r][5], e0, e1, e2, e3);
+            const float nr[4] = {nz[0][r], nz[1][r], nz[2][r], nz[3][r]};
+            float o0 = (pa * xr[r].x + pn * nr[0] + pd) * (gb + g0) + (bb + e0);
+            float o1 = (pa * xr[r].y + pn * nr[1] + pd) * (gb + g1) + (bb + e1);
+            float o2 = (pa * xr[r].z + pn * nr[2] + pd) * (gb + g2) + (bb + e2);
+            float o3 = (pa * xr[r].w + pn * nr[3] + pd) * (gb + g3) + (bb + e3);
+            if (p.act != ACT_NONE) {
+                o0 = apply_act(o0, p.act); o1 = apply_act(o1, p.act);
+                o2 = apply_act(o2, p.act); o3 = apply_act(o3, p.act);
+            }
+            if (ch < p.C) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.C + ch) * HW + (y + r) * p.W + x) = (f32x4){o0, o1, o2, o3};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int DUMMY>
@@ -603,56 +676,7 @@ __global__ __launch_bounds__(512, 1) void wino4_ace_kernel(const Wino4AceParams 
         // ---- ACE epilogue of task ct: this lane = tile (tyl, tx) x channels cA, cA + 1 ---------------------------------------------
         int crt, tile;
         task_of(ct, crt, tile);
-        const int ttx = tile % p.ntx, tty = (tile / p.ntx) % p.nty, b = tile / (p.ntx * p.nty);
-        const int y = tty * TS + 4 * tyl, x = ttx * TS + 4 * tx;
-        const int xW = p.W >> p.x_up, xHW = xW * (p.H >> p.x_up);
-        f32x4 nz[4];                                  // nz[c] = noise of column x + c, rows y .. y + 3 (plane layout [W][H])
-        const float* nzp = p.noise + (long long)b * p.noise_bstride + (long long)x * p.H + y;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) nz[c] = *reinterpret_cast<const f32x4*>(nzp + (long long)c * p.H);
-        const int cA = crt * 16 + mh * 8 + 2 * kk;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {                 // the lane's two channels: accumulator rows e (gamma) and 2 + e (beta)
-            const int ch = cA + e, cc = ch < p.C ? ch : p.C - 1;
-            const float gb = 1.f + p.bias_g[cc], bb = p.bias_b[cc], pa = p.bn_a[cc], pd = p.bn_d[cc], pn = p.nv[cc];
-            f32x4 xr[4];                              // x rows y .. y + 3, columns x .. x + 3
-            const float* xp = p.x + ((long long)b * p.C + cc) * xHW;
-            if (p.x_up) {
-#pragma unroll
-                for (int r2 = 0; r2 < 2; ++r2) {
-                    const float2 q2 = *reinterpret_cast<const float2*>(xp + ((y >> 1) + r2) * xW + (x >> 1));
-                    xr[2 * r2] = xr[2 * r2 + 1] = (f32x4){q2.x, q2.x, q2.y, q2.y};
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xr[r] = *reinterpret_cast<const f32x4*>(xp + (y + r) * xW + x);
-            }
-            float tg_[4][6], tb_[4][6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                wino4_out1d(acc[j][e], acc[6 + j][e], acc[12 + j][e], acc[18 + j][e], acc[24 + j][e], acc[30 + j][e], tg_[0][j], tg_[1][j], tg_[2][j],
-                            tg_[3][j]);
-                wino4_out1d(acc[j][2 + e], acc[6 + j][2 + e], acc[12 + j][2 + e], acc[18 + j][2 + e], acc[24 + j][2 + e], acc[30 + j][2 + e], tb_[0][j],
-                            tb_[1][j], tb_[2][j], tb_[3][j]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float g0, g1, g2, g3, e0, e1, e2, e3;
-                wino4_out1d(tg_[r][0], tg_[r][1], tg_[r][2], tg_[r][3], tg_[r][4], tg_[r][5], g0, g1, g2, g3);
-                wino4_out1d(tb_[r][0], tb_[r][1], tb_[r][2], tb_[r][3], tb_[r][4], tb_[r][5], e0, e1, e2, e3);
-                const float nr[4] = {nz[0][r], nz[1][r], nz[2][r], nz[3][r]};
-                float o0 = (pa * xr[r].x + pn * nr[0] + pd) * (gb + g0) + (bb + e0);
-                float o1 = (pa * xr[r].y + pn * nr[1] + pd) * (gb + g1) + (bb + e1);
-                float o2 = (pa * xr[r].z + pn * nr[2] + pd) * (gb + g2) + (bb + e2);
-                float o3 = (pa * xr[r].w + pn * nr[3] + pd) * (gb + g3) + (bb + e3);
-                if (p.act != ACT_NONE) {
-                    o0 = apply_act(o0, p.act); o1 = apply_act(o1, p.act);
-                    o2 = apply_act(o2, p.act); o3 = apply_act(o3, p.act);
-                }
-                if (ch < p.C) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.C + ch) * HW + (y + r) * p.W + x) = (f32x4){o0, o1, o2, o3};
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        wino4_ace_epilogue(p, acc, crt, tile, mh, kk, tyl, tx);
 #pragma unroll
         for (int x2 = 0; x2 < 36; ++x2) acc[x2] = (f32x4){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

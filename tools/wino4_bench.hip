@@ -112,12 +112,49 @@ int main(int argc, char** argv) {
             ms /= it;
             if (B == 16) { tot_ms += ms * (strstr(c.name, "G_middle") ? 2 : 1); tot_fl += fl * (strstr(c.name, "G_middle") ? 2 : 1); }
         }
+        // pre-transformed input route (conv_wino4v.h): pack pass + contraction; must equal the in-kernel-transform result bit for bit
+        float msv = 0, msp = 0;
+        double vdiff = -1;
+        if (Cin % 8 == 0) {
+            float *d_v, *d_out2;
+            const size_t vb = wino4v_bytes(B, H, W, Cin / 4);
+            CK(hipMalloc(&d_v, vb)); CK(hipMalloc(&d_out2, nout * 4));
+            CK(hipMemset(d_out2, 0xFF, nout * 4));
+            Wino4vPackParams pp{};
+            pp.in = d_in; pp.v = d_v; pp.B = B; pp.K = Cin; pp.H = H; pp.W = W; pp.nks = Cin / 4; pp.pitch = W; pp.xoff = 0; pp.padded = 0; pp.reflect = p.reflect;
+            Wino4Params pv = p;
+            pv.v = d_v; pv.out = d_out2;
+            CK(wino4v_pack(pp, 0));
+            CK(conv_wino4v_plain(pv, 0));
+            CK(hipDeviceSynchronize());
+            std::vector<float> h1(nout), h2(nout);
+            CK(hipMemcpy(h1.data(), d_out, nout * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h2.data(), d_out2, nout * 4, hipMemcpyDeviceToHost));
+            vdiff = 0;
+            for (size_t i = 0; i < nout; ++i) { const double d = fabs((double)h1[i] - h2[i]); if (!(d <= vdiff)) vdiff = d; }
+            if (!quick) {
+                hipEvent_t e0, e1, e2;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+                const int it = 5;
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < it; ++i) CK(wino4v_pack(pp, 0));
+                CK(hipEventRecord(e1, 0));
+                for (int i = 0; i < it; ++i) CK(conv_wino4v_plain(pv, 0));
+                CK(hipEventRecord(e2, 0));
+                CK(hipEventSynchronize(e2));
+                CK(hipEventElapsedTime(&msp, e0, e1)); CK(hipEventElapsedTime(&msv, e1, e2));
+                msp /= it; msv /= it;
+            }
+            (void)hipFree(d_v); (void)hipFree(d_out2);
+        }
         const double exec = 2.0 * B * (H / 4) * (W / 4) * (double)Cout * Cin * 36.0;
+        printf("   V route: max|v - in-kernel| %.3e %s  pack %7.3f ms + conv %7.3f ms = %7.3f ms  (conv alone executed %6.1f TF/s)\n", vdiff,
+               vdiff == 0 ? "BITEQ" : "DIFF ", msp, msv, msp + msv, msv > 0 ? 2.0 * B * (H / 4) * (W / 4) * (double)Cout * Cin * 36.0 / msv * 1e-9 : 0.0);
         printf("%-28s B%2d %4d->%4d %3d^2  maxdiff %.3e (max|ref| %.2f)  %s  %8.3f ms  dense %6.1f TF/s  executed %6.1f TF/s\n", c.name, B, Cin, Cout, H, maxd,
                maxr, maxd <= 2e-4 * (maxr > 1 ? maxr : 1) ? "OK  " : "FAIL", ms, ms > 0 ? fl / ms * 1e-9 : 0.0, ms > 0 ? exec / ms * 1e-9 : 0.0);
         fflush(stdout);
-        hipFree(d_in); hipFree(d_w); hipFree(d_b); hipFree(d_pk); hipFree(d_out); hipFree(d_ref);
-        if (d_res) hipFree(d_res);
+        (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_pk); (void)hipFree(d_out); (void)hipFree(d_ref);
+        if (d_res) (void)hipFree(d_res);
     }
     if (!quick) printf("sum over the ResBlock convs of one step from 32^2 up (G_middle x2): %.2f ms, dense-equivalent %.1f TF/s\n", tot_ms, tot_fl / tot_ms * 1e-9);
     return 0;
