@@ -366,6 +366,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.wino4_force = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.wino4v") == 0) {       // 1 = pre-transformed-input route of the F(4x4,3x3) layers with many GEMM rows (conv_wino4v.h; default), 0 = off
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino4v) must precede ch_finalize");
+        h->sean.wino4v = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.wino4_ace") == 0) {    // largest level (pixels) whose SPADE convs run as F(4x4,3x3) over every tile; 0 = none
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino4_ace) must precede ch_finalize");
         h->sean.wino4_ace_max_r = value < 0 ? 0 : value;

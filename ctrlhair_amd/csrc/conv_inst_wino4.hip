@@ -117,7 +117,7 @@ hipError_t wino4v_pack(const Wino4vPackParams& p, hipStream_t s) {
     if (!p.in || !p.v || p.H % 32 || p.W % 32 || p.H < 32 || p.W < 32 || p.nks <= 0 || p.pitch % 4 || p.xoff % 4 || (p.reflect && p.padded)) return hipErrorInvalidValue;
     const long long blocks = (long long)p.B * (p.H / 32) * (p.W / 32) * p.nks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(wino4v_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(wino4v_pack_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t conv_wino4v_plain(Wino4Params p, hipStream_t s) {

@@ -504,7 +504,6 @@ __global__ __launch_bounds__(512, 1) void wino4_ace_kernel(const Wino4AceParams 
     if (lb >= p.ntasks) return;
     const int mytasks = (p.ntasks - lb + G - 1) / G;
     const int nk = p.nks;                          // 32, or 38 with the style images
-    const int HW = p.H * p.W;
     const int AP = wino_apitch(p.W), APL = p.H * AP;
     constexpr unsigned SB = SUNITS * 16u, RING = NST * SB;
     const unsigned lds0 = (unsigned)(size_t)(wino_lds_void*)smem;

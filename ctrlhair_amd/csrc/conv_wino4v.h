@@ -31,8 +31,8 @@
 namespace chk {
 
 #ifndef W4V_ABL
-#define W4V_ABL 0      // timing ablations of tools/wino4_bench.hip (wrong results): 1 no barrier, 2 fragment reads of groups 0, 1 only, 4 no DMA, 8 no s_setprio, 16 every k-step from the same addresses, 32 every other DMA piece only,
-                       // 64 register loads instead of LDS-DMA, 128 all pieces at the start of the k-step, 256 the two row halves' pieces one group apart
+#define W4V_ABL 0      // timing ablations of tools/wino4_bench.hip (wrong results): 1 no barrier, 2 fragment reads of groups 0, 1 only, 4 no DMA, 8 no s_setprio, 16 every k-step from the same addresses, 32 every other DMA piece only
+                       // (profiles/r06_wino4v_ablations.txt; bits 64 / 128 / 256 of that table were removed again)
 #endif
 namespace wino4v {
 constexpr int VUN = 2304;                        // V units (16 bytes) per (spatial tile, k-step)
@@ -55,6 +55,7 @@ struct Wino4vPackParams {
 };
 // one block = (spatial tile, k-step), wave = tile group, lane = (channel kk, tile n): the lane's 6 x 6 patch -> 36 values -> nine 16-byte
 // stores, each a contiguous kilobyte per wave
+template <int DUMMY>          // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(256) void wino4v_pack_kernel(const Wino4vPackParams p) {
     const int lane = threadIdx.x & 63, tg = threadIdx.x >> 6;
     const int n = lane & 15, kk = lane >> 4;
@@ -165,12 +166,6 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
         if constexpr (W4V_ABL & 4) return;
         if constexpr (W4V_ABL & 32)
             if (pc & 1) return;
-        if constexpr (W4V_ABL & 64) {          // the same loads into registers instead of LDS (dropped)
-            f32x4 junk;
-            if constexpr (pc < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(junk) : "v"(va), "s"(d_v), "s"(so_v + (unsigned)pc * 8192u) : "memory");
-            else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(junk) : "v"(va), "s"(d_a), "s"(so_a + (unsigned)(pc - 4) * 9216u) : "memory");
-            return;
-        }
         if constexpr (pc < 4) wino_dma16(va, d_v, so_v + (unsigned)pc * 8192u, wb + (unsigned)pc * 8192u);
         else wino_dma16(va, d_a, so_a + (unsigned)(pc - 4) * 9216u, wb + VUN * 16u + (unsigned)(pc - 4) * 8192u);
     };
@@ -265,10 +260,6 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
         __builtin_amdgcn_sched_barrier(0);
         issue_direct(a8[PAR]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (W4V_ABL & 128) {
-            issue_piece(WInt<0>{}); issue_piece(WInt<1>{}); issue_piece(WInt<2>{}); issue_piece(WInt<3>{}); issue_piece(WInt<4>{}); issue_piece(WInt<5>{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
         auto group = [&](auto gt) {
             constexpr int g = decltype(gt)::value;
             if constexpr (g + 2 < 8 && !(W4V_ABL & 2)) {
@@ -280,15 +271,7 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
             mfma4(A[(W4V_ABL & 2) ? (g & 1) : g % 3], V[(W4V_ABL & 2) ? (g & 1) : g % 3], g);
             if constexpr (!(W4V_ABL & 8)) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (W4V_ABL & 256) {
-                if (mh == 0) {
-                    if constexpr (g < 6) issue_piece(WInt<g < 6 ? g : 0>{});
-                } else {
-                    if constexpr (g >= 1 && g < 7) issue_piece(WInt<(g >= 1 && g < 7) ? g - 1 : 0>{});
-                }
-            } else if constexpr (!(W4V_ABL & 128)) {
-                if constexpr (g < 6) issue_piece(WInt<g>{});
-            }
+            if constexpr (g < 6) issue_piece(WInt<g>{});
             __builtin_amdgcn_sched_barrier(0);
         };
         group(WInt<0>{}); group(WInt<1>{}); group(WInt<2>{}); group(WInt<3>{}); group(WInt<4>{}); group(WInt<5>{});

@@ -19,7 +19,7 @@
 #include "conv_sh16.h"
 #include "conv_pw.h"
 #include "conv_wino.h"
-#include "conv_wino4.h"
+#include "conv_wino4v.h"
 #include "kernels.h"
 #include "sh16.h"
 
@@ -641,6 +641,28 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             }
         if (wsty_max) wsty = B.falloc(wsty_max);
         if (wsty4_max) wsty4 = B.falloc(wsty4_max);
+        // pre-transformed-input route (conv_wino4v.h): one V image, sized for the largest layer that takes it at (mb, ms)
+        vbuf = nullptr;
+        vbuf_bytes = 0;
+        if (wino >= 2 && wino4v) {
+            size_t need = 0;
+            for (const auto& b : blocks) {
+                int k = 0;
+                while ((1 << k) < b.ace_0.res_div) ++k;
+                const int r = ms >> k;
+                if (r < 32 || r % 32 || r > 64) continue;
+                for (const ConvW* c : {&b.conv_0, &b.conv_1})
+                    if (c->wino4 && wino4v_pays(c->Cout, r)) need = std::max(need, wino4v_bytes(mb, r, r, c->Cin / 4));
+                for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1})
+                    if (a && a->spade_wino4 && r <= wino4_ace_max_r && wino4v_pays(2 * a->C, r)) need = std::max(need, wino4v_bytes(mb, r, r, 38));
+            }
+            // the Zencoder's 256 -> 512 conv on the half-resolution grid: 9 bytes x 256 channels x (ms / 2)^2 per sample -- up to 2.5 GB only
+            if (z14_wino4 && (ms / 2) % 32 == 0 && wino4v_bytes(mb, ms / 2, ms / 2, 64) <= ((size_t)5 << 29)) need = std::max(need, wino4v_bytes(mb, ms / 2, ms / 2, 64));
+            if (need) {
+                vbuf = static_cast<float*>(B.dalloc(need));
+                vbuf_bytes = need;
+            }
+        }
         for (int k = 0; k < 6; ++k)
             if (wq_level[k].qlist) {
                 const size_t r = (size_t)ms >> k;
@@ -1187,9 +1209,26 @@ struct Runner {
             w.noise_bstride = (long long)nf;
             const int ktot = w.wsty ? 152 : 128;             // (38 / 32 k-steps of four channels)
             next_flops_exec = 2.0 * 32.0 * ((a.C + 15) / 16) * ktot * 36.0 * npix / 16.0;
+            // 2 C GEMM rows over 128 (+ 20) input planes: the input transform once for all C / 8 row tiles (conv_wino4v.h)
+            const bool vroute = m.wino4v && wino4v_pays(2 * a.C, r) && m.wino4v_fits(B, r, w.wsty ? 38 : 32);
             timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 4.0 * (npix * (HID + (a.styled ? 20 : 0)) + npix * a.C / (x_up ? 4.0 : 1.0) + npix * a.C), [&] {
                 if (w.wsty) check(wino4_style_pack(q.lut, m.wsty4, B, a.C, st), "wino4_style_pack");
-                check(conv_wino4_ace(w, st), "spade conv (winograd F(4x4,3x3), every tile)");
+                if (vroute) {
+                    Wino4vPackParams vp{};
+                    vp.in = q.actv;
+                    vp.v = m.vbuf;
+                    vp.B = B;
+                    vp.K = HID + (a.styled ? 20 : 0);       // (the buffer's plane count: ace_prepare; an ACE without LUT reads the first 128 only)
+                    vp.H = vp.W = r;
+                    vp.nks = w.wsty ? 38 : 32;
+                    vp.pitch = wino_apitch(r);
+                    vp.xoff = WINO_AXOFF;
+                    vp.padded = 1;
+                    check(wino4v_pack(vp, st), "hidden activation transform (winograd F(4x4,3x3))");
+                    w.v = m.vbuf;
+                    check(conv_wino4v_ace(w, st), "spade conv (winograd F(4x4,3x3), every tile, pre-transformed input)");
+                } else
+                    check(conv_wino4_ace(w, st), "spade conv (winograd F(4x4,3x3), every tile)");
             });
             return;
         }
@@ -1465,9 +1504,24 @@ struct Runner {
             q.res = res;
             q.res_up = res_up;
             next_flops_exec = 2.0 * w.Cout * w.Cin * 36.0 * npix / 16.0;
+            // many GEMM rows on a small level: the input transform once, in its own pass, instead of in every row tile (conv_wino4v.h)
+            const bool vroute = m.wino4v && wino4v_pays(w.Cout, r) && m.wino4v_fits(B, r, w.Cin / 4);
             timed(0, 2.0 * w.Cout * w.Cin * 9.0 * npix,
-                  4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * 36.0),
-                  [&] { check(conv_wino4_plain(q, st), "conv (winograd F(4x4,3x3))"); });
+                  4.0 * (npix * w.Cin + npix * w.Cout * (res ? 2.0 : 1.0) + (double)w.Cout * w.Cin * 36.0), [&] {
+                      if (vroute) {
+                          Wino4vPackParams vp{};
+                          vp.in = in;
+                          vp.v = m.vbuf;
+                          vp.B = B;
+                          vp.K = w.Cin;
+                          vp.H = vp.W = vp.pitch = r;
+                          vp.nks = w.Cin / 4;
+                          check(wino4v_pack(vp, st), "conv input transform (winograd F(4x4,3x3))");
+                          q.v = m.vbuf;
+                          check(conv_wino4v_plain(q, st), "conv (winograd F(4x4,3x3), pre-transformed input)");
+                      } else
+                          check(conv_wino4_plain(q, st), "conv (winograd F(4x4,3x3))");
+                  });
             return;
         }
         if (use_wino(w, r) && !w2 && !(r == 16 && res_up)) {      // (16 x 16 sample pairs: residual at the same size only)
@@ -1781,7 +1835,20 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
                 q.bias = z14.bias;
                 q.act = ACT_TANH;
                 q.reflect = 1;
-                ck(conv_wino4_plain(q, st), "zenc conv5 (winograd F(4x4,3x3))");
+                if (wino4v && wino4v_fits(B, h2, 64)) {          // 512 GEMM rows: the (reflected) input transform in its own pass
+                    Wino4vPackParams vp{};
+                    vp.in = hs;
+                    vp.v = vbuf;
+                    vp.B = B;
+                    vp.K = 256;
+                    vp.H = vp.W = vp.pitch = h2;
+                    vp.nks = 64;
+                    vp.reflect = 1;
+                    ck(wino4v_pack(vp, st), "zenc conv5 input transform");
+                    q.v = vbuf;
+                    ck(conv_wino4v_plain(q, st), "zenc conv5 (winograd F(4x4,3x3), pre-transformed input)");
+                } else
+                    ck(conv_wino4_plain(q, st), "zenc conv5 (winograd F(4x4,3x3))");
             } else if (z14_wino && wino_supported(h2, h2, 256)) {
                 WinoParams q{};
                 q.in = hs;
@@ -1816,5 +1883,7 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
     }
     return "";
 }
+
+bool SeanModel::wino4v_fits(int Bn, int r, int nks) const { return vbuf && r % 32 == 0 && wino4v_bytes(Bn, r, r, nks) <= vbuf_bytes; }
 
 }  // namespace chk

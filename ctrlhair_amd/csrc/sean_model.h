@@ -158,6 +158,11 @@ struct SeanModel {
     int num_cus = 256;                         // compute units of the handle's device (build())
     int wino4_force = 0;                       // option "sean.wino4_force": 1 = F(4x4,3x3) wherever the shape allows, whatever the task count (tests)
     int wino4_ace_max_r = 64;                  // option "sean.wino4_ace": largest level whose SPADE convs run as F(4x4,3x3) over EVERY tile (0 = none)
+    int wino4v = 1;                            // option "sean.wino4v": 1 = F(4x4,3x3) layers with >= 512 GEMM rows at <= 64 pixels (and the Zencoder's 256 -> 512
+                                               //   conv) take their input pre-transformed by one extra pass (conv_wino4v.h; bit-identical results)
+    float* vbuf = nullptr;                     // the pre-transformed input V of the layer being run (conv_wino4v.h)
+    size_t vbuf_bytes = 0;
+    bool wino4v_fits(int Bn, int r, int nks) const;      // sean_model.cpp
     int* prof_stats = nullptr;                 // profiling: snapshots of the work-list statistics of sparse launches (16 B each)
     int prof_stats_cap = 0, prof_stats_used = 0;
     int sparse = 1;                            // option "sean.sparse" (0 = every pixel through the conv)

@@ -88,6 +88,11 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   Both F(4x4,3x3) choices are made per call: with fewer tasks of 32 x 32 pixels than a round of F(2x2,3x3) tasks would need CUs (single
  *   images, small batches of small images) the F(2x2,3x3) kernels run instead (wino4_pays, conv_wino4.h); "sean.wino4_force" = 1 (any
  *   time) switches that rule off.
+ * "sean.wino4v" (default 1; before ch_finalize; with "sean.wino" = 2): F(4x4,3x3) layers with at least 512 GEMM rows at up to 64 x 64
+ *   pixels -- the ResBlock convs of G_middle / up_0 and every SPADE / style conv that "sean.wino4_ace" selects -- and the Zencoder's
+ *   256 -> 512 conv read their input pre-transformed (V = B^T d B, written once by an extra bandwidth-bound pass, csrc/conv_wino4v.h)
+ *   instead of transforming it again in every row tile; same arithmetic in the same order: bit-identical results.  Costs a workspace
+ *   of 9 bytes per input element of the largest such layer (604 MB at max_batch 16, 512 x 512).  0 = transform inside the conv kernel.
  * "sean.overlap" (default 0; before ch_finalize): number of CUs given to CU-masked side streams on which the interior passes and
  *   label-table kernels run beside the convs (with dynamic task claiming in the Winograd kernels).  Bit-identical results; measured
  *   SLOWER than the serial order at every setting on MI355X: kept as an option, not used.

@@ -148,6 +148,35 @@ def test_f4x4_task_count_rule_only_changes_the_kernels(hip_lib):
         g.handle.close()
 
 
+@pytest.mark.parametrize('ngf,S,B', [(64, 256, 3), (64, 512, 2), (16, 128, 5)])
+def test_pretransformed_input_route_equals_the_in_kernel_transform(hip_lib, ngf, S, B):
+    """Option sean.wino4v (default 1; conv_wino4v.h): F(4x4,3x3) layers with >= 512 GEMM rows at <= 64 pixels read V = B^T d B from an
+    extra pass instead of transforming their patches in every row tile -- the same wino4_in1d sequence, the same order of products, the
+    same epilogues: the images must be IDENTICAL, with the route on the plain convs (G_middle / up_0 at ngf = 64), on the SPADE / style
+    convs (every F(4x4) ACE level with C >= 256; ngf = 16 has none: the option must change nothing there) and with styled and unstyled
+    ACEs, ragged batches and label maps with no interior pixel.  architecture.py:82-91, normalization.py:249-257."""
+    from ctrlhair_amd import procedural as P
+    sd = P.sean_state_dict(0, ngf)
+    on, off = _gen(sd, B, S, 2, {'sean.wino4_force': 1, 'sean.wino4v': 1}), _gen(sd, B, S, 2, {'sean.wino4_force': 1, 'sean.wino4v': 0})
+    codes, noise = P.style_codes(B, seed=81), P.noise_planes(B, S, ngf, seed=82)
+    sets = _label_sets(B, S)
+    for name in ('face', 'diag', 'noclass_at_tile_borders'):
+        a, b = _run(on, sets[name], codes, noise), _run(off, sets[name], codes, noise)
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), f'{name}: max |V route - in-kernel transform| = {np.abs(a - b).max():.3e}'
+    one = _run(on, sets['face'][B - 1:], codes[B - 1:], noise[B - 1:])        # a smaller batch on the same handle (V image sized for max_batch)
+    assert np.array_equal(one, _run(off, sets['face'][B - 1:], codes[B - 1:], noise[B - 1:]))
+    if ngf == 64:       # the route is actually taken: its kernels show up in the executed-FLOP accounting unchanged, and the pass is timed with the conv
+        on.handle.profile_enable(True)
+        _run(on, sets['face'], codes, noise)
+        on.handle.profile_enable(False)
+        plain = on.handle.profile_read(0)
+        on.handle.profile_read(-1)
+        assert 0.25 - 1e-9 <= plain['flops_executed'] / plain['flops'] <= 0.45
+    for g in (on, off):
+        g.handle.close()
+
+
 @pytest.mark.parametrize('S,mb', [(64, 8), (256, 9)])
 def test_grouped_style_luts_equal_per_ace_launches(hip_lib, S, mb):
     """Exact-f32 path, more than 64 (sample, label) columns: the style LUTs of all styled ACEs from ONE grouped GEMM launch
