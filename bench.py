@@ -64,12 +64,16 @@ DTYPE = {
 }
 
 
-def csrc_sha():
-    """Hash of the sources of the dominant kernels: profiles/latest_traffic.json records the one its PMC passes were taken at;
-    a mismatch means the committed traffic figure is stale and is not reported."""
+def csrc_sha(path='f32'):
+    """Hash of the sources of the kernels whose launches roofline.traffic averages over on `path` (the SPADE conv + fused ACE
+    epilogue set): profiles/latest_traffic.json records the one its PMC passes were taken at; a mismatch means the committed
+    traffic figure is stale and is not reported.  Per path, and only those kernels' files, so that a late edit elsewhere in csrc/
+    does not void the evidence of a kernel it did not touch (round 5: the driver line lost its traffic that way)."""
+    files = {'f32': ('conv_mfma.h', 'conv_wino.h', 'conv_wino4.h', 'conv_wino4v.h', 'conv_ace_sparse.h'),
+             'f16x3': ('conv_sh16.h', 'sh16.h', 'ace_sparse.h')}.get(path, ('conv_sh16.h', 'sh16.h', 'ace_sparse.h'))
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'ctrlhair_amd', 'csrc')
-    for f in ('conv_mfma.h', 'conv_wino.h', 'conv_wino4.h', 'conv_ace_sparse.h', 'ace_sparse.h', 'conv_sh16.h', 'sh16.h'):
+    for f in files:
         h.update(f.encode())
         h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
@@ -108,7 +112,7 @@ def cpu_baseline(ngf, S, sd_np, budget_s=120.0, weights=None, b16=False):
                      f'{torch.__version__} CPU, after a 128x128 warm-up',
            'b1_seconds': [round(t, 2) for t in times],
            'b16': {'run': False, 'estimate_seconds_per_batch': round(16 * med, 1),
-                   'why': 'no cross-sample op in the graph: a batch of 16 is 16 of these forwards; run it with --cpu-b16 (minutes)'}}
+                   'why': 'no cross-sample op in the graph: a batch of 16 is 16 of these forwards; skipped by --no-cpu-b16'}}
     if b16:
         t = time.time()
         O.generator_forward(sd, P.blocky_labels(16, S), P.style_codes(16), P.noise_planes(16, S, ngf), ngf, weights_cache=wc)
@@ -347,14 +351,24 @@ def run_leg(job, args, dist, dev, world, steps=None, warmup=None, profile=True):
     for _ in range(warmup):
         step()
     sync()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # host time to enqueue one step's launches, measured OUTSIDE the timed region on an EMPTY queue (synchronise, enqueue one step, stop the
+    # clock, synchronise): inside the region the HIP queue is full and step() blocks on it -- that figure (kept below as
+    # host_step_call_ms_in_region) is queue back-pressure, not enqueue cost (round 5 review)
     enq = []
+    for _ in range(min(5, max(steps, 0))):
+        sync()
+        h0 = time.perf_counter()
+        step()
+        enq.append((time.perf_counter() - h0) * 1e3)
+    sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    call_ms = []
     t0 = time.perf_counter()
     for i in range(steps):
         marks[i].record()            # on the launch stream; nothing waits on it inside the region
         h0 = time.perf_counter()
         step()
-        enq.append((time.perf_counter() - h0) * 1e3)       # host time to enqueue the step's launches (no synchronisation inside)
+        call_ms.append((time.perf_counter() - h0) * 1e3)
     marks[steps].record()
     sync()
     dt = time.perf_counter() - t0
@@ -382,7 +396,7 @@ def run_leg(job, args, dist, dev, world, steps=None, warmup=None, profile=True):
         prof['steps'] = nprof
     value = world * job.images * steps / dt if steps else 0.0
     return {'value': round(value, 3), 'ms_per_step': round(dt / max(steps, 1) * 1e3, 3), 'step_ms': percentiles(step_ms),
-            'host_enqueue_ms_per_step': percentiles(enq), 'steps': steps, 'warmup': warmup}, prof
+            'host_enqueue_ms_per_step': percentiles(enq), 'host_step_call_ms_in_region': percentiles(call_ms), 'steps': steps, 'warmup': warmup}, prof
 
 
 def roofline_block(path, prof, value, B, sustained):
@@ -407,7 +421,7 @@ def roofline_block(path, prof, value, B, sustained):
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
         try:
             detail = json.load(open(tpath)).get(path)
-            if detail and detail.get('csrc_sha') == csrc_sha():
+            if detail and detail.get('csrc_sha') == csrc_sha(path):
                 traffic = round(float(detail['hbm_bytes']))
                 traffic_raw = round(float(detail['fetch_raw']) + float(detail['write']))
             elif detail:
@@ -491,7 +505,8 @@ def main():
     ap.add_argument('--workload', choices=('all', 'generator', 'pipeline'), default='all')
     ap.add_argument('--labels', choices=('blocky', 'face'), default='blocky', help='label maps of the top-level generator legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-b16', action='store_true', help='CPU baseline: also run ONE real batch-16 forward of the dense graph (minutes)')
+    ap.add_argument('--cpu-b16', action='store_true', help='(default since round 6; kept for old command lines)')
+    ap.add_argument('--no-cpu-b16', action='store_true', help='CPU baseline: skip the ONE real batch-16 forward of the dense graph (SURVEY.md 8(d): Config 2 at B=16; about a minute of host time)')
     ap.add_argument('--only-headline', action='store_true', help='top-level leg only (no f16x3 / face-like / pipeline blocks)')
     ap.add_argument('--no-strict-fp32', action='store_true', help=argparse.SUPPRESS)      # (older tools: implies --only-headline)
     ap.add_argument('--path', choices=tuple(PATH_OPTION), default='f32',
@@ -693,7 +708,7 @@ def main():
         except Exception as e:          # never lose the line over a side block
             res['interactive_b1'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and do_gen and not args.no_cpu_baseline and world == 1:
-        res['cpu_baseline'] = cpu_baseline(ngf, S, sd, weights=all_weights, b16=args.cpu_b16)
+        res['cpu_baseline'] = cpu_baseline(ngf, S, sd, weights=all_weights, b16=not args.no_cpu_b16)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
     }
 }
 
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));      // (a 16-byte store the compiler keeps whole)
 // Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
 // values of a thread share their 32-byte sectors with the seven other rows of the block.
 __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {
@@ -387,7 +388,19 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
     }
     const int nmine = __syncthreads_count(i0) + __syncthreads_count(i1) + __syncthreads_count(i2) + __syncthreads_count(i3);
     if (nmine == 0) return;                                  // no interior pixel in this block
-    const bool fill = nmine >= 4 * (q.fill_min > 0 ? q.fill_min : 128);
+    // What is written.  A partially written 128-byte line costs more than a whole one (masked stores: 538 vs 423 us at 77 % interior
+    // pixels, profiles/r05_interior_bench.txt), so boundary pixels next to interior ones are written too -- the boundary conv, launched
+    // after this pass, overwrites them.  fill_min = 0 (default since round 6): per LINE -- the eight threads of a 128-byte line write
+    // it whole if it holds an interior pixel and skip it (loads and stores) if it holds none: the all-boundary rows along the region
+    // borders, 12 / 25 / 50 % of the lines of the 512 / 256 / 128-pixel levels on the benchmark labels, are no longer written twice.
+    // fill_min > 0 (rounds 3-5): per BLOCK of 128 x 8 pixels -- all of it if it has at least 4 fill_min interior pixels, else masked.
+    bool fill;
+    if (q.fill_min == 0) {
+        const unsigned long long bal = __ballot(i0 || i1 || i2 || i3);
+        fill = ((bal >> (threadIdx.x & 56)) & 0xFFull) != 0;
+    } else {
+        fill = nmine >= 4 * q.fill_min;
+    }
     const bool any = inimg && (fill || i0 || i1 || i2 || i3);
     float nz0 = 0.f, nz1 = 0.f, nz2 = 0.f, nz3 = 0.f;
     if (any) {
@@ -414,8 +427,7 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
     const int cmax = q.C - c0 < IN_CG ? q.C - c0 : IN_CG;
     const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
     const bool all4 = fill || (i0 && i1 && i2 && i3);
-#pragma unroll 4
-    for (int c = 0; c < cmax; ++c) {
+    auto channel = [&](int c) {
         float4 xv;
         if (q.x_up) {
             const float2 t = *reinterpret_cast<const float2*>(xp + (long long)c * xHW);
@@ -431,10 +443,22 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
         o.w = (a * xv.w + n * nz3 + d) * (1.f + g3[c]) + g3[IN_CG + c];
         o.x = fmaxf(o.x, slope * o.x); o.y = fmaxf(o.y, slope * o.y);
         o.z = fmaxf(o.z, slope * o.z); o.w = fmaxf(o.w, slope * o.w);
-        float* oc = op + (long long)c * HW;
-        if (all4) {
-            *reinterpret_cast<float4*>(oc) = o;
-        } else {
+        return o;
+    };
+    // Two loops, not one loop with the choice inside: with `if (all4) 16-byte store else four masked stores` in one body hipcc
+    // if-converts both arms into four predicated 4-byte stores -- the shipped kernel of rounds 4-5 never issued a global_store_dwordx4
+    // (found in round 6 when an unrelated branch in the body changed the code: interior passes of a step 3.37 -> 2.75 ms).
+    if (all4) {
+#pragma unroll 4
+        for (int c = 0; c < cmax; ++c) {
+            const float4 o = channel(c);
+            *reinterpret_cast<nt_f32x4*>(op + (long long)c * HW) = (nt_f32x4){o.x, o.y, o.z, o.w};
+        }
+    } else {
+#pragma unroll 4
+        for (int c = 0; c < cmax; ++c) {
+            const float4 o = channel(c);
+            float* oc = op + (long long)c * HW;
             if (i0) oc[0] = o.x;
             if (i1) oc[1] = o.y;
             if (i2) oc[2] = o.z;

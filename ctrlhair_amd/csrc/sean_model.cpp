@@ -1257,7 +1257,9 @@ struct Runner {
                 // four pixels per thread (16-byte stores) from 128 pixels of width: 530 -> 420 us on the up-sampled 512^2 launches
                 // (tools/interior_bench.hip); level in the 100 ms step of round 3, measurable in this one
                 ip.impl = r >= 128 ? 2 : 0;
-                ip.fill_min = (x_up && r < 128) ? 257 : 128;
+                // (tile4 kernel, r >= 128: 0 = whole 128-byte lines that hold an interior pixel, ace_sparse.hip; sean.dbg bit 134217728: the
+                //  block rule of rounds 3-5 for A/B)
+                ip.fill_min = (x_up && r < 128) ? 257 : ((r >= 128 && !(m.dbg & 134217728)) ? 0 : 128);
                 if (overlap) {
                     // beside the boundary conv of the same ACE (disjoint output pixels -- so no block may fill its boundary pixels),
                     // on the few CUs of the side stream; the consumer of `hout` waits for ev_int below

@@ -30,7 +30,7 @@ def main(d, key, sub, note):
     cur = json.load(open(path)) if os.path.exists(path) else {}
     sys.path.insert(0, root)
     import bench
-    cur[key] = {'unit': "bytes per launch (avg over the kernel's launches)", 'kernel': sub, 'csrc_sha': bench.csrc_sha(),
+    cur[key] = {'unit': "bytes per launch (avg over the kernel's launches)", 'kernel': sub, 'csrc_sha': bench.csrc_sha(key),
                 'fetch_raw': f * 1024, 'fetch_x2_gfx950_corrected': 2 * f * 1024, 'write': w * 1024,
                 'hbm_bytes': (2 * f + w) * 1024, 'launches_sampled': nf, 'source': note}
     json.dump(cur, open(path, 'w'), indent=1)
