@@ -97,6 +97,7 @@ struct AceInteriorParams {
     float out_scale;
     unsigned* out_amax;
     int pass, bf16;
+    int single;                 // f16x3 kernels: 1 = single-term operands (f16 / bf16 legs): the low halves are never read, their plane is not written
     const int* cnt;             // f16x3 path: boundary-pixel count per tile of 32 x 16 (tiles_x = ceil(W / 32))
     int impl;                   // 0 = blocks of 32 x 8 pixels (default), 1 = blocks of 256 consecutive pixels (first version, A/B),
                                 // 2 = exact-f32 kernel only: four pixels per thread, blocks of 128 x 8 (W >= 128)

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInterio
                 }
                 const long long u = (long long)(c >> 3) * 2 * HW;
                 op[u] = __builtin_bit_cast(uint4, vh);
-                op[u + HW] = __builtin_bit_cast(uint4, vl);
+                if (!q.single) op[u + HW] = __builtin_bit_cast(uint4, vl);
             }
         }
     }
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_tile_kernel(const AceIn
                 if (mine) amax = fmaxf(amax, am);              // filler pixels are overwritten: they do not set the scale
                 const long long u = (long long)(c >> 3) * 2 * HW;
                 op[u] = __builtin_bit_cast(uint4, vh);
-                op[u + HW] = __builtin_bit_cast(uint4, vl);
+                if (!q.single) op[u + HW] = __builtin_bit_cast(uint4, vl);
             }
         }
     }

@@ -1635,7 +1635,7 @@ hipError_t dispatch_sh16_ace(const ConvParams& p, hipStream_t s) {
 #endif
     const bool ws_ok = p.W >= 32 && p.Cin >= 48;
     if (ws_ok && ((p.dbg & 64) || (!(p.dbg & 128) && ntiles >= 512))) {
-        if constexpr (TERMS == 3) {        // pixel-level compaction when the caller passes the per-tile lists (sean_model.cpp)
+        {        // pixel-level compaction when the caller passes the per-tile lists (sean_model.cpp); every operand format since round 6
             if (p.sp_work && p.sp_list) {
                 hipError_t e = launch_sh16_ws<3, 32, 16, 1, EPI_ACE, TERMS, 1>(p, rows, s);
                 if (e != hipSuccess || !p.sp_work2) return e;

@@ -705,7 +705,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     SparseWork w;
                     w.mtiles = mt;
                     w.TH = L.TH;
-                    w.mode = use_sh16 ? ((sh16_compact && terms == 3) ? (sh16_compact >= 2 ? 2 : 3) : 1) : 0;   // 3: with pair entries
+                    w.mode = use_sh16 ? (sh16_compact ? (sh16_compact >= 2 ? 2 : 3) : 1) : 0;   // 3: with pair entries
                     w.cap = (long long)L.cap_tiles * (use_sh16 ? mt : sparse_max_tasks(L.TH, mt));
                     w.work = static_cast<unsigned*>(B.dalloc((size_t)w.cap * sizeof(unsigned)));
                     w.total = static_cast<int*>(B.dalloc(4 * sizeof(int)));
@@ -1376,6 +1376,7 @@ struct Runner {
             ip.out_scale = a.out_scale;
             ip.out_amax = m.amax_slots + 2 * a.index;
             ip.bf16 = m.terms == 2;
+            ip.single = (m.use_sh16 && m.terms != 3 && !(m.dbg & 268435456)) ? 1 : 0;      // (dbg bit: A/B)
             ip.variant = m.use_sh16 ? (compact ? 1 : 0) : (CH_ABL(m.dbg & 65536) ? 1 : (CH_ABL(m.dbg & 1048576) ? 2 : 0));
             // blocks of 32 x 8 pixels; mostly-interior blocks write every pixel (the conv below overwrites the boundary pixels).
             // Exact-f32 pass: filling pays only where x is read at full size (measured, tools/interior_bench.hip).

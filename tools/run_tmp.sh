@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 exec < /dev/null
-timeout 600 python -m pytest tests/test_hip_sparse_ace.py tests/test_hip_wino.py -x -q -m gpu 2>&1 | tail -5 > gpurun_out/t_int2.txt
-timeout 400 python bench.py --only-headline --no-cpu-baseline --steps 20 > gpurun_out/b_two.json 2> gpurun_out/b_two.err
-timeout 400 python bench.py --only-headline --no-cpu-baseline --steps 20 --labels face > gpurun_out/b_two_face.json 2> gpurun_out/b_two_face.err
-timeout 400 python bench.py --only-headline --no-cpu-baseline --steps 10 --workload pipeline --path f32 > gpurun_out/b_two_pipe.json 2> gpurun_out/b_two_pipe.err
-for f in b_two b_two_face; do timeout 20 python tools/bench_brief.py $f < gpurun_out/$f.json; done > gpurun_out/b_two_brief.txt 2>&1
+timeout 900 python -m pytest tests/test_hip_sean_generator.py -x -q -m gpu -k "bf16 or f16 or single_term or reduced" 2>&1 | tail -8 > gpurun_out/t_bf16.txt
+timeout 400 python bench.py --only-headline --no-cpu-baseline --steps 10 --path bf16 --batch 32 > gpurun_out/b_bf16_s1.json 2> gpurun_out/b_bf16_s1.err
+timeout 400 python bench.py --only-headline --no-cpu-baseline --steps 10 --path bf16 --batch 32 --dbg 268435456 > gpurun_out/b_bf16_s0.json 2> gpurun_out/b_bf16_s0.err
+for f in b_bf16_s1 b_bf16_s0; do timeout 20 python tools/bench_brief.py $f < gpurun_out/$f.json; done > gpurun_out/b_bf16_brief2.txt 2>&1
