@@ -124,6 +124,13 @@ hipError_t conv_wino4v_plain(Wino4Params p, hipStream_t s) {
     if (!wino4_supported(p.H, p.W, p.Cin) || !p.v || !p.wpk || !p.out) return hipErrorInvalidValue;
     wino4_fill_launch(p);
     if (p.nks & 1) return hipErrorInvalidValue;
+    // task order: a group of 32 consecutive tasks (one XCD, one L2) = 8 row tiles x 4 spatial tiles -- a V tile is twice an A image, so fewer
+    // spatial tiles per group than conv_wino4.h's 4 x 8 (-DW4V_RB=2 / 4 / 8: level to +1 %, profiles/r06_wino4v_tuning.txt)
+#ifndef W4V_RB
+#define W4V_RB 8
+#endif
+    p.rb = p.nrt >= W4V_RB ? W4V_RB : p.nrt;
+    p.tbk = 32 / p.rb;
     int cus = 0;
     hipError_t e = wino4v_device(cus);
     if (e != hipSuccess) return e;

@@ -30,6 +30,9 @@
 
 namespace chk {
 
+#ifndef W4V_CARRY
+#define W4V_CARRY 1    // 1: group 8 of a k-step runs behind the NEXT k-step's barrier (its operands are registers: covers the LDS latency there)
+#endif
 #ifndef W4V_ABL
 #define W4V_ABL 0      // timing ablations of tools/wino4_bench.hip (wrong results): 1 no barrier, 2 fragment reads of groups 0, 1 only, 4 no DMA, 8 no s_setprio, 16 every k-step from the same addresses, 32 every other DMA piece only
                        // (profiles/r06_wino4v_ablations.txt; bits 64 / 128 / 256 of that table were removed again)
@@ -172,6 +175,12 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
     auto issue_direct = [&](f32x4& dst) {
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(va8), "s"(d_a), "s"(so_a) : "memory");
     };
+    // W4V_CARRY: the ninth quad is loaded ONE k-step ahead (not two), from the A image the previous issue step addressed
+    wino_u32x4 d_ap;
+    unsigned so_ap = 0;
+    auto issue_direct_prev = [&](f32x4& dst) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(va8), "s"(d_ap), "s"(so_ap) : "memory");
+    };
     auto issue_tail = [&]() {
         // V round 4 is half a round (waves 0-3); waves 4-7 issue a DMA too, from beyond num_records (zeros) into the sink behind the ring,
         // so that every wave has the same number of loads in flight and ONE counted wait serves all (no branch around the wait)
@@ -180,6 +189,10 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
             else wino_dma16(0x80000000u, d_v, 0u, lds0 + RING + (unsigned)(wave - 4) * 1024u);
         }
         islot = islot + SB == lds0 + RING ? lds0 : islot + SB;
+        if constexpr (W4V_CARRY) {
+            d_ap = d_a;
+            so_ap = so_a;
+        }
         if constexpr (!(W4V_ABL & 16)) {
             so_v += (unsigned)VDW * 4u;
             so_a += (unsigned)ADW * 4u;
@@ -223,12 +236,14 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
     const unsigned a_off = (unsigned)(VUN + mh * 512 + lane) * 4u, v_off = (unsigned)(tg * 9 * 64 + lane) * 4u;      // floats
     auto stage = [&](unsigned slot) { return reinterpret_cast<const float*>(smem) + (slot - lds0) / 4; };
 
+    f32x4 v8c = {0.f, 0.f, 0.f, 0.f};         // W4V_CARRY: V fragments idx 8 of the previous k-step (zero: nothing pending)
     {   // prologue: k-steps 0 and 1
         issue_piece(WInt<0>{}); issue_piece(WInt<1>{}); issue_piece(WInt<2>{}); issue_piece(WInt<3>{}); issue_piece(WInt<4>{}); issue_piece(WInt<5>{});
         issue_direct(a8[0]);
         issue_tail();
         issue_piece(WInt<0>{}); issue_piece(WInt<1>{}); issue_piece(WInt<2>{}); issue_piece(WInt<3>{}); issue_piece(WInt<4>{}); issue_piece(WInt<5>{});
-        issue_direct(a8[1]);
+        if constexpr (W4V_CARRY) a8[1] = (f32x4){0.f, 0.f, 0.f, 0.f};       // (k-step 0 loads the quad of k-step 1 itself)
+        else issue_direct(a8[1]);
         issue_tail();
     }
     unsigned rslot = lds0;
@@ -238,27 +253,34 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
         acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[4 * g + 2], 0, 0, 0);
         acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[4 * g + 3], 0, 0, 0);
     };
-    // one k-step: group 8 first (its A quad is a register: the register is free for the load of k-step q + 2 right after), then groups
-    // 0..7 with the fragment reads two groups ahead; the DMAs of k-step q + 2 go out one piece per group
+    // One k-step q.  Fragment reads two groups ahead; the DMAs of k-step q + 2 go out one piece per group.
+    //   W4V_CARRY = 1: behind the barrier the reads of groups 0, 1 are issued and then the four MFMAs of group 8 of k-step q - 1 run -- their
+    //     operands (the ninth A quad of q - 1, loaded during q - 2, and V idx 8 of stage q - 1, read before the barrier) are registers, so the
+    //     matrix pipe works while the LDS answers; the quad's register is then reloaded for k-step q + 1.  A task's last group 8 is
+    //     flushed before its epilogue.
+    //   W4V_CARRY = 0: group 8 first in its own k-step (its A quad is a register: free for the load of k-step q + 2 right after).
     auto kstep = [&](auto par) {
         constexpr int PAR = decltype(par)::value;
-        wait_ring(a8[PAR]);
+        constexpr int QR = W4V_CARRY ? (PAR ^ 1) : PAR;       // the quad register consumed (and reloaded) in this k-step
+        wait_ring(a8[QR]);
         if constexpr (!(W4V_ABL & 1)) __syncthreads();
         const float* sp = stage(rslot);
         const f32x4* ap = reinterpret_cast<const f32x4*>(sp + a_off);
         const f32x4* vp = reinterpret_cast<const f32x4*>(sp + v_off);
         f32x4 A[3], V[3];
-        const f32x4 v8 = vp[8 * 64];
+        f32x4 v8 = v8c;
+        if constexpr (!W4V_CARRY) v8 = vp[8 * 64];
         A[0] = ap[0];
         V[0] = vp[0];
         A[1] = ap[64];
         V[1] = vp[64];
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(W4V_ABL & 8)) __builtin_amdgcn_s_setprio(1);
-        mfma4(a8[PAR], v8, 8);
+        mfma4(a8[QR], v8, 8);
         if constexpr (!(W4V_ABL & 8)) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        issue_direct(a8[PAR]);
+        if constexpr (W4V_CARRY) issue_direct_prev(a8[QR]);
+        else issue_direct(a8[QR]);
         __builtin_amdgcn_sched_barrier(0);
         auto group = [&](auto gt) {
             constexpr int g = decltype(gt)::value;
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
                 A[(g + 2) % 3] = ap[(g + 2) * 64];
                 V[(g + 2) % 3] = vp[(g + 2) * 64];
             }
+            if constexpr (W4V_CARRY && g == 6) v8c = vp[8 * 64];       // (read before the next barrier: the stage is overwritten after it)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(W4V_ABL & 8)) __builtin_amdgcn_s_setprio(1);
             mfma4(A[(W4V_ABL & 2) ? (g & 1) : g % 3], V[(W4V_ABL & 2) ? (g & 1) : g % 3], g);
@@ -284,6 +307,11 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
         for (int cs = 0; cs < nk; cs += 2) {      // (nk is even: the launchers)
             kstep(WInt<0>{});
             kstep(WInt<1>{});
+        }
+        if constexpr (W4V_CARRY) {                // group 8 of the task's last k-step (quad a8[1], loaded during the k-step before it)
+            wait_ring(a8[1]);
+            mfma4(a8[1], v8c, 8);
+            v8c = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         int crt, tile;
         task_of(ct, crt, tile);
