@@ -159,8 +159,20 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
                 const int sz = S >> (l + 1);          // output side of layer l; |LN output| <= sqrt(N) max|gamma| + max|beta|
                 enc_ln_scale[w][l] = sh16_scale_for_bound(std::sqrt((float)cout * sz * sz) * gm + bm);
             } else {
-                enc[w][l] = make_conv(B, B.vec(p + ".conv.weight", (size_t)cout * cin * 16), B.vec(p + ".conv.bias", cout), cout,
-                                      cin, 4, 2, 1);
+                const auto wv0 = B.vec(p + ".conv.weight", (size_t)cout * cin * 16);
+                enc[w][l] = make_conv(B, wv0, B.vec(p + ".conv.bias", cout), cout, cin, 4, 2, 1);
+                if (l == 0 && !use_sh16 && enc_l0_lut && wv0.size() == (size_t)cout * cin * 16) {
+                    // the mask channels' weights as table rows [tap][label][channel] (misc_kernels.hip shape_enc_l0): hair = class 13 -> input
+                    // channel 0; face = class l != 13 -> input channel l (l < 13) or l - 1 (shape_util.py:23-26); row 19 and unused rows: zeros
+                    if (enc0_tab_host.empty()) enc0_tab_host.assign((size_t)2 * 16 * 20 * 32, 0.f);
+                    for (int t = 0; t < 16; ++t)
+                        for (int lab = 0; lab < 19; ++lab) {
+                            const int ch = w == 0 ? (lab == 13 ? 0 : -1) : (lab == 13 ? -1 : (lab < 13 ? lab : lab - 1));
+                            if (ch < 0) continue;
+                            for (int c = 0; c < 32; ++c)
+                                enc0_tab_host[(((size_t)w * 16 + t) * 20 + lab) * 32 + c] = wv0[((size_t)c * cin + ch) * 16 + t];
+                        }
+                }
             }
             enc_ln[w][l].gamma = B.upload(gam);
             enc_ln[w][l].beta = B.upload(bet);
@@ -241,6 +253,27 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
     splitk_cap = (long long)8 << 20;
     splitk_ws = B.falloc((size_t)splitk_cap);
     codecat = B.falloc((size_t)mb * (FACE_DIM + HAIR_DIM));
+    enc0_tab = nullptr;
+    enc0_pc[0] = enc0_pc[1] = nullptr;
+    if (!use_sh16 && enc_l0_lut && !enc0_tab_host.empty() && B.err.empty()) {
+        // layer 0 of the encoders as a label table: the positional channels' part of the conv (+ bias) comes from the conv kernel itself,
+        // run once on a label map without any class (every one-hot channel zero)
+        enc0_tab = B.upload(enc0_tab_host);
+        std::vector<float> none((size_t)(HW + 3) / 4);
+        std::memset(none.data(), 0xFF, none.size() * sizeof(float));
+        const uint8_t* lab_none = reinterpret_cast<const uint8_t*>(B.upload(none));
+        enc0_pc[0] = B.falloc((size_t)32 * HW / 4);
+        enc0_pc[1] = B.falloc((size_t)32 * HW / 4);
+        if (B.err.empty()) {
+            Ck ck;
+            ck(shape_inputs(lab_none, pos, in_hair, in_face, 1, (int)HW, nullptr), "shape encoder layer 0: inputs of the positional part");
+            ck(run_conv(enc[0][0], in_hair, enc0_pc[0], 1, S, S, ConvOpts(), nullptr), "shape encoder layer 0: positional part (hair)");
+            ck(run_conv(enc[1][0], in_face, enc0_pc[1], 1, S, S, ConvOpts(), nullptr), "shape encoder layer 0: positional part (face)");
+            if (!ck.err.empty()) return ck.err;
+        }
+    }
+    enc0_tab_host.clear();
+    enc0_tab_host.shrink_to_fit();
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "device sync failed";
     ready = true;
@@ -293,7 +326,12 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
         ConvOpts eo;
         eo.partial = splitk_ws;
         eo.partial_cap = splitk_cap;
-        ck(run_conv(enc[w][l], x, y, B, size, size, eo, st), "shape enc conv");
+        if (l == 0 && enc0_tab) {
+            // `in` already holds layer 0's conv output (encode(): the label-table kernel wrote both encoders'): LayerNorm in place
+            y = const_cast<float*>(in);
+        } else {
+            ck(run_conv(enc[w][l], x, y, B, size, size, eo, st), "shape enc conv");
+        }
         size /= 2;
         ck(layernorm_act(y, enc_ln[w][l].gamma, enc_ln[w][l].beta, lnpart, B, enc[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st),
            "shape enc ln");
@@ -311,6 +349,9 @@ std::string ShapeModel::encode(const uint8_t* labels, float* hair_code, float* f
         const int B = std::min(max_batch, Btot - bo);
         Ck ck;
         if (use_sh16) ck(shape_inputs_sh16(labels + (size_t)bo * S * S, pos, in_hair, in_face, B, S * S, ENC_IN_SCALE, st), "shape inputs");
+        else if (enc0_tab)       // exact f32: no one-hot / positional input tensors at all -- layer 0 of both encoders straight from the labels
+            ck(shape_enc_l0(labels + (size_t)bo * S * S, enc0_tab, enc0_pc[0], enc0_pc[1], hair_code ? in_hair : nullptr, face_code ? in_face : nullptr,
+                            B, S, st), "shape encoder layer 0 (label table)");
         else ck(shape_inputs(labels + (size_t)bo * S * S, pos, in_hair, in_face, B, S * S, st), "shape inputs");
         if (!ck.err.empty()) return ck.err;
         std::string e;

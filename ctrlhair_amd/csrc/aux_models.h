@@ -53,6 +53,12 @@ struct ShapeModel {
     float enc_ln_scale[2][7] = {};
     static constexpr float ENC_IN_SCALE = 16384.f;
     float* pos = nullptr;      // [40][S*S]
+    // exact-f32 path: layer 0 of both encoders as a label table (misc_kernels.hip shape_enc_l0): the positional channels' part of the
+    // conv + bias per output element, and the mask channels' weights as [encoder][tap][label row][channel]
+    float* enc0_pc[2] = {nullptr, nullptr};
+    float* enc0_tab = nullptr;
+    std::vector<float> enc0_tab_host;       // (build() only)
+    int enc_l0_lut = 1;        // option "shape.enc_lut": 0 = layer 0 through the conv kernel on materialised one-hot + positional inputs
     float *in_hair = nullptr, *in_face = nullptr, *bufa = nullptr, *bufb = nullptr, *bufc = nullptr, *lnpart = nullptr,
           *codecat = nullptr, *splitk_ws = nullptr;
     long long splitk_cap = 0;

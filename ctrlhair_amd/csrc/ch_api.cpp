@@ -333,6 +333,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->shape.use_sh16 = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "shape.enc_lut") == 0) {     // exact-f32 shape encoders: 1 = layer 0 as a label table (default), 0 = through the conv kernel
+        if (h->shape.ready) return fail(h, CH_ERR_STATE, "ch_set_option(shape.enc_lut) must precede ch_finalize");
+        h->shape.enc_l0_lut = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "bisenet.f16x3") == 0) {
         if (h->bisenet.ready) return fail(h, CH_ERR_STATE, "ch_set_option(bisenet.f16x3) must precede ch_finalize");
         h->bisenet.use_sh16 = value != 0;

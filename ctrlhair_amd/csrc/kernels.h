@@ -82,6 +82,9 @@ hipError_t chan_affine_c4(const float* in, const float* sc, float sc_add, const 
 hipError_t shape_softmax(const float* hair, const float* face, uint8_t* lab, float* probs, int B, int HW, hipStream_t s,
                          int c4 = 0);
 hipError_t c4_rows_to_nchw(const float* in, float* out, int B, int C, int Cpad, int HW, hipStream_t s);
+// layer 0 of both shape encoders from the label map: out = posconst + 16 table rows per pixel (misc_kernels.hip); either output may be null
+hipError_t shape_enc_l0(const uint8_t* lab, const float* tab, const float* pc_hair, const float* pc_face, float* out_hair, float* out_face,
+                        int B, int S, hipStream_t s);
 hipError_t shape_inputs(const uint8_t* lab, const float* pos, float* hair_in, float* face_in, int B, int HW,
                         hipStream_t s);
 hipError_t shape_inputs_sh16(const uint8_t* lab, const float* pos, void* hair_in, void* face_in, int B, int HW, float scale,

@@ -1109,6 +1109,61 @@ hipError_t shape_inputs_sh16(const uint8_t* lab, const float* pos, void* hair_in
                        static_cast<uint4*>(face_in), B, HW, scale);
     return hipGetLastError();
 }
+// First layer of BOTH shape encoders as a label table (exact-f32 path; shape_branch/model.py:74-79,96-100; shape_util.py:6-26).
+// Its input is one-hot mask channels (hair: class 13; face: the 18 other classes) + 40 positional channels that never change:
+//     conv4x4s2(cat[onehot, pos]) = posconst + sum over the 16 taps of  W[:, channel(label at the tap), tap]
+// posconst[c][y][x] = bias + the positional channels' part (computed once at ch_finalize by the conv kernel itself on an all-'no class'
+// label map), the tap sum is 16 table rows per output pixel instead of 2 x 58 x 16 products per output element: the same real number in
+// another association of the f32 sum (1e-7 relative).  Taps outside the image and labels >= 19 select the all-zero row; label 13
+// selects zero in the face half and the hair row in the hair half.
+//   tab: [2 encoders][16 taps][20 rows][32 channels]   (row 19 = zeros)
+// Block = 32 output pixels of a row x the 32 channels of one encoder; thread = (pixel, group of 4 channels): 16 ds_read_b128 + 4 stores.
+__global__ __launch_bounds__(256) void shape_enc_l0_kernel(const uint8_t* __restrict__ lab, const float* __restrict__ tab,
+                                                           const float* __restrict__ pc_hair, const float* __restrict__ pc_face,
+                                                           float* __restrict__ out_hair, float* __restrict__ out_face, int B, int S) {
+    __shared__ __attribute__((aligned(16))) float T[16 * 20 * 32];
+    const int w = blockIdx.y;                     // 0 hair, 1 face
+    float* out = w == 0 ? out_hair : out_face;
+    if (!out) return;
+    const float* pc = w == 0 ? pc_hair : pc_face;
+    for (int i = threadIdx.x; i < 16 * 20 * 32 / 4; i += 256)
+        reinterpret_cast<float4*>(T)[i] = reinterpret_cast<const float4*>(tab + (size_t)w * 16 * 20 * 32)[i];
+    __syncthreads();
+    const int So = S >> 1, tpr = So >> 5;         // tiles of 32 pixels per output row
+    const int px = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const long long ntile = (long long)B * So * tpr;
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int b = (int)(t / ((long long)So * tpr)), r = (int)(t - (long long)b * So * tpr), y = r / tpr, x = (r - y * tpr) * 32 + px;
+        const uint8_t* L = lab + (size_t)b * S * S;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const int yy = 2 * y + dy - 1;
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int xx = 2 * x + dx - 1;
+                int l = 19;
+                if ((unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) l = L[yy * S + xx];
+                l = l < 19 ? l : 19;
+                const float4 v = *reinterpret_cast<const float4*>(&T[((dy * 4 + dx) * 20 + l) * 32 + cg * 4]);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        const size_t o = (((size_t)b * 32 + cg * 4) * So + y) * So + x, pcs = (size_t)So * So, pco = ((size_t)(cg * 4) * So + y) * So + x;
+        out[o] = pc[pco] + acc.x;
+        out[o + pcs] = pc[pco + pcs] + acc.y;
+        out[o + 2 * pcs] = pc[pco + 2 * pcs] + acc.z;
+        out[o + 3 * pcs] = pc[pco + 3 * pcs] + acc.w;
+    }
+}
+hipError_t shape_enc_l0(const uint8_t* lab, const float* tab, const float* pc_hair, const float* pc_face, float* out_hair, float* out_face,
+                        int B, int S, hipStream_t s) {
+    if (S % 64 != 0) return hipErrorInvalidValue;
+    const long long ntile = (long long)B * (S / 2) * (S / 64);
+    const unsigned gx = (unsigned)(ntile < 2048 ? ntile : 2048);
+    hipLaunchKernelGGL(shape_enc_l0_kernel, dim3(gx, 2), dim3(256), 0, s, lab, tab, pc_hair, pc_face, out_hair, out_face, B, S);
+    return hipGetLastError();
+}
 hipError_t shape_inputs(const uint8_t* lab, const float* pos, float* hair_in, float* face_in, int B, int HW,
                         hipStream_t s) {
     const long long n = (long long)B * HW;

@@ -222,3 +222,37 @@ def test_bisenet_non_square_and_exact_f32_option(hip_lib):
         assert float((lg.cpu() - rl).abs().max()) <= TOL
         assert not ((lab.cpu() != rlab) & ((top2[:, 0] - top2[:, 1]) > 1e-3)).any()
         fp.handle.close()
+
+
+def test_shape_encoder_layer0_label_table_equals_the_conv(hip_lib):
+    """Exact-f32 shape encoders (shape.f16x3 = 0), option shape.enc_lut (default 1): layer 0 -- a 4x4 stride-2 conv over one-hot mask
+    channels + 40 constant positional channels (shape_branch/model.py:74-79,96-100) -- is evaluated as posconst + 16 table rows per
+    output pixel straight from the label map (misc_kernels.hip shape_enc_l0) instead of a conv over materialised inputs.  Same real
+    number in another f32 association: codes against the conv evaluation of the same library (enc_lut = 0) far inside the golden bar,
+    against the reference-made fixture, on 'no class' labels at the image frame, and for the one-encoder calls (NULL outputs)."""
+    from ctrlhair_amd import lib, models
+    from ctrlhair_amd import procedural as P
+    e = env()
+    z = np.load(os.path.join(GOLDEN, 'shape_054.npz'))
+    lab = z['labels'].copy()
+    extra = P.blocky_labels(1, 256, seed=31, grid=16).copy()
+    extra[:, :3, :] = 255          # 'no class' along the top frame, hair (13) along the left one
+    extra[:, :, :2] = 13
+    labs = torch.from_numpy(np.concatenate([lab, extra])[:2]).to(e['dev'])
+    codes = {}
+    for lut in (1, 0):
+        h = lib.Handle(0)
+        h.set_option('shape.enc_lut', lut)
+        sg = models.ShapeGenerator(h, e['dev']).load_state_dict(P.shape_state_dict(0), max_batch=2, f16x3=False)
+        hc, fc = sg.encode_labels(labs)
+        hair, face = models.split_hair_face(models.mask_label_to_one_hot(labs[:, None]))
+        hc1, fc1 = sg.forward_hair_encoder(hair, testing=True), sg.forward_face_encoder(face)      # one encoder per call
+        torch.cuda.synchronize()
+        assert torch.equal(hc1, hc) and torch.equal(fc1, fc)
+        codes[lut] = (hc.cpu().numpy(), fc.cpu().numpy())
+        h.close()
+    n = lab.shape[0] if lab.shape[0] < 2 else 2
+    assert np.abs(codes[1][0][:n] - z['hair_code'][:n]).max() <= TOL and np.abs(codes[1][1][:n] - z['face_code'][:n]).max() <= TOL
+    dh, df = float(np.abs(codes[1][0] - codes[0][0]).max()), float(np.abs(codes[1][1] - codes[0][1]).max())
+    print(f'shape encoder layer 0, label table vs conv: max |delta| hair code {dh:.3e}, face code {df:.3e}')
+    assert 0 < dh + df and dh <= 2e-5 and df <= 2e-5

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 exec < /dev/null
-for r in 1 2; do for a in wino4_bench w4v_nocarry w4v_rb8 w4v_rb2; do echo "== $a run $r"; timeout 200 tools/$a.bin | grep 'V route' | sed -n '6,10p' | cut -c14-150; done; done > gpurun_out/w4v_tune.txt 2>&1
+timeout 900 python -m pytest tests/test_hip_aux_models.py tests/test_pipeline.py -x -q -m gpu 2>&1 | tail -12 > gpurun_out/t_lut.txt
+timeout 400 python bench.py --only-headline --no-cpu-baseline --steps 10 --workload pipeline --path f32 > gpurun_out/b_lut_pipe.json 2> gpurun_out/b_lut_pipe.err
