@@ -253,6 +253,18 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
     splitk_cap = (long long)8 << 20;
     splitk_ws = B.falloc((size_t)splitk_cap);
     codecat = B.falloc((size_t)mb * (FACE_DIM + HAIR_DIM));
+    // second workspace set + side stream: the hair encoder / decoder beside the face one (option "shape.overlap")
+    bufa2 = bufb2 = bufc2 = lnpart2 = splitk_ws2 = nullptr;
+    if (overlap) {
+        bufa2 = B.falloc((size_t)mb * 8192);
+        bufb2 = B.falloc(mb * 32 * HW);
+        bufc2 = B.falloc(mb * 32 * HW);
+        lnpart2 = B.falloc((size_t)mb * 128 * 3);
+        splitk_ws2 = B.falloc((size_t)splitk_cap);
+        if (!side_stream && (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess))
+            return "shape model: side stream / events";
+    }
     enc0_tab = nullptr;
     enc0_pc[0] = enc0_pc[1] = nullptr;
     if (!use_sh16 && enc_l0_lut && !enc0_tab_host.empty() && B.err.empty()) {
@@ -279,13 +291,24 @@ std::string ShapeModel::build(const TensorStore& ts, int mb) {
     ready = true;
     return "";
 }
-void ShapeModel::destroy() { free_all(allocs); ready = false; }
+void ShapeModel::destroy() {
+    free_all(allocs);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    ev_fork = ev_join = nullptr;
+    side_stream = nullptr;
+    ready = false;
+}
 
 // MaskEncoder.forward (shape_branch/model.py:96-108); vae std head unused at test (:164-169 testing=True)
-std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, hipStream_t st) {
+std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, hipStream_t st, int set) {
     Ck ck;
+    // workspace set: 0 = the caller's stream, 1 = the side stream (the two encoders are independent and each one alone leaves most of
+    // the chip idle: encode() runs them side by side)
+    float *wb = set ? bufb2 : bufb, *wc = set ? bufc2 : bufc, *wl = set ? lnpart2 : lnpart, *wk = set ? splitk_ws2 : splitk_ws;
     const float* x = in;
-    float* bufs[2] = {bufb, bufc};
+    float* bufs[2] = {wb, wc};
     int size = S;
     int l0 = 0;
     if (use_sh16) {
@@ -298,7 +321,7 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
             p.wpk = L.sh_wpk;
             p.wscale = L.sh_wscale;
             p.in_scale_inv = 1.f / s_in;
-            p.out = bufc;
+            p.out = wc;
             p.B = B;
             p.Cin = L.Cin;
             p.s2d_cr = L.s2d_cr;
@@ -309,22 +332,22 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
             p.Mrows = L.Cout;
             p.bias = L.bias;
             p.act = ACT_NONE;
-            p.partial = splitk_ws;
+            p.partial = wk;
             p.partial_cap = splitk_cap;
             ck(conv_sh16_s2d(p, L.KS, st), "shape enc conv (f16x3)");
-            ck(layernorm_act_conv(bufc, 1, bufb, l < ENC_S2D - 1 ? 1 : 0, enc_ln_scale[w][l], enc_ln[w][l].gamma, enc_ln[w][l].beta, lnpart, B,
+            ck(layernorm_act_conv(wc, 1, wb, l < ENC_S2D - 1 ? 1 : 0, enc_ln_scale[w][l], enc_ln[w][l].gamma, enc_ln[w][l].beta, wl, B,
                                   L.Cout, size * size, 1e-5f, ACT_LRELU, st), "shape enc ln");
-            x = bufb;
+            x = wb;
             s_in = enc_ln_scale[w][l];
         }
         l0 = ENC_S2D;
-        bufs[0] = bufc;              // layer 4 reads bufb
-        bufs[1] = bufb;
+        bufs[0] = wc;              // layer 4 reads wb
+        bufs[1] = wb;
     }
     for (int l = l0; l < 7; ++l) {
         float* y = bufs[l & 1];
         ConvOpts eo;
-        eo.partial = splitk_ws;
+        eo.partial = wk;
         eo.partial_cap = splitk_cap;
         if (l == 0 && enc0_tab) {
             // `in` already holds layer 0's conv output (encode(): the label-table kernel wrote both encoders'): LayerNorm in place
@@ -333,7 +356,7 @@ std::string ShapeModel::run_encoder(int w, const float* in, float* code, int B, 
             ck(run_conv(enc[w][l], x, y, B, size, size, eo, st), "shape enc conv");
         }
         size /= 2;
-        ck(layernorm_act(y, enc_ln[w][l].gamma, enc_ln[w][l].beta, lnpart, B, enc[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st),
+        ck(layernorm_act(y, enc_ln[w][l].gamma, enc_ln[w][l].beta, wl, B, enc[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st),
            "shape enc ln");
         x = y;
     }
@@ -355,24 +378,34 @@ std::string ShapeModel::encode(const uint8_t* labels, float* hair_code, float* f
         else ck(shape_inputs(labels + (size_t)bo * S * S, pos, in_hair, in_face, B, S * S, st), "shape inputs");
         if (!ck.err.empty()) return ck.err;
         std::string e;
-        if (hair_code) e = run_encoder(0, in_hair, hair_code + (size_t)bo * HAIR_DIM, B, st);
+        const bool par = overlap && side_stream && hair_code && face_code;      // the hair encoder on the side stream, beside the face encoder
+        if (par) {
+            ck(hipEventRecord(ev_fork, st), "shape encode fork");
+            ck(hipStreamWaitEvent(side_stream, ev_fork, 0), "shape encode fork wait");
+            if (!ck.err.empty()) return ck.err;
+        }
+        if (hair_code) e = run_encoder(0, in_hair, hair_code + (size_t)bo * HAIR_DIM, B, par ? side_stream : st, par ? 1 : 0);
         if (!e.empty()) return e;
-        if (face_code) e = run_encoder(1, in_face, face_code + (size_t)bo * FACE_DIM, B, st);
+        if (par) ck(hipEventRecord(ev_join, side_stream), "shape encode join");
+        if (face_code) e = run_encoder(1, in_face, face_code + (size_t)bo * FACE_DIM, B, st, 0);
         if (!e.empty()) return e;
+        if (par) ck(hipStreamWaitEvent(st, ev_join, 0), "shape encode join wait");
+        if (!ck.err.empty()) return ck.err;
     }
     return "";
 }
 
 // MaskDecoder.forward (shape_branch/model.py:138-143)
-std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, float* logit, int B, hipStream_t st) {
+std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, float* logit, int B, hipStream_t st, int set) {
     Ck ck;
-    ck(linear(code, dec_in_w[w], dec_in_b[w], nullptr, nullptr, bufa, B, code_dim, 8192, code_dim, 8192, ACT_NONE, st), "dec in");
-    const float* x = bufa;   // [B,2048,2,2]
-    float* bufs[2] = {bufb, bufc};
+    float *wa = set ? bufa2 : bufa, *wb = set ? bufb2 : bufb, *wc = set ? bufc2 : bufc, *wl = set ? lnpart2 : lnpart, *wk = set ? splitk_ws2 : splitk_ws;
+    ck(linear(code, dec_in_w[w], dec_in_b[w], nullptr, nullptr, wa, B, code_dim, 8192, code_dim, 8192, ACT_NONE, st), "dec in");
+    const float* x = wa;   // [B,2048,2,2]
+    float* bufs[2] = {wb, wc};
     int size = 2;
     ConvOpts up;
     up.in_mode = IN_UP2_NEAREST;
-    up.partial = splitk_ws;
+    up.partial = wk;
     up.partial_cap = splitk_cap;
     up.no_wino = !wino;
     ConvOpts plain_o;
@@ -380,17 +413,17 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
     if (use_sh16) {
         // layer 0 (2x2 -> 4x4, input straight from the Linear) on the exact-f32 kernel; its LayerNorm writes SH16.  Layers 1-6:
         // f16x3 conv over the nearest-x2 view (SH16 in, C4 out) -> LayerNorm + lrelu (C4 in, SH16 out); output conv -> C4 logits.
-        ck(run_conv(dec[w][0], x, bufc, B, size, size, up, st), "shape dec conv0");
+        ck(run_conv(dec[w][0], x, wc, B, size, size, up, st), "shape dec conv0");
         size *= 2;
-        ck(layernorm_act_conv(bufc, 0, bufb, 1, dec_ln_scale[w][0], dec_ln[w][0].gamma, dec_ln[w][0].beta, lnpart, B,
+        ck(layernorm_act_conv(wc, 0, wb, 1, dec_ln_scale[w][0], dec_ln[w][0].gamma, dec_ln[w][0].beta, wl, B,
                               dec[w][0].Cout, size * size, 1e-5f, ACT_LRELU, st), "shape dec ln0");
         for (int l = 1; l < 7; ++l) {
             ConvParams p{};
-            p.in = bufb;
+            p.in = wb;
             p.wpk = dec_sh[w][l];
             p.wscale = dec_ws[w][l];
             p.in_scale_inv = 1.f / dec_ln_scale[w][l - 1];
-            p.out = bufc;
+            p.out = wc;
             p.B = B;
             p.Cin = dec[w][l].Cin;
             p.H = 2 * size;
@@ -399,17 +432,17 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
             p.bias = dec[w][l].bias;
             p.act = ACT_NONE;
             p.in_mode = IN_UP2_NEAREST;
-            p.partial = splitk_ws;
+            p.partial = wk;
             p.partial_cap = splitk_cap;
             ck(conv_sh16_plain(p, 3, st), "shape dec conv (f16x3)");
             size *= 2;
-            ck(layernorm_act_conv(bufc, 1, bufb, 1, dec_ln_scale[w][l], dec_ln[w][l].gamma, dec_ln[w][l].beta, lnpart, B,
+            ck(layernorm_act_conv(wc, 1, wb, 1, dec_ln_scale[w][l], dec_ln[w][l].gamma, dec_ln[w][l].beta, wl, B,
                                   dec[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st), "shape dec ln");
         }
         {   // output conv (32 -> 1 / 18 rows, padded): C4 logits
             const ConvLayer& L = dec_out_sh[w];
             ConvParams p{};
-            p.in = bufb;
+            p.in = wb;
             p.wpk = L.sh_wpk;
             p.wscale = L.sh_wscale;
             p.in_scale_inv = 1.f / dec_ln_scale[w][6];
@@ -429,7 +462,7 @@ std::string ShapeModel::run_decoder(int w, const float* code, int code_dim, floa
         float* y = bufs[l & 1];
         ck(run_conv(dec[w][l], x, y, B, size, size, up, st), "shape dec conv");
         size *= 2;
-        ck(layernorm_act(y, dec_ln[w][l].gamma, dec_ln[w][l].beta, lnpart, B, dec[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st),
+        ck(layernorm_act(y, dec_ln[w][l].gamma, dec_ln[w][l].beta, wl, B, dec[w][l].Cout, size * size, 1e-5f, ACT_LRELU, st),
            "shape dec ln");
         x = y;
     }
@@ -458,18 +491,27 @@ std::string ShapeModel::decode(const float* hair_code, const float* face_code, f
         float* hl = hair_logit && !use_sh16 ? hair_logit + bo * HW : bufa + (size_t)B * 8192;
         float* fl = face_logit && !use_sh16 ? face_logit + bo * 18 * HW : bufa + (size_t)B * 8192 + (use_sh16 ? 4 : 1) * B * HW;
         std::string e;
+        const bool par = overlap && side_stream && hair_code;       // the hair decoder on the side stream, beside the face decoder
         if (hair_code) {
             Ck ck;
+            hipStream_t hs = par ? side_stream : st;
+            if (par) {
+                ck(hipEventRecord(ev_fork, st), "shape decode fork");
+                ck(hipStreamWaitEvent(side_stream, ev_fork, 0), "shape decode fork wait");
+            }
             ck(hipMemcpy2DAsync(codecat, (FACE_DIM + HAIR_DIM) * 4, face_code + (size_t)bo * FACE_DIM, FACE_DIM * 4, FACE_DIM * 4, B,
-                                hipMemcpyDeviceToDevice, st), "cat face");
+                                hipMemcpyDeviceToDevice, hs), "cat face");
             ck(hipMemcpy2DAsync(codecat + FACE_DIM, (FACE_DIM + HAIR_DIM) * 4, hair_code + (size_t)bo * HAIR_DIM, HAIR_DIM * 4,
-                                HAIR_DIM * 4, B, hipMemcpyDeviceToDevice, st), "cat hair");
+                                HAIR_DIM * 4, B, hipMemcpyDeviceToDevice, hs), "cat hair");
             if (!ck.err.empty()) return ck.err;
-            e = run_decoder(0, codecat, FACE_DIM + HAIR_DIM, hl, B, st);
+            e = run_decoder(0, codecat, FACE_DIM + HAIR_DIM, hl, B, hs, par ? 1 : 0);
             if (!e.empty()) return e;
+            if (par) ck(hipEventRecord(ev_join, side_stream), "shape decode join");
+            if (!ck.err.empty()) return ck.err;
         }
-        e = run_decoder(1, face_code + (size_t)bo * FACE_DIM, FACE_DIM, fl, B, st);
+        e = run_decoder(1, face_code + (size_t)bo * FACE_DIM, FACE_DIM, fl, B, st, 0);
         if (!e.empty()) return e;
+        if (par && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return "shape decode join wait failed";
         if (use_sh16) {
             Ck ck;
             if (hair_code && hair_logit) ck(c4_rows_to_nchw(hl, hair_logit + bo * HW, B, 1, 4, (int)HW, st), "hair logits");

@@ -62,6 +62,11 @@ struct ShapeModel {
     float *in_hair = nullptr, *in_face = nullptr, *bufa = nullptr, *bufb = nullptr, *bufc = nullptr, *lnpart = nullptr,
           *codecat = nullptr, *splitk_ws = nullptr;
     long long splitk_cap = 0;
+    // the two encoders (decoders) are independent chains of small launches: the hair one runs on a side stream with its own workspace
+    int overlap = 1;           // option "shape.overlap"
+    float *bufa2 = nullptr, *bufb2 = nullptr, *bufc2 = nullptr, *lnpart2 = nullptr, *splitk_ws2 = nullptr;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string build(const TensorStore& ts, int max_batch);
     std::string encode(const uint8_t* labels, float* hair_code, float* face_code, int B, hipStream_t st);
     // decode: any of hair_logit/face_logit/labels/probs may be null; hair_code may be null when only the face is wanted
@@ -71,9 +76,9 @@ struct ShapeModel {
                         hipStream_t st);
     void destroy();
   private:
-    std::string run_encoder(int which, const float* in, float* code, int B, hipStream_t st);
+    std::string run_encoder(int which, const float* in, float* code, int B, hipStream_t st, int set);
     // logit: NCHW [B][1 | 18][S*S]; f16x3 path: C4 [B][1 | 5][S*S][4] (rows padded)
-    std::string run_decoder(int which, const float* code, int code_dim, float* logit, int B, hipStream_t st);
+    std::string run_decoder(int which, const float* code, int code_dim, float* logit, int B, hipStream_t st, int set);
 };
 
 // ---- BiSeNet (external_code/face_parsing/model.py, resnet.py, my_parsing_util.py) ------------------------------

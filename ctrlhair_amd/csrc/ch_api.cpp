@@ -333,6 +333,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->shape.use_sh16 = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "shape.overlap") == 0) {     // 1 = the hair encoder / decoder on a side stream beside the face one (default), 0 = one after the other
+        if (h->shape.ready) return fail(h, CH_ERR_STATE, "ch_set_option(shape.overlap) must precede ch_finalize");
+        h->shape.overlap = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "shape.enc_lut") == 0) {     // exact-f32 shape encoders: 1 = layer 0 as a label table (default), 0 = through the conv kernel
         if (h->shape.ready) return fail(h, CH_ERR_STATE, "ch_set_option(shape.enc_lut) must precede ch_finalize");
         h->shape.enc_l0_lut = value != 0;
