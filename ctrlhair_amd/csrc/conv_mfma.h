@@ -584,7 +584,8 @@ hipError_t launch_conv(ConvParams p, int rows, hipStream_t stream) {
     int grid = p.mtiles * p.tiles_x * p.tiles_y * p.tiles_b;
     p.splitk = 1;
     p.cps = p.nchunks;
-    if (EPI == EPI_PLAIN && p.partial && grid < 192 && p.nchunks >= 8 && !FUSE) {
+    // (4x4 stride-2 layers -- the shape encoders -- split from four chunks on: layer 1, 32 -> 64 channels at 64 x 64, is 64 blocks otherwise)
+    if (EPI == EPI_PLAIN && p.partial && grid < 192 && (p.nchunks >= 8 || (KS == 4 && STRIDE == 2 && p.nchunks >= 4)) && !FUSE) {
         // few tiles but a long reduction (low-resolution, wide layers: shape VAE, BiSeNet tail): split K so that
         // ~2 blocks per CU stream the weights concurrently; partial sums go to slabs and are reduced deterministically.
         const long long slab = (long long)p.B * p.Mrows * p.H * p.W;
