@@ -149,8 +149,8 @@ def interactive_b1(ngf, S, sd_np, weights, dev):
     from ctrlhair_amd.hostutil import cap_threads_to_cpu_quota
     out = {'what': f'one {S}x{S} image per call (batch 1), median of 30 calls after 5 warm-up calls, inputs resident in HBM', 'unit': 'ms per image',
            'host_threads': cap_threads_to_cpu_quota()}
-    for path, mode in (('f32', 0), ('f16x3', 1)):
-        g = SeanGenerator(dev.index or 0, f16x3=mode).load_state_dict(sd_np, max_batch=1, max_size=S)
+    for path, mode, opts in (('f32', 0, None), ('f16x3', 1, None), ('f32_batch_invariant', 0, {'sean.batch_invariant': 1})):
+        g = SeanGenerator(dev.index or 0, f16x3=mode, options=opts).load_state_dict(sd_np, max_batch=1, max_size=S)
         l = torch.from_numpy(P.blocky_labels(1, S)).to(dev)
         c = torch.from_numpy(P.style_codes(1)).to(dev)
         n = torch.from_numpy(P.noise_planes(1, S, ngf)).to(dev)
@@ -607,7 +607,10 @@ def main():
                 variants += [('winograd_f2x2_only', {'wino': 1}), ('direct_convs_no_winograd', {'wino': 0}),
                              ('dense_worst_case_no_interior_reduction', {'sparse': 0}),
                              # the label-INDEPENDENT path: every level's SPADE convs as dense F(4x4,3x3) (what an adversarial label map costs at most)
-                             ('dense_all_levels_f4x4', {'sparse': 0, 'opt': (args.opt or []) + ['sean.wino4_ace=512']})]
+                             ('dense_all_levels_f4x4', {'sparse': 0, 'opt': (args.opt or []) + ['sean.wino4_ace=512']}),
+                             # what bit-identical results across batch sizes cost at B = 16 (option sean.batch_invariant: no split-K, no sample-pair
+                             # tiles at 16 pixels; the F(4x4) / F(2x2) rule does not bind at this size)
+                             ('batch_invariant_mode', {'opt': (args.opt or []) + ['sean.batch_invariant=1']})]
             for name, over in variants:
                 a2 = argparse.Namespace(**vars(args))
                 vpath = over.get('_path', 'f32')

@@ -376,6 +376,10 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.wino4_force = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.batch_invariant") == 0) {      // exact-f32 path: 1 = kernel choices independent of the batch size of a call (default 0)
+        h->sean.batch_inv = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.wino4v") == 0) {       // 1 = pre-transformed-input route of the F(4x4,3x3) layers with many GEMM rows (conv_wino4v.h; default), 0 = off
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.wino4v) must precede ch_finalize");
         h->sean.wino4v = value != 0;

@@ -127,7 +127,7 @@ hipError_t conv_pw(PwParams p, hipStream_t s) {
 // several GEMMs (same Cin, same Cout, own operands and pixel counts) as ONE persistent launch of the RT = 4 kernel (conv_pw.h)
 hipError_t conv_pw_grouped(PwParams p, int ntasks, hipStream_t s) {
     using Cfg = PwCfg<4>;
-    if (p.Cin % 16 || p.Cout < 32 || !p.groups || p.ngroups < 1 || ntasks < 1) return hipErrorInvalidValue;
+    if (p.Cin % 16 || p.Cout < 1 || !p.groups || p.ngroups < 1 || ntasks < 1) return hipErrorInvalidValue;      // (rows beyond Cout: zero rows of the packed operand, masked at the store)
     static bool d0[64] = {};
     hipError_t e = wino_attr(pw_conv_kernel<4>, Cfg::LDS_BYTES, d0);
     if (e != hipSuccess) return e;

@@ -971,7 +971,7 @@ struct Runner {
     // tile holds a boundary pixel -- no classification, no interior pass, hidden activations at every pixel
     bool use_wino4_ace(const AceW& a, int r) const {
         return use_wino_ace(a, r) && m.wino >= 2 && a.spade_wino4 && r <= m.wino4_ace_max_r && wino4_ace_supported(r, r, a.C) && (!a.styled || m.wsty4) &&
-               (m.wino4_force || wino4_pays((long long)B * (r / 32) * (r / 32) * ((a.C + 15) / 16), m.num_cus));      // (few tasks per CU -- single images -- : the gather kernel)
+               (m.wino4_force || m.batch_inv || wino4_pays((long long)B * (r / 32) * (r / 32) * ((a.C + 15) / 16), m.num_cus));      // (few tasks per CU -- single images -- : the gather kernel)
     }
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
                         float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr,
@@ -992,7 +992,7 @@ struct Runner {
             const int N = B * bs, npad = ((N + 31) / 32) * 32;
             q.lut_bs = bs;
             const double fl = 2.0 * 18 * a.C * STYLE * N, by = 4.0 * (18.0 * a.C * STYLE + (double)STYLE * N + 18.0 * a.C * N);
-            if (a.lut_rows && N <= 64) {
+            if (a.lut_rows && N <= 64 && !m.batch_inv) {
                 // interactive batch sizes: P[n][row] = sum_k W[row][k] mu[n][k] as a batched GEMV (weight-bandwidth bound)
                 check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s, m.mu_img, 0, bs), "fc_mu");
                 tm(fl, by, [&] {
@@ -1031,7 +1031,7 @@ struct Runner {
                 q.lut_ns = 4;
             } else {
                 const float* mu = m.mu_img;
-                if (m.fcmu_batched && N > 64) mu = m.mu_all + (size_t)a.index * m.mu_stride;      // projected at the start of the chunk (generate())
+                if (m.fcmu_batched && (N > 64 || m.batch_inv)) mu = m.mu_all + (size_t)a.index * m.mu_stride;      // projected at the start of the chunk (generate())
                 else check(fc_mu(codes, a.fcmu_w, a.fcmu_b, m.mu_img, B, npad, s), "fc_mu");
                 ConvParams p{};
                 p.in = mu;
@@ -1415,7 +1415,7 @@ struct Runner {
             }
             return;
         }
-        if (!m.use_sh16 && m.gb_small) {
+        if (!m.use_sh16 && m.gb_small && !m.batch_inv) {
             // Tiny levels at small batches (one image at 16 x 16: 16 blocks of the fused kernel, 8 % of the CUs, 200 us): the SPADE conv as a
             // PLAIN conv over the same packed image -- which splits K over blocks when its grid is small (conv_mfma.h launch_conv) -- into
             // a scratch of gamma | beta sums, then ace_finish_f32 (style-LUT gathers, biases, modulation).  Same sums per element, the
@@ -1457,7 +1457,7 @@ struct Runner {
                !(((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192);
     }
     bool use_wino(const ConvW& w, int r) const {
-        return m.wino && !m.use_sh16 && w.wino && w.KS == 3 && (wino_supported(r, r, w.Cin) || wino_supported_pair16(B, r, r, w.Cin));
+        return m.wino && !m.use_sh16 && w.wino && w.KS == 3 && (wino_supported(r, r, w.Cin) || (!m.batch_inv && wino_supported_pair16(B, r, r, w.Cin)));
     }
     // `prod` / `prod2`: the ACEs that wrote `in` / `in2` (their slots hold the scale in effect)
     void conv(const ConvW& w, const float* in, const AceW& prod, float* out, int r, const float* res, int res_up,
@@ -1487,12 +1487,12 @@ struct Runner {
         p.terms = m.terms;
         p.wscale = w.wscale;                       // shared with w2's rows when a 1x1 operand is fused (build())
         p.in_scale_inv = 1.f / prod.out_scale;     // inputs are ACE outputs (a fused second operand: see sh16_in_scale_inv)
-        p.partial = m.splitk_ws;
+        p.partial = m.batch_inv ? nullptr : m.splitk_ws;      // (split-K follows the grid size, i.e. the batch)
         p.partial_cap = m.splitk_cap;
         p.mtiles_hint_small = (((w.Cout + 63) / 64) * (((long long)B * r * r + 511) / 512) < 192) ? 1 : 0;
         const double npix = (double)B * r * r, k2 = w.KS * w.KS, cin2 = w2 ? w2->Cin : 0;
         if (m.wino >= 2 && !m.use_sh16 && w.wino4 && w.KS == 3 && !w2 && wino4_supported(r, r, w.Cin) &&
-            (!use_wino(w, r) || m.wino4_force || wino4_pays((long long)B * (r / 32) * (r / 32) * ((w.Cout + 31) / 32), m.num_cus))) {
+            (!use_wino(w, r) || m.wino4_force || m.batch_inv || wino4_pays((long long)B * (r / 32) * (r / 32) * ((w.Cout + 31) / 32), m.num_cus))) {
             // Winograd F(4x4,3x3) on the exact-f32 matrix cores: 36 MFMA products per 4 x 4 tile and channel instead of 144
             Wino4Params q{};
             q.in = in;
@@ -1544,7 +1544,7 @@ struct Runner {
             q.act = ACT_NONE;
             q.zero = m.zero_page;
             q.claim = next_claim();
-            q.partial = m.splitk_ws;               // (launches with far fewer tasks than CUs split K: conv_wino_plain)
+            q.partial = m.batch_inv ? nullptr : m.splitk_ws;               // (launches with far fewer tasks than CUs split K: conv_wino_plain)
             q.partial_cap = m.splitk_cap;
             next_flops_exec = 2.0 * w.Cout * w.Cin * 16.0 * npix / 4.0;
             timed(0, 2.0 * w.Cout * w.Cin * 9.0 * npix,
@@ -1623,7 +1623,7 @@ std::string SeanModel::generate(const uint8_t* labels, const float* codes, const
         for (int k = 1; k <= 5; ++k) R.check(label_downsample(lab, lab_r[k], B, S, S >> k, st), "label_downsample");
         if (use_sh16) R.check(hipMemsetAsync(amax_slots, 0, 64 * sizeof(unsigned), st), "amax slots");
         if (fcmu_batched && !use_sh16) {
-            if (B * LABEL_NC > 64) {     // (smaller batches take the GEMV branch of ace_prepare, which projects per ACE)
+            if (B * LABEL_NC > 64 || batch_inv) {     // (smaller batches take the GEMV branch of ace_prepare, which projects per ACE)
                 // grouped LUT build: the projections are its A operand, written in fragment order (sh16 = 2: pack_pw_A layout)
                 const bool grouped = lut_groups && lut_ngroups > 0;
                 R.check(fc_mu_batched(cd, fcmu_w_ptrs, fcmu_b_ptrs, mu_all, mu_stride, n_aces, B, ((B * LABEL_NC + 31) / 32) * 32, LABEL_NC, 1.f,
@@ -1825,7 +1825,7 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             ck(conv_sh16_plain(p, 3, st), "zenc conv5 (f16x3)");
         } else {
             ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
-            if (z14_wino4 && wino4_supported(h2, h2, 256) && (wino4_force || wino4_pays((long long)B * (h2 / 32) * (h2 / 32) * 16, num_cus))) {
+            if (z14_wino4 && wino4_supported(h2, h2, 256) && (wino4_force || batch_inv || wino4_pays((long long)B * (h2 / 32) * (h2 / 32) * 16, num_cus))) {
                 Wino4Params q{};
                 q.in = hs;
                 q.wpk = z14_wino4;

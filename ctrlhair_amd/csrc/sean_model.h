@@ -158,6 +158,9 @@ struct SeanModel {
     int num_cus = 256;                         // compute units of the handle's device (build())
     int wino4_force = 0;                       // option "sean.wino4_force": 1 = F(4x4,3x3) wherever the shape allows, whatever the task count (tests)
     int wino4_ace_max_r = 64;                  // option "sean.wino4_ace": largest level whose SPADE convs run as F(4x4,3x3) over EVERY tile (0 = none)
+    int batch_inv = 0;                         // option "sean.batch_invariant": 1 = every choice that follows the number of tasks of a call (F(4x4) vs F(2x2),
+                                               //   split-K, sample-pair tiles at 16 pixels, the small-batch LUT / tiny-level routes) is made as for a large
+                                               //   batch: sample i alone == sample i in any batch, bit for bit (exact-f32 path)
     int wino4v = 1;                            // option "sean.wino4v": 1 = F(4x4,3x3) layers with >= 512 GEMM rows at <= 64 pixels (and the Zencoder's 256 -> 512
                                                //   conv) take their input pre-transformed by one extra pass (conv_wino4v.h; bit-identical results)
     float* vbuf = nullptr;                     // the pre-transformed input V of the layer being run (conv_wino4v.h)

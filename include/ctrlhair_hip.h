@@ -88,6 +88,12 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   Both F(4x4,3x3) choices are made per call: with fewer tasks of 32 x 32 pixels than a round of F(2x2,3x3) tasks would need CUs (single
  *   images, small batches of small images) the F(2x2,3x3) kernels run instead (wino4_pays, conv_wino4.h); "sean.wino4_force" = 1 (any
  *   time) switches that rule off.
+ * "sean.batch_invariant" (default 0; any time; exact-f32 path): by default several choices follow the number of tasks of a call, i.e. its
+ *   batch size -- F(4x4,3x3) vs F(2x2,3x3) (wino4_pays), split-K of launches with few tasks, sample-pair tiles of the 16-pixel level, the
+ *   GEMV / tiny-level routes of interactive batches -- so the same sample rendered alone and inside a batch differs by the rounding of two
+ *   associations of the same f32 sums (measured <= 3e-5 at 512 x 512).  1 = every such choice is made as for a large batch: sample i
+ *   alone == sample i in any batch of the same handle, bit for bit (tests/test_hip_sean_generator.py); costs latency on small calls
+ *   (bench.py reports both).
  * "sean.wino4v" (default 1; before ch_finalize; with "sean.wino" = 2): F(4x4,3x3) layers with at least 512 GEMM rows at up to 64 x 64
  *   pixels -- the ResBlock convs of G_middle / up_0 and every SPADE / style conv that "sean.wino4_ace" selects -- and the Zencoder's
  *   256 -> 512 conv read their input pre-transformed (V = B^T d B, written once by an extra bandwidth-bound pass, csrc/conv_wino4v.h)

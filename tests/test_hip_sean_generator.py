@@ -276,3 +276,32 @@ def test_alternating_sizes_on_a_run_ahead_handle(hip_lib, sizes):
         fresh.handle.close()
         d = np.abs(got - want)
         assert d.max() == 0.0, f'S={S} after other sizes differs from a fresh handle: {d.max():.3e}; border columns {d[..., :2].max():.3e} / {d[..., -2:].max():.3e}'
+
+
+def test_batch_invariant_mode(hip_lib):
+    """Option sean.batch_invariant = 1 (exact-f32 path): every choice that follows the task count of a call -- F(4x4,3x3) vs F(2x2,3x3)
+    (wino4_pays), split-K, sample-pair tiles at 16 pixels, the GEMV / tiny-level routes of interactive batches -- is made as for a large
+    batch, so that sample i rendered alone equals sample i inside a batch of 16 (BASELINE.json configs[1] shape) and inside a batch of 3:
+    <= 2e-6 asked, bit-identical expected; and the mode stays inside the golden bar.  The default mode differs at
+    the 1e-5 level on the same inputs (test_golden_batch16_full_size)."""
+    from ctrlhair_amd import procedural as P
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    ui = Case('ngf64_S512_ui')
+    ngf, S, B = 64, 512, 16
+    sd = _sds.setdefault((ngf, 0), P.sean_state_dict(0, ngf))
+    gen = SeanGenerator(0, f16x3=0, options={'sean.batch_invariant': 1}).load_state_dict(sd, max_batch=B, max_size=S)
+    labels = np.concatenate([ui.labels, P.blocky_labels(B - 2, S, seed=910), np.stack([P.face_like_labels(S, 77)])])
+    codes = np.concatenate([ui.codes, P.style_codes(B - 1, seed=911)])
+    noise = np.concatenate([ui.noise, P.noise_planes(B - 1, S, ngf, seed=912)])
+    img = _run(gen, labels, codes, noise)
+    assert np.isfinite(img).all()
+    assert ui.diff_samples(img[0:1], [0]) <= TOL
+    worst = 0.0
+    for i in (0, 5, B - 1):
+        one = _run(gen, labels[i:i + 1], codes[i:i + 1], noise[i:i + 1])
+        worst = max(worst, float(np.abs(one[0] - img[i]).max()))
+    three = _run(gen, labels[4:7], codes[4:7], noise[4:7])
+    worst = max(worst, float(np.abs(three - img[4:7]).max()))
+    print(f'batch-invariant mode: max |alone - in batch| = {worst:.3e}')
+    assert worst <= 2e-6
+    gen.handle.close()
