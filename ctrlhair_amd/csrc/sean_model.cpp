@@ -604,6 +604,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
     wsty = wsty4 = nullptr;
     if (wino && !use_sh16) {
         size_t wsty_max = 0, wsty4_max = 0;
+        int lvl_planes[6] = {0, 0, 0, 0, 0, 0};        // planes of the level's padded hidden-activation buffer: what its ACEs write (ace_prepare: kout)
         for (const auto& b : blocks)
             for (const AceW* a : {b.learned ? &b.ace_s : nullptr, &b.ace_0, &b.ace_1}) {
                 if (!a || !a->spade_wino) continue;
@@ -636,6 +637,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     w.total = static_cast<int*>(B.dalloc(8 * sizeof(int)));
                     L.works.push_back(w);
                 }
+                lvl_planes[k] = std::max(lvl_planes[k], a->styled ? HID + 20 : HID);       // (up_3 is unstyled: 128 planes, no one-hot planes)
                 if (a->styled) wsty_max = std::max(wsty_max, (size_t)mb * nrt * 5 * 2048);
                 if (a->styled && a->spade_wino4) wsty4_max = std::max(wsty4_max, (size_t)mb * nrt * 6 * wino4::ADW);
             }
@@ -666,7 +668,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
         for (int k = 0; k < 6; ++k)
             if (wq_level[k].qlist) {
                 const size_t r = (size_t)ms >> k;
-                actv_lvl[k] = B.falloc((size_t)mb * r * wino_apitch((int)r) * (HID + 20));
+                actv_lvl[k] = B.falloc((size_t)mb * r * wino_apitch((int)r) * lvl_planes[k]);
             }
     }
     prof_stats_cap = 16384;

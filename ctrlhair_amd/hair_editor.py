@@ -78,15 +78,22 @@ class HairEditor:
     """This is the basic module (hair_editor.py:40-43); ctrlhair_amd.ui.backend.Backend succeeds this class."""
 
     def __init__(self, load_feature_model=True, load_mask_model=True, *, weights='procedural', device: int = 0,
-                 img_size: int = 256, models=None, texture_dirs=None, shape_dirs=None, max_batch: int = 1, f16x3=None):
+                 img_size: int = 256, models=None, texture_dirs=None, shape_dirs=None, max_batch: int = 1, f16x3=None,
+                 cap_threads: bool = None):
         """f16x3: None = by the weights: True (split-operand f16 MFMA, f32-class, ~3x faster) for procedural weights, on which
         every parity test runs; False (exact-f32 MFMA, the reference's arithmetic) for a released checkpoint tree
         (weights='reference' or a directory) -- the split-operand path is tested on heavy-tailed synthetic weights
         (tests/test_hip_robust_weights.py) but has never seen the real checkpoints, which cannot be fetched here.  Pass
-        True / False to choose explicitly."""
+        True / False to choose explicitly.
+        cap_threads: the constructor lowers torch's intra-op thread count to the container's CPU quota when the pool is larger (a pool
+        larger than the CFS quota stalls every other edit for ~85 ms).  That is a PROCESS-WIDE setting the reference does not touch:
+        pass False (or set CTRLHAIR_NO_THREAD_CAP=1) to leave the embedding application's thread pool alone."""
         if f16x3 is None:
             f16x3 = not is_released_checkpoint(weights)
-        U.cap_threads_to_cpu_quota()       # (a CPU thread pool larger than the container's CFS quota stalls every other edit for ~85 ms)
+        if cap_threads is None:
+            cap_threads = os.environ.get('CTRLHAIR_NO_THREAD_CAP', '') in ('', '0')
+        if cap_threads:
+            U.cap_threads_to_cpu_quota()
         if models is None:
             if weights == 'procedural':
                 weights = procedural_weights()

@@ -63,6 +63,15 @@ def cap_threads_to_cpu_quota():
 
 
 _PINNED = {}
+_PINNED_LOCK = None
+
+
+def _pinned_lock():
+    global _PINNED_LOCK
+    if _PINNED_LOCK is None:
+        import threading
+        _PINNED_LOCK = threading.Lock()
+    return _PINNED_LOCK
 
 
 def to_host(t):
@@ -77,13 +86,14 @@ def to_host(t):
     if not t.is_cuda:
         return t.numpy()
     key = (tuple(t.shape), t.dtype)
-    buf = _PINNED.get(key)
-    if buf is None:
-        if len(_PINNED) > 64:
-            _PINNED.clear()
-        buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    buf.copy_(t.contiguous())          # synchronous: the data has landed when copy_ returns
-    return buf.numpy().copy()
+    with _pinned_lock():               # (two threads with tensors of one shape would otherwise share the staging buffer between copy_ and copy)
+        buf = _PINNED.get(key)
+        if buf is None:
+            if len(_PINNED) > 64:
+                _PINNED.clear()
+            buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t.contiguous())          # synchronous: the data has landed when copy_ returns
+        return buf.numpy().copy()
 
 
 def _linear_taps(n_out: int, n_in: int):

@@ -104,9 +104,11 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   SLOWER than the serial order at every setting on MI355X: kept as an option, not used.
  * "sean.lut_grouped" (default 1; exact-f32 path, calls with more than 64 (sample, label) columns): the style LUTs of all styled ACEs
  *   of a chunk come from ONE grouped GEMM launch at its start (csrc/conv_pw.h); 0 = one launch of the generic 1x1 kernel per ACE.
- * "sean.hidden_wq" (default 1; any time): Winograd ACE levels of 128 pixels and more take the SPADE hidden activations and the one-hot
- *   planes from one persistent kernel that writes only the 64-byte pixel groups a boundary quad's patch touches
- *   (csrc/sean_kernels.hip spade_hidden_wq); 0 = the label-table kernel over every pixel + the one-hot kernel (bit-identical results).
+ * "sean.hidden_wq" (default 1; any time): every Winograd ACE level (32 pixels and more) takes the SPADE hidden activations and the
+ *   one-hot planes from one persistent kernel (csrc/sean_kernels.hip spade_hidden_wq).  1 = on the gather levels it writes only the
+ *   64-byte pixel groups that a boundary quad's patch touches; 0 = the same kernel over every pixel (bit-identical results).  The dense
+ *   F(4x4,3x3) levels ("sean.wino4_ace") read every pixel either way.  (The two-kernel route of round 4 -- label table + one-hot kernel --
+ *   serves the levels below 32 pixels only.)
  * "sean.wino_gather" (default 1): the Winograd ACE kernel takes tasks of 64 consecutive boundary quads of a sample and fetches each
  *   quad's own 4 x 4 patch (csrc/conv_wino.h); 0 = tasks per tile of 32 x 16 / 32 x 32 pixels (bit-identical results).
  * "sean.wino_th": tile height 16 / 32 of the tile mode (0 = chosen per resolution level).
