@@ -305,3 +305,24 @@ def test_batch_invariant_mode(hip_lib):
     print(f'batch-invariant mode: max |alone - in batch| = {worst:.3e}')
     assert worst <= 2e-6
     gen.handle.close()
+
+
+@pytest.mark.parametrize('wino', [1, 0])
+def test_batch_composition_tight_bound_without_f4x4(hip_lib, wino):
+    """sean.wino = 1 (F(2x2,3x3): transforms that only add) and 0 (direct sums): sample i alone vs inside a batch at the bound that held
+    before F(4x4,3x3) became the default (2e-5; the default mode's bound is 1e-4, test_golden_batch16_full_size) -- a regression in the
+    non-F(4x4) kernels must not hide behind the looser default bound."""
+    from ctrlhair_amd import procedural as P
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    ngf, S, B = 64, 256, 6
+    sd = _sds.setdefault((ngf, 0), P.sean_state_dict(0, ngf))
+    gen = SeanGenerator(0, f16x3=0, options={'sean.wino': wino}).load_state_dict(sd, max_batch=B, max_size=S)
+    labels, codes, noise = P.blocky_labels(B, S, seed=920), P.style_codes(B, seed=921), P.noise_planes(B, S, ngf, seed=922)
+    img = _run(gen, labels, codes, noise)
+    worst = 0.0
+    for i in (0, 3, B - 1):
+        one = _run(gen, labels[i:i + 1], codes[i:i + 1], noise[i:i + 1])
+        worst = max(worst, float(np.abs(one[0] - img[i]).max()))
+    print(f'sean.wino={wino}: max |alone - in batch| = {worst:.3e}')
+    assert worst <= 2e-5
+    gen.handle.close()
