@@ -414,8 +414,9 @@ def roofline_block(path, prof, value, B, sustained):
     else:
         executed, peak, pk = useful, PEAK_F32_MFMA_TFLOPS, 'f32'
         kname = ('wino_ace_gather_kernel (SPADE gamma/beta conv + style convs as Winograd F(2x2,3x3) on the exact-f32 matrix cores over '
-                 'tasks of 64 boundary quads, fused ACE epilogue: the levels above 64 pixels) + wino4_ace_kernel (the same conv as F(4x4,3x3) over '
-                 'every tile: 32 / 64 pixels) + conv_mfma_kernel<KS=3,...,EPI_ACE> for the ACEs below 32 pixels; --wino 0: conv_ace_sparse_kernel')
+                 'tasks of 64 boundary quads, fused ACE epilogue: the levels above 64 pixels) + wino4v_kernel<1> (the same conv as F(4x4,3x3) over '
+                 'every tile with the hidden activations pre-transformed by wino4v_pack_kernel, csrc/conv_wino4v.h: 32 / 64 pixels; '
+                 'sean.wino4v=0: wino4_ace_kernel) + conv_mfma_kernel<KS=3,...,EPI_ACE> for the ACEs below 32 pixels; --wino 0: conv_ace_sparse_kernel')
     traffic = traffic_raw = detail = note = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
