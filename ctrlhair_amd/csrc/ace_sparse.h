@@ -15,6 +15,17 @@
 //     conv_sh16.h), whose B-fragment addresses are per lane anyway.
 // Identities in real arithmetic; in fp32 the interior value is the same sum in another association (1e-6 level).
 //
+// Round 6 -- STRAIGHT-EDGE pixels (exact-f32 Winograd path, levels of 128 pixels and more; option "sean.edge").  Most boundary pixels of a
+// label map sit next to ONE straight, axis-aligned piece of a region border: their 5x5 neighbourhood is five uniform columns (or rows)
+// A..A B..B with s = 1..4 columns of label A.  The hidden activation then depends on the column only (three vectors out of
+// {a_A, h_AAB, h_ABB, a_B}, h_XYZ = relu(b + sum_tx Tcol[X|Y|Z][tx]) with the shared conv's taps summed over rows), and
+//      gamma = b + sum_dx (sum_dy W[:, :, (dy, dx)]) h_dx(A, B, s)
+// is a per-(orientation, A, B, s) constant: 2 x 19 x 19 x 4 = 2888 table rows E[code][gamma|beta][C] per ACE, built once at
+// ch_finalize in double (ace_edge_table).  The style term (normalization.py:117-153,172-173) of such a pixel is three column (row)
+// sums of the style LUT, P6[(sample, label)][3 columns + 3 rows][gamma|beta][C], built per call (ace_p6table).  Such pixels are marked
+// u5 = 253 with their code in e16 and are modulated by the interior pass -- no convolution; only corners, curved pieces and the image
+// frame are left to the boundary conv.  Same real number, another association of the f32 sum (as the interior pixels).
+//
 // Per resolution level and generate() chunk, ace_classify builds
 //      u5   [B][H][W]  uint8   label if the pixel is interior, else 255
 //      need [B][H][W]  uint8   1 where the boundary conv reads the SPADE hidden activations (the label-table kernel skips the rest)
@@ -52,6 +63,7 @@ __host__ __device__ inline int sparse_max_tasks(int TH, int mtiles) {
 
 struct SparseLevel {            // device buffers of one resolution level (sean_model.cpp allocates them at build())
     uint8_t* u5 = nullptr;
+    uint16_t* e16 = nullptr;    // [B][H][W] code of a straight-edge pixel (u5 == 253): ((orientation * 19 + A) * 19 + B) * 4 + (s - 1); or null
     uint8_t* need = nullptr;    // [B][H][W] 1 where the boundary conv reads the SPADE hidden activations (3x3 around a boundary pixel)
     uint16_t* list = nullptr;
     int* cnt = nullptr;
@@ -73,8 +85,18 @@ struct SparseWork {             // block tasks of one (level, mtiles) pair
 };
 
 // lab: [B][H][W] labels of the level.  Tiles of 32 x TH pixels (TH = 8 or 16).
+// e16 (may be null): also recognise the straight-edge pixels (u5 = 253, e16 = code); they are NOT boundary pixels of the lists
+constexpr int ACE_EDGE = 253, ACE_EDGE_CODES = 2 * 19 * 19 * 4;
 hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t* list, int* cnt, int B, int H, int W, int TH,
-                        hipStream_t s);
+                        hipStream_t s, uint16_t* e16 = nullptr);
+// E[code][gamma|beta][C] (float) from the column / row sums of the SPADE gamma/beta weights W6[gb][k][6][C] (double; 0..2: sum over dy of
+// tap (dy, dx = -1, 0, 1), 3..5: sum over dx of tap (dy = -1, 0, 1)) and the hidden vectors hv[orientation][741][128] (double; index 0..18:
+// a_j, 19 + (A * 19 + B) * 2 + (0: window X X Y = AAB | 1: window X Y Y = ABB)); scale_g / scale_b: the SPADE share of the blend;
+// bias_g / bias_b are added (the table rows are complete gamma / beta of an unstyled ACE)
+hipError_t ace_edge_table(const double* W6, const double* hv, const float* bias_g, const float* bias_b, float scale_g, float scale_b,
+                          float* E, int C, hipStream_t s);
+// P6[(b, j)][k = 0..5][gamma|beta][C] = lut_mul * sum of the three style-LUT taps of column k (k < 3: taps (dy, dx = k - 1)) or row k - 3
+hipError_t ace_p6table(const float* lut, int lut_rs, int lut_ns, int lut_bs, float lut_mul, float* p6, int B, int C, hipStream_t s);
 // mode 0: block tasks of conv_ace_sparse_kernel; mode 1: (tile, row tile) pairs of the tiles with a boundary pixel (f16x3 tile-skip)
 hipError_t ace_worklist(const int* cnt, int ntiles, int mtiles, unsigned* work, int* total, hipStream_t s, int mode = 0,
                         int tile_px = 512, unsigned* work2 = nullptr, int* total2 = nullptr,    // mode 3: second list (pair entries)
@@ -105,6 +127,9 @@ struct AceInteriorParams {
                                 // pixels -- the boundary conv, launched after this pass, overwrites the others; 0 = 128
     int quad_only;              // exact-f32 tile kernels: 1 = write an interior pixel only when its whole 2 x 2 quad is interior (the Winograd
                                 // boundary conv writes all four pixels of a boundary quad; needed when the two run concurrently)
+    const uint16_t* e16;        // exact-f32 tile4 kernel: codes of the straight-edge pixels (u5 == 253), or null
+    const float* etab;          //   E[2888][2][C] of this ACE (bias included)
+    const float* p6;            //   P6[(b, j)][6][2][C] of this call, or null (unstyled ACE)
     int variant;                // exact-f32 kernel: 0 = one pixel per thread (default), 1 = four pixels per thread (16-byte
                                 // accesses), 2 = one pixel per thread writing whole 32-byte sectors (A/B measurements)
 };

@@ -11,13 +11,42 @@ namespace chk {
 // A pixel is INTERIOR iff its label is < 19 and all 25 labels of its 5x5 neighbourhood exist (inside the image) and equal it.
 // need[p] = 1 iff some pixel of the 3x3 neighbourhood of p is a boundary pixel: only there does the boundary conv read the
 // SPADE hidden activations, so the label-table kernel may skip every other pixel.
+// e16 != nullptr: a pixel that is not interior but whose 5x5 neighbourhood (inside the image, labels < 19) is five uniform columns
+// A^s B^(5-s) or five uniform rows likewise (s = 1..4, A != B) is a STRAIGHT-EDGE pixel: u5 = 253, e16 = its code (ace_sparse.h); it is
+// not a boundary pixel for `need`, `list` and `cnt`.
+__device__ __forceinline__ int ace_edge_code(const uint8_t* w, int PW) {      // w: top-left of the 5x5 window in the LDS patch; -1: none
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int sj = o ? PW : 1, si = o ? 1 : PW;          // step along the split direction / along a line of equal labels
+        int l[5];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            l[j] = w[j * sj];
+#pragma unroll
+            for (int i = 1; i < 5; ++i) ok = ok && w[j * sj + i * si] == l[j];
+        }
+        const int A = l[0], Bl = l[4];
+        ok = ok && A < 19 && Bl < 19 && A != Bl;
+        int s = 1;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) s += (l[j] == A && s == j) ? 1 : 0;       // leading run of A
+#pragma unroll
+        for (int j = 1; j < 4; ++j) ok = ok && l[j] == (j < s ? A : Bl);
+        if (ok) return ((o * 19 + A) * 19 + Bl) * 4 + (s - 1);
+    }
+    return -1;
+}
+
 template <int TH>
 __global__ __launch_bounds__(32 * TH) void ace_classify_kernel(const uint8_t* __restrict__ lab, uint8_t* __restrict__ u5,
                                                              uint8_t* __restrict__ need, uint16_t* __restrict__ list,
-                                                             int* __restrict__ cnt, int H, int W, int tiles_x, int tiles_y) {
+                                                             int* __restrict__ cnt, int H, int W, int tiles_x, int tiles_y,
+                                                             uint16_t* __restrict__ e16) {
     constexpr int NT = 32 * TH, PW = 38, PH = TH + 6, BW = 34, BH = TH + 2, NW = NT / 64;
     __shared__ uint8_t patch[PH * PW];       // labels of the tile + 3 pixels around it (255 outside the image)
     __shared__ uint8_t bflag[BH * BW];       // boundary flags of the tile + 1 pixel around it
+    __shared__ uint16_t ecode[BH * BW];      // codes of the straight-edge pixels among them
     __shared__ int wcnt[NW];
     const int tile = blockIdx.x, tid = threadIdx.x;
     const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
@@ -38,7 +67,15 @@ __global__ __launch_bounds__(32 * TH) void ace_classify_kernel(const uint8_t* __
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) uni = uni && patch[(by + dy) * PW + bx + dx] == c;
         const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        bflag[i] = inside ? (uni ? c : (uint8_t)255) : (uint8_t)254;       // 254: outside the image (neither kind)
+        uint8_t f = inside ? (uni ? c : (uint8_t)255) : (uint8_t)254;       // 254: outside the image (neither kind)
+        if (e16 && f == 255) {
+            const int code = ace_edge_code(patch + by * PW + bx, PW);
+            if (code >= 0) {
+                f = (uint8_t)ACE_EDGE;
+                ecode[i] = (uint16_t)code;
+            }
+        }
+        bflag[i] = f;
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31, y = y0 + ty, x = x0 + tx;
@@ -52,6 +89,7 @@ __global__ __launch_bounds__(32 * TH) void ace_classify_kernel(const uint8_t* __
     if (inside) {
         u5[(long long)b * H * W + (long long)y * W + x] = me;
         need[(long long)b * H * W + (long long)y * W + x] = nd ? 1 : 0;
+        if (e16 && me == ACE_EDGE) e16[(long long)b * H * W + (long long)y * W + x] = ecode[(ty + 1) * BW + tx + 1];
     }
     const bool bnd = inside && me == 255;
     // ordered compaction: raster order inside the tile (wave w = rows 2w, 2w+1)
@@ -70,10 +108,10 @@ __global__ __launch_bounds__(32 * TH) void ace_classify_kernel(const uint8_t* __
 }
 
 hipError_t ace_classify(const uint8_t* lab, uint8_t* u5, uint8_t* need, uint16_t* list, int* cnt, int B, int H, int W, int TH,
-                        hipStream_t s) {
+                        hipStream_t s, uint16_t* e16) {
     const int tx = (W + 31) / 32, ty = (H + TH - 1) / TH;
-    if (TH == 8) hipLaunchKernelGGL(ace_classify_kernel<8>, dim3(B * tx * ty), dim3(256), 0, s, lab, u5, need, list, cnt, H, W, tx, ty);
-    else if (TH == 16) hipLaunchKernelGGL(ace_classify_kernel<16>, dim3(B * tx * ty), dim3(512), 0, s, lab, u5, need, list, cnt, H, W, tx, ty);
+    if (TH == 8) hipLaunchKernelGGL(ace_classify_kernel<8>, dim3(B * tx * ty), dim3(256), 0, s, lab, u5, need, list, cnt, H, W, tx, ty, e16);
+    else if (TH == 16) hipLaunchKernelGGL(ace_classify_kernel<16>, dim3(B * tx * ty), dim3(512), 0, s, lab, u5, need, list, cnt, H, W, tx, ty, e16);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -187,6 +225,59 @@ hipError_t ace_gtable(const float* bias_g, const float* bias_b, const float* gco
     const long long n = (long long)B * 19 * 2 * C;
     hipLaunchKernelGGL(ace_gtable_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bias_g, bias_b, gconst, lut, lut_rs,
                        lut_ns, lut_bs, lut_mul, gtab, B, C);
+    return hipGetLastError();
+}
+
+// ---- straight-edge pixels: the per-code rows of an ACE (ch_finalize) and the per-call column / row sums of the style LUT ----------------
+// hidden-vector index of the window (X, Y, Z) of three column (row) labels out of {A, B}, monotone: XXX -> a_X; AAB / ABB -> pair entries
+__host__ __device__ inline int ace_edge_hv(int X, int Y, int Z) { return (X == Z) ? X : 19 + (X * 19 + Z) * 2 + (Y == X ? 0 : 1); }
+// labels of the five columns (rows) of code (A, B, s): A for index < s, B from s on; hidden position d = -1, 0, 1 sees columns 1 + d .. 3 + d
+__global__ __launch_bounds__(256) void ace_edge_table_kernel(const double* __restrict__ W6, const double* __restrict__ hv, const float* __restrict__ bias_g,
+                                                             const float* __restrict__ bias_b, float scale_g, float scale_b, float* __restrict__ E, int C) {
+    const long long n = (long long)ACE_EDGE_CODES * 2 * C;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C), gb = (int)((i / C) & 1), code = (int)(i / (2LL * C));
+    const int s = (code & 3) + 1, Bl = (code >> 2) % 19, A = ((code >> 2) / 19) % 19, o = (code >> 2) / 361;
+    double acc = 0.0;
+    if (A != Bl) {
+        const double* w = W6 + (long long)gb * 128 * 6 * C + (long long)(o * 3) * C + c;      // [gb][k][6][C]: consecutive threads, consecutive c
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {                            // hidden position d - 1: window = line labels d, d + 1, d + 2
+            const int X = d < s ? A : Bl, Y = d + 1 < s ? A : Bl, Z = d + 2 < s ? A : Bl;
+            const double* h = hv + ((long long)o * 741 + ace_edge_hv(X, Y, Z)) * 128;
+            double a = 0.0;
+            for (int k = 0; k < 128; ++k) a += w[((long long)k * 6 + d) * C] * h[k];
+            acc += a;
+        }
+    }
+    E[i] = (float)(acc * (gb ? scale_b : scale_g) + (double)(gb ? bias_b : bias_g)[c]);
+}
+hipError_t ace_edge_table(const double* W6, const double* hv, const float* bias_g, const float* bias_b, float scale_g, float scale_b, float* E, int C,
+                          hipStream_t s) {
+    const long long n = (long long)ACE_EDGE_CODES * 2 * C;
+    hipLaunchKernelGGL(ace_edge_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W6, hv, bias_g, bias_b, scale_g, scale_b, E, C);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void ace_p6table_kernel(const float* __restrict__ lut, int lut_rs, int lut_ns, int lut_bs, float lut_mul,
+                                                          float* __restrict__ p6, int B, int C) {
+    const long long n = (long long)B * 19 * 6 * 2 * C;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C), gb = (int)((i / C) & 1), k = (int)((i / (2 * C)) % 6), j = (int)((i / (12LL * C)) % 19), b = (int)(i / (12LL * C * 19));
+    const long long col = (long long)(b * lut_bs + j) * lut_ns;
+    float sacc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = k < 3 ? u * 3 + k : (k - 3) * 3 + u;        // column k: taps (dy = u - 1, dx = k - 1); row k - 3: taps (dy = k - 4, dx = u - 1)
+        const long long row = (long long)(t * 2 + gb) * C + c;
+        sacc += lut_rs == 1 ? lut[row + col] : lut[(row >> 2) * 4 * lut_rs + col + (row & 3)];
+    }
+    p6[i] = sacc * lut_mul;
+}
+hipError_t ace_p6table(const float* lut, int lut_rs, int lut_ns, int lut_bs, float lut_mul, float* p6, int B, int C, hipStream_t s) {
+    const long long n = (long long)B * 19 * 6 * 2 * C;
+    hipLaunchKernelGGL(ace_p6table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lut, lut_rs, lut_ns, lut_bs, lut_mul, p6, B, C);
     return hipGetLastError();
 }
 
@@ -380,28 +471,32 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
     uchar4 j4 = make_uchar4(255, 255, 255, 255);
     if (inimg) j4 = *reinterpret_cast<const uchar4*>(q.u5 + (long long)b * HW + pix);
     bool i0 = j4.x < 19, i1 = j4.y < 19, i2 = j4.z < 19, i3 = j4.w < 19;
+    // straight-edge pixels (u5 == 253, ace_sparse.h): modulated here as well, with the table row of their code (+ three style sums)
+    const bool edges = q.e16 != nullptr && !q.quad_only;
+    const bool e0 = edges && j4.x == ACE_EDGE, e1 = edges && j4.y == ACE_EDGE, e2 = edges && j4.z == ACE_EDGE, e3 = edges && j4.w == ACE_EDGE;
     if (q.quad_only && inimg) {          // overlap mode: the boundary conv writes every pixel of a boundary quad at the same time
         const uchar4 o4 = *reinterpret_cast<const uchar4*>(q.u5 + (long long)b * HW + (y ^ 1) * q.W + x);      // the other row of the two quads
         const bool q0 = i0 && i1 && o4.x < 19 && o4.y < 19, q1 = i2 && i3 && o4.z < 19 && o4.w < 19;
         i0 = i1 = q0;
         i2 = i3 = q1;
     }
-    const int nmine = __syncthreads_count(i0) + __syncthreads_count(i1) + __syncthreads_count(i2) + __syncthreads_count(i3);
-    if (nmine == 0) return;                                  // no interior pixel in this block
+    const bool m0 = i0 || e0, m1 = i1 || e1, m2 = i2 || e2, m3 = i3 || e3;      // pixels this pass owns
+    const int nmine = __syncthreads_count(m0) + __syncthreads_count(m1) + __syncthreads_count(m2) + __syncthreads_count(m3);
+    if (nmine == 0) return;                                  // no pixel of this pass in this block
     // What is written.  A partially written 128-byte line costs more than a whole one (masked stores: 538 vs 423 us at 77 % interior
-    // pixels, profiles/r05_interior_bench.txt), so boundary pixels next to interior ones are written too -- the boundary conv, launched
+    // pixels, profiles/r05_interior_bench.txt), so boundary pixels next to owned ones are written too -- the boundary conv, launched
     // after this pass, overwrites them.  fill_min = 0 (default since round 6): per LINE -- the eight threads of a 128-byte line write
-    // it whole if it holds an interior pixel and skip it (loads and stores) if it holds none: the all-boundary rows along the region
+    // it whole if it holds an owned pixel and skip it (loads and stores) if it holds none: the all-boundary rows along the region
     // borders, 12 / 25 / 50 % of the lines of the 512 / 256 / 128-pixel levels on the benchmark labels, are no longer written twice.
-    // fill_min > 0 (rounds 3-5): per BLOCK of 128 x 8 pixels -- all of it if it has at least 4 fill_min interior pixels, else masked.
+    // fill_min > 0 (rounds 3-5): per BLOCK of 128 x 8 pixels -- all of it if it has at least 4 fill_min owned pixels, else masked.
     bool fill;
     if (q.fill_min == 0) {
-        const unsigned long long bal = __ballot(i0 || i1 || i2 || i3);
+        const unsigned long long bal = __ballot(m0 || m1 || m2 || m3);
         fill = ((bal >> (threadIdx.x & 56)) & 0xFFull) != 0;
     } else {
         fill = nmine >= 4 * q.fill_min;
     }
-    const bool any = inimg && (fill || i0 || i1 || i2 || i3);
+    const bool any = inimg && (fill || m0 || m1 || m2 || m3);
     float nz0 = 0.f, nz1 = 0.f, nz2 = 0.f, nz3 = 0.f;
     if (any) {
         const float* np = q.noise + (long long)b * q.noise_bstride + (long long)x * q.H + y;      // plane layout [W][H]
@@ -426,8 +521,8 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
                 *g3 = gt + (i3 ? j4.w : 0) * RS;
     const int cmax = q.C - c0 < IN_CG ? q.C - c0 : IN_CG;
     const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
-    const bool all4 = fill || (i0 && i1 && i2 && i3);
-    auto channel = [&](int c) {
+    const bool all4 = fill || (m0 && m1 && m2 && m3);
+    auto load_x = [&](int c) {
         float4 xv;
         if (q.x_up) {
             const float2 t = *reinterpret_cast<const float2*>(xp + (long long)c * xHW);
@@ -435,16 +530,80 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
         } else {
             xv = *reinterpret_cast<const float4*>(xp + (long long)c * xHW);
         }
+        return xv;
+    };
+    auto finish = [&](int c, const float4& xv, const float4& gm, const float4& bt) {
         const float a = pa[c], n = pn[c], d = pd[c];
         float4 o;
-        o.x = (a * xv.x + n * nz0 + d) * (1.f + g0[c]) + g0[IN_CG + c];
-        o.y = (a * xv.y + n * nz1 + d) * (1.f + g1[c]) + g1[IN_CG + c];
-        o.z = (a * xv.z + n * nz2 + d) * (1.f + g2[c]) + g2[IN_CG + c];
-        o.w = (a * xv.w + n * nz3 + d) * (1.f + g3[c]) + g3[IN_CG + c];
+        o.x = (a * xv.x + n * nz0 + d) * (1.f + gm.x) + bt.x;
+        o.y = (a * xv.y + n * nz1 + d) * (1.f + gm.y) + bt.y;
+        o.z = (a * xv.z + n * nz2 + d) * (1.f + gm.z) + bt.z;
+        o.w = (a * xv.w + n * nz3 + d) * (1.f + gm.w) + bt.w;
         o.x = fmaxf(o.x, slope * o.x); o.y = fmaxf(o.y, slope * o.y);
         o.z = fmaxf(o.z, slope * o.z); o.w = fmaxf(o.w, slope * o.w);
         return o;
     };
+    auto channel = [&](int c) {
+        return finish(c, load_x(c), make_float4(g0[c], g1[c], g2[c], g3[c]), make_float4(g0[IN_CG + c], g1[IN_CG + c], g2[IN_CG + c], g3[IN_CG + c]));
+    };
+    if (e0 || e1 || e2 || e3) {
+        // ---- a thread with straight-edge pixels: gamma / beta of such a pixel = its code's row of the ACE's table (bias included) + the
+        //      three column (row) sums of the style LUT that its 3x3 window selects; the other pixels as below.  Rows come from L1 / L2:
+        //      the pixels along an edge share them. ----------------------------------------------------------------------------------
+        const ushort4 k4 = *reinterpret_cast<const ushort4*>(q.e16 + (long long)b * HW + pix);
+        const unsigned short kk[4] = {k4.x, k4.y, k4.z, k4.w};
+        const bool ee[4] = {e0, e1, e2, e3};
+        const float* gl[4] = {g0, g1, g2, g3};
+        unsigned eo[4], po[4][3];                            // float offsets of the gamma rows (beta: + C)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int code = ee[s] ? kk[s] : 0;
+            const int sl = (code & 3) + 1, Bl = (code >> 2) % 19, A = ((code >> 2) / 19) % 19, o = (code >> 2) / 361;
+            eo[s] = (unsigned)code * 2u * (unsigned)q.C + (unsigned)c0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int l = (1 + t < sl) ? A : Bl;            // line label 1 + t of A^s B^(5-s)
+                po[s][t] = (unsigned)(((b * 19 + l) * 6 + o * 3 + t) * 2) * (unsigned)q.C + (unsigned)c0;
+            }
+        }
+        auto edge_channel = [&](int c) {
+            float gm[4], bt[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (ee[s]) {
+                    float g = q.etab[eo[s] + c], be = q.etab[eo[s] + q.C + c];
+                    if (q.p6) {
+                        g += q.p6[po[s][0] + c] + q.p6[po[s][1] + c] + q.p6[po[s][2] + c];
+                        be += q.p6[po[s][0] + q.C + c] + q.p6[po[s][1] + q.C + c] + q.p6[po[s][2] + q.C + c];
+                    }
+                    gm[s] = g;
+                    bt[s] = be;
+                } else {
+                    gm[s] = gl[s][c];
+                    bt[s] = gl[s][IN_CG + c];
+                }
+            }
+            return finish(c, load_x(c), make_float4(gm[0], gm[1], gm[2], gm[3]), make_float4(bt[0], bt[1], bt[2], bt[3]));
+        };
+        if (all4) {
+#pragma unroll 2
+            for (int c = 0; c < cmax; ++c) {
+                const float4 o = edge_channel(c);
+                *reinterpret_cast<nt_f32x4*>(op + (long long)c * HW) = (nt_f32x4){o.x, o.y, o.z, o.w};
+            }
+        } else {
+#pragma unroll 2
+            for (int c = 0; c < cmax; ++c) {
+                const float4 o = edge_channel(c);
+                float* oc = op + (long long)c * HW;
+                if (m0) oc[0] = o.x;
+                if (m1) oc[1] = o.y;
+                if (m2) oc[2] = o.z;
+                if (m3) oc[3] = o.w;
+            }
+        }
+        return;
+    }
     // Two loops, not one loop with the choice inside: with `if (all4) 16-byte store else four masked stores` in one body hipcc
     // if-converts both arms into four predicated 4-byte stores -- the shipped kernel of rounds 4-5 never issued a global_store_dwordx4
     // (found in round 6 when an unrelated branch in the body changed the code: interior passes of a step 3.37 -> 2.75 ms).

@@ -376,6 +376,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.wino4_force = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.edge") == 0) {         // 1 = straight-edge pixels from per-code table rows in the interior pass (default), 0 = through the boundary conv
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.edge) must precede ch_finalize");
+        h->sean.edge = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.batch_invariant") == 0) {      // exact-f32 path: 1 = kernel choices independent of the batch size of a call (default 0)
         h->sean.batch_inv = value != 0;
         return CH_OK;

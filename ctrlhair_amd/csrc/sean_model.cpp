@@ -242,6 +242,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 const float w = (beta ? wbp : wgp)[((size_t)c * HID + ci) * 9 + t];
                 return w * (beta ? sb : sg);
             };
+            std::vector<double> edge_hv, edge_W6;      // straight-edge tables: host operands (filled below, contracted after the biases are final)
             {   // per-label constants of the SPADE gamma/beta for pixels with a uniform 5x5 label neighbourhood (ace_sparse.h):
                 // every tap sees a_j = relu(b_shared + sum_t' W_shared[:, j, t']), so gamma_j = (sum_t W[:, :, t]) a_j.  Double.
                 std::vector<double> aj((size_t)LABEL_NC * HID);
@@ -268,6 +269,48 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                         }
                     }
                 a.gconst = B.upload(gc);
+                // straight-edge pixels (ace_sparse.h, option sean.edge): the per-code rows E[2888][gamma|beta][C] of the ACEs that can run at
+                // 128 pixels and more (res_div <= 4), from the hidden vectors of the windows AAB / ABB (double, host) and the column / row sums
+                // of the gamma / beta weights, contracted on the device in double (ace_edge_table).  vbg / vbb (blended biases) are added.
+                a.edge_tab = nullptr;
+                if (edge && !use_sh16 && wino && s.res_div <= 4) {
+                    edge_hv.assign((size_t)2 * 741 * HID, 0.0);
+                    edge_W6.assign((size_t)2 * HID * 6 * C, 0.0);
+                    std::vector<double>&hv = edge_hv, &W6 = edge_W6;
+                    for (int o = 0; o < 2; ++o) {
+                        auto line = [&](int j, int u, int k) {       // shared conv's taps of label j summed across the split: column u (o = 0) / row u (o = 1)
+                            double v = 0.0;
+                            for (int w = 0; w < 3; ++w) v += T[((size_t)j * 9 + (o == 0 ? w * 3 + u : u * 3 + w)) * HID + k];
+                            return v;
+                        };
+                        for (int j = 0; j < LABEL_NC; ++j)
+                            for (int k = 0; k < HID; ++k) hv[((size_t)o * 741 + j) * HID + k] = aj[(size_t)j * HID + k];
+                        for (int A = 0; A < LABEL_NC; ++A)
+                            for (int Bl = 0; Bl < LABEL_NC; ++Bl) {
+                                if (A == Bl) continue;
+                                for (int k = 0; k < HID; ++k) {
+                                    const double aab = bs->f32()[k] + line(A, 0, k) + line(A, 1, k) + line(Bl, 2, k);
+                                    const double abb = bs->f32()[k] + line(A, 0, k) + line(Bl, 1, k) + line(Bl, 2, k);
+                                    hv[((size_t)o * 741 + 19 + (A * 19 + Bl) * 2 + 0) * HID + k] = aab > 0.0 ? aab : 0.0;
+                                    hv[((size_t)o * 741 + 19 + (A * 19 + Bl) * 2 + 1) * HID + k] = abb > 0.0 ? abb : 0.0;
+                                }
+                            }
+                    }
+                    for (int gb = 0; gb < 2; ++gb)
+                        for (int c = 0; c < C; ++c) {
+                            const float* w = (gb ? wbp : wgp) + (size_t)c * HID * 9;
+                            for (int k = 0; k < HID; ++k)
+                                for (int d = 0; d < 3; ++d) {
+                                    double col = 0.0, row = 0.0;
+                                    for (int u = 0; u < 3; ++u) {
+                                        col += w[k * 9 + u * 3 + d];      // taps (dy = u - 1, dx = d - 1)
+                                        row += w[k * 9 + d * 3 + u];      // taps (dy = d - 1, dx = u - 1)
+                                    }
+                                    W6[(((size_t)gb * HID + k) * 6 + d) * C + c] = col;
+                                    W6[(((size_t)gb * HID + k) * 6 + 3 + d) * C + c] = row;
+                                }
+                        }
+                }
             }
             if (use_sh16) {
                 auto kexp = sh16_row_exponents(tiles * 64, HID, 3, getsp);
@@ -352,6 +395,21 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     }
                     a.lut_rows = B.upload(rows);
                 }
+            }
+            if (!edge_hv.empty()) {      // (after the style branch's biases went into vbg / vbb: the table rows are complete gamma / beta)
+                const std::vector<double>&hv = edge_hv, &W6 = edge_W6;
+                double *dW = nullptr, *dH = nullptr;
+                float *dbg_ = B.upload(vbg), *dbb_ = B.upload(vbb);
+                a.edge_tab = B.falloc((size_t)ACE_EDGE_CODES * 2 * C);
+                if (B.err.empty() && hipMalloc(&dW, W6.size() * 8) == hipSuccess && hipMalloc(&dH, hv.size() * 8) == hipSuccess &&
+                    hipMemcpy(dW, W6.data(), W6.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                    hipMemcpy(dH, hv.data(), hv.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                    ace_edge_table(dW, dH, dbg_, dbb_, sg, sb, a.edge_tab, C, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+                } else if (B.err.empty()) {
+                    B.err = "edge table of " + p + " failed";
+                }
+                if (dW) (void)hipFree(dW);
+                if (dH) (void)hipFree(dH);
             }
             a.bn_a = B.upload(va);
             a.bn_d = B.upload(vd);
@@ -697,6 +755,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     L.TH = th;
                     L.cap_tiles = mb * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
                     L.u5 = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
+                    L.e16 = (edge && !use_sh16 && wino && r >= 128) ? static_cast<uint16_t*>(B.dalloc((size_t)mb * r * r * sizeof(uint16_t))) : nullptr;
                     L.need = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
                     L.list = static_cast<uint16_t*>(B.dalloc((size_t)L.cap_tiles * 32 * L.TH * sizeof(uint16_t)));
                     L.cnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
@@ -723,6 +782,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             }
         if (cmax) gtab = B.falloc((size_t)mb * LABEL_NC * 2 * cmax);
         if (cmax && overlap_on) gtab_side = B.falloc((size_t)mb * LABEL_NC * 2 * cmax);
+        p6 = (cmax && edge && !use_sh16 && wino) ? B.falloc((size_t)mb * LABEL_NC * 6 * 2 * cmax) : nullptr;      // (straight-edge pixels: ace_sparse.h)
     }
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "hipDeviceSynchronize failed after weight upload";
@@ -863,9 +923,18 @@ struct Runner {
                 const SparseLevel& L = m.sp_level[k][ti];
                 if (!L.u5) return nullptr;
                 const int ntiles = B * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
-                if (!lvl_done[k][ti]) {
+                if (!lvl_done[k][ti] || lvl_edges[k][ti]) {
+                    // (a level classified WITH straight-edge marks for the Winograd ACEs and then needed by the direct sparse kernels, which do not
+                    //  know them: classified again without, and the quad lists of the level with it -- not expected to happen: every ACE of a
+                    //  level takes the same route)
                     check(ace_classify(lab, L.u5, L.need, L.list, L.cnt, B, r, r, L.TH, st), "ace_classify");
                     lvl_done[k][ti] = true;
+                    if (lvl_edges[k][ti]) {
+                        lvl_edges[k][ti] = false;
+                        wq_done[k] = false;
+                        wwork_done[k].clear();
+                        work_done[k].clear();
+                    }
                 }
                 bool done = false;
                 for (int d : work_done[k]) done = done || d == mt;
@@ -878,8 +947,9 @@ struct Runner {
         return nullptr;
     }
     // Winograd ACE path: classification of the level (when the interior reduction serves it), boundary-quad lists, task list
-    struct WinoPrep { const SeanModel::WinoLevel* L = nullptr; const SeanModel::WinoWork* W = nullptr; const SparseLevel* S = nullptr; };
+    struct WinoPrep { const SeanModel::WinoLevel* L = nullptr; const SeanModel::WinoWork* W = nullptr; const SparseLevel* S = nullptr; bool edges = false; };
     bool wq_done[6] = {};
+    bool lvl_edges[6][2] = {};          // the level's interior map carries straight-edge marks (u5 == 253 + e16)
     std::vector<int> wwork_done[6];
     WinoPrep wino_prepare(const AceW& a, const uint8_t* lab, int r) {
         WinoPrep o;
@@ -897,10 +967,15 @@ struct Runner {
                 if (m.sp_level[k][ti].u5) {
                     const SparseLevel& S = m.sp_level[k][ti];
                     if (!lvl_done[k][ti]) {
-                        check(ace_classify(lab, S.u5, S.need, S.list, S.cnt, B, r, r, S.TH, st), "ace_classify");
+                        // straight-edge pixels (ace_sparse.h): marked on the levels whose interior pass knows them (128 pixels and more) when
+                        // the ACE carries its table -- every ACE of such a level does (res_div <= 4), checked in ace()
+                        const bool edges = m.edge && S.e16 && r >= 128 && a.edge_tab && (!a.styled || m.p6) && !m.overlap_on;      // (overlap mode: quad_only interior pass)
+                        check(ace_classify(lab, S.u5, S.need, S.list, S.cnt, B, r, r, S.TH, st, edges ? S.e16 : nullptr), "ace_classify");
                         lvl_done[k][ti] = true;
+                        lvl_edges[k][ti] = edges;
                     }
                     o.S = &S;
+                    o.edges = lvl_edges[k][ti];
                 }
         }
         const int ntiles = B * (r / 32) * (r / L.TH);
@@ -1259,6 +1334,12 @@ struct Runner {
                 // four pixels per thread (16-byte stores) from 128 pixels of width: 530 -> 420 us on the up-sampled 512^2 launches
                 // (tools/interior_bench.hip); level in the 100 ms step of round 3, measurable in this one
                 ip.impl = r >= 128 ? 2 : 0;
+                if (wp.edges) {         // straight-edge pixels: table row of the code + three column / row sums of the style LUT (built below)
+                    if (!a.edge_tab || r < 128) check(hipErrorInvalidValue, "straight-edge marks on a level whose ACE has no table");
+                    ip.e16 = wp.S->e16;
+                    ip.etab = a.edge_tab;
+                    ip.p6 = (a.styled && q.lut) ? m.p6 : nullptr;
+                }
                 // (tile4 kernel, r >= 128: 0 = whole 128-byte lines that hold an interior pixel, ace_sparse.hip; sean.dbg bit 134217728: the
                 //  block rule of rounds 3-5 for A/B)
                 ip.fill_min = (x_up && r < 128) ? 257 : ((r >= 128 && !(m.dbg & 134217728)) ? 0 : 128);
@@ -1276,6 +1357,7 @@ struct Runner {
                 } else {
                     timed(3, 0.0, 0.0, wp.W->total + 4, 0.0, xpp + opp + 5.0, 4.0 * 19 * 2 * a.C * B, npix, [&] {
                         check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.gtab, B, a.C, st), "ace_gtable");
+                        if (ip.p6) check(ace_p6table(q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f, m.p6, B, a.C, st), "ace_p6table");
                         check(ace_interior_f32(ip, st), "ace interior");
                     });
                 }

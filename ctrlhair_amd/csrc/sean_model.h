@@ -40,6 +40,7 @@ struct AceW {
                                                 //   shortcut's ace_s carries the 2^D aligning conv_s with conv_1, sean_model.cpp)
     float actv_scale = 1.f;                     // f16x3 path: SH16 scale of the SPADE hidden activations (from a table bound)
     float* spade_wino = nullptr;                // exact-f32 Winograd path: pack_wino_A image of the (gamma | beta) rows, 16-channel row tiles
+    float* edge_tab = nullptr;                  // sean.edge: E[2888][gamma|beta][C] of the straight-edge pixels (ace_sparse.h), ACEs with res_div <= 4
     float* spade_wino4 = nullptr;               // sean.wino = 2: the same rows as an F(4x4,3x3) image (conv_wino4.h wino4_ace_row), levels <= wino4_ace_max_r
     float* gconst = nullptr;                    // [19][gamma|beta][C]: SPADE gamma/beta of a pixel whose 5x5 label neighbourhood
                                                 //   is uniformly j (blend factor folded in, biases not) -- ace_sparse.h
@@ -158,6 +159,9 @@ struct SeanModel {
     int num_cus = 256;                         // compute units of the handle's device (build())
     int wino4_force = 0;                       // option "sean.wino4_force": 1 = F(4x4,3x3) wherever the shape allows, whatever the task count (tests)
     int wino4_ace_max_r = 64;                  // option "sean.wino4_ace": largest level whose SPADE convs run as F(4x4,3x3) over EVERY tile (0 = none)
+    int edge = 1;                              // option "sean.edge": 1 = straight-edge pixels of the levels >= 128 pixels are modulated by the interior pass from
+                                               //   per-code table rows instead of going through the boundary conv (exact-f32 Winograd path; ace_sparse.h)
+    float* p6 = nullptr;                       // per-call column / row sums of the style LUT of the ACE being run: [mb][19][6][2][C]
     int batch_inv = 0;                         // option "sean.batch_invariant": 1 = every choice that follows the number of tasks of a call (F(4x4) vs F(2x2),
                                                //   split-K, sample-pair tiles at 16 pixels, the small-batch LUT / tiny-level routes) is made as for a large
                                                //   batch: sample i alone == sample i in any batch, bit for bit (exact-f32 path)

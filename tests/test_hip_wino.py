@@ -177,6 +177,38 @@ def test_pretransformed_input_route_equals_the_in_kernel_transform(hip_lib, ngf,
         g.handle.close()
 
 
+@pytest.mark.parametrize('ngf,S,B', [(64, 256, 3), (64, 512, 2), (16, 256, 4)])
+def test_straight_edge_pixels_equal_the_boundary_conv(hip_lib, ngf, S, B):
+    """Option sean.edge (default 1; ace_sparse.h): a boundary pixel whose 5x5 label neighbourhood is five uniform columns (rows) A^s B^(5-s)
+    gets gamma / beta from the per-code row of its ACE's table (+ three column / row sums of the style LUT) in the interior pass instead of
+    from the boundary conv -- on the levels of 128 pixels and more.  The same real number in another association: images against the
+    conv evaluation of the same library (sean.edge = 0) at 1e-5 and against the direct evaluation (sean.wino = 0), on label maps with
+    straight edges (blocky), curved ones (face-like), 'no class' labels along tile borders, no straight edge at all (diag) and a single
+    region; the reduction must actually apply (fewer executed FLOPs) where straight edges exist.  normalization.py:117-153,172-187,249-257."""
+    from ctrlhair_amd import procedural as P
+    sd = P.sean_state_dict(0, ngf)
+    on, off, direct = _gen(sd, B, S, 2, {'sean.edge': 1}), _gen(sd, B, S, 2, {'sean.edge': 0}), _gen(sd, B, S, 0)
+    codes, noise = P.style_codes(B, seed=91), P.noise_planes(B, S, ngf, seed=92)
+    sets = _label_sets(B, S)
+    for name in ('blocky', 'face', 'noclass_at_tile_borders', 'diag', 'one_region'):
+        a, b, c = _run(on, sets[name], codes, noise), _run(off, sets[name], codes, noise), _run(direct, sets[name], codes, noise)
+        d, dd = float(np.abs(a - b).max()), float(np.abs(a - c).max())
+        print(f'ngf{ngf} S={S} {name}: max |edge rows - boundary conv| = {d:.3e}, |edge rows - direct| = {dd:.3e}')
+        assert np.isfinite(a).all() and d <= 1e-5 and dd <= 2e-4, (name, d, dd)
+        assert np.array_equal(a, _run(on, sets[name], codes, noise)), 'repeated call differs'
+    ex = {}
+    for g, key in ((on, 1), (off, 0)):
+        g.handle.profile_enable(True)
+        _run(g, sets['blocky'], codes, noise)
+        g.handle.profile_enable(False)
+        ex[key] = g.handle.profile_read(1)['flops_executed']
+        g.handle.profile_read(-1)
+    print(f'SPADE conv FLOPs executed on blocky labels: {ex[0]:.3e} -> {ex[1]:.3e}')
+    assert ex[1] < 0.8 * ex[0]
+    for g in (on, off, direct):
+        g.handle.close()
+
+
 @pytest.mark.parametrize('S,mb', [(64, 8), (256, 9)])
 def test_grouped_style_luts_equal_per_ace_launches(hip_lib, S, mb):
     """Exact-f32 path, more than 64 (sample, label) columns: the style LUTs of all styled ACEs from ONE grouped GEMM launch
@@ -254,7 +286,9 @@ def test_overlap_mode_equals_the_serial_schedule(hip_lib):
     from ctrlhair_amd import procedural as P
     ngf, B, S = 16, 3, 256
     sd = P.sean_state_dict(0, ngf)
-    ov, serial = _gen(sd, B, S, 1, {'sean.ahead': 0, 'sean.overlap': 64}), _gen(sd, B, S, 1, {'sean.ahead': 0, 'sean.overlap': 0})
+    # (sean.edge = 0 on the serial handle: the overlap schedule's quad-only interior pass does not take the straight-edge pixels, and the
+    #  table rows are another association of the same sums -- 1e-6, not bit-identical)
+    ov, serial = _gen(sd, B, S, 1, {'sean.ahead': 0, 'sean.overlap': 64}), _gen(sd, B, S, 1, {'sean.ahead': 0, 'sean.overlap': 0, 'sean.edge': 0})
     codes, noise = P.style_codes(B, seed=61), P.noise_planes(B, S, ngf, seed=62)
     sets = _label_sets(B, S)
     for name in ('face', 'blocky', 'one_region', 'noclass_at_tile_borders', 'diag'):
