@@ -460,8 +460,10 @@ typedef float nt_f32x4 __attribute__((ext_vector_type(4)));      // (a 16-byte s
 // Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
 // values of a thread share their 32-byte sectors with the seven other rows of the block.
 __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {
-    constexpr int RS = 2 * IN_CG + 1;
+    constexpr int RS = 2 * IN_CG + 1, ES = 64;               // ES: slots of the block's table of straight-edge rows
     __shared__ float gt[19 * RS];
+    __shared__ float et[ES * RS];
+    __shared__ int ekey[ES];
     __shared__ float pa[IN_CG], pd[IN_CG], pn[IN_CG];
     const int HW = q.H * q.W, tpr = (q.W + 127) >> 7, tpc = (q.H + 7) >> 3;
     const int b = blockIdx.x / (tpr * tpc), r = blockIdx.x - b * (tpr * tpc), tyi = r / tpr, c0 = blockIdx.y * IN_CG;
@@ -481,8 +483,33 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
         i2 = i3 = q1;
     }
     const bool m0 = i0 || e0, m1 = i1 || e1, m2 = i2 || e2, m3 = i3 || e3;      // pixels this pass owns
+    if (edges && threadIdx.x < ES) ekey[threadIdx.x] = -1;
     const int nmine = __syncthreads_count(m0) + __syncthreads_count(m1) + __syncthreads_count(m2) + __syncthreads_count(m3);
     if (nmine == 0) return;                                  // no pixel of this pass in this block
+    // straight-edge pixels: the block's distinct codes go into a 64-slot table (open addressing on the code, LDS compare-and-swap); the
+    // rows -- E[code] + the three style sums -- are then built once per block, cooperatively, and read like the interior rows.  A pixel
+    // whose code finds no slot (more than 64 distinct codes in 128 x 8 pixels: not seen) takes its row from global memory (slow path).
+    int slot[4] = {-1, -1, -1, -1};
+    unsigned short kk[4] = {0, 0, 0, 0};
+    const bool ee[4] = {e0, e1, e2, e3};
+    if (e0 || e1 || e2 || e3) {
+        const ushort4 k4 = *reinterpret_cast<const ushort4*>(q.e16 + (long long)b * HW + pix);
+        kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!ee[s]) continue;
+            const int code = kk[s];
+            unsigned h = ((unsigned)code * 2654435761u) >> 26;
+            for (int probe = 0; probe < ES; ++probe) {
+                const int old = atomicCAS(&ekey[h], -1, code);
+                if (old == -1 || old == code) {
+                    slot[s] = (int)h;
+                    break;
+                }
+                h = (h + 1) & (ES - 1);
+            }
+        }
+    }
     // What is written.  A partially written 128-byte line costs more than a whole one (masked stores: 538 vs 423 us at 77 % interior
     // pixels, profiles/r05_interior_bench.txt), so boundary pixels next to owned ones are written too -- the boundary conv, launched
     // after this pass, overwrites them.  fill_min = 0 (default since round 6): per LINE -- the eight threads of a 128-byte line write
@@ -512,13 +539,35 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
         pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
         pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
     }
+    if (edges) {
+        __syncthreads();                                     // (the slots are final)
+        for (int i = threadIdx.x; i < ES * 2 * IN_CG; i += 256) {
+            const int sl = i / (2 * IN_CG), rr = i % (2 * IN_CG), gb = rr / IN_CG, c = c0 + rr % IN_CG;
+            const int code = ekey[sl];
+            if (code < 0) continue;
+            float v = 0.f;
+            if (c < q.C) {
+                v = q.etab[((long long)code * 2 + gb) * q.C + c];
+                if (q.p6) {
+                    const int sn = (code & 3) + 1, Bl = (code >> 2) % 19, A = ((code >> 2) / 19) % 19, o = (code >> 2) / 361;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int l = (1 + t < sn) ? A : Bl;        // line label 1 + t of A^s B^(5-s)
+                        v += q.p6[((((long long)b * 19 + l) * 6 + o * 3 + t) * 2 + gb) * q.C + c];
+                    }
+                }
+            }
+            et[sl * RS + rr] = v;
+        }
+    }
     __syncthreads();
     if (!any) return;
     const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up);
     const float* __restrict__ xp = q.x + ((long long)b * q.C + c0) * xHW + (y >> q.x_up) * xW + (x >> q.x_up);
     float* __restrict__ op = reinterpret_cast<float*>(q.out) + ((long long)b * q.C + c0) * HW + pix;
-    const float *g0 = gt + (i0 ? j4.x : 0) * RS, *g1 = gt + (i1 ? j4.y : 0) * RS, *g2 = gt + (i2 ? j4.z : 0) * RS,
-                *g3 = gt + (i3 ? j4.w : 0) * RS;
+    // a pixel's gamma | beta row: the (sample, label) row of the interior pixels, the block-table row of a straight-edge pixel
+    const float *g0 = slot[0] >= 0 ? et + slot[0] * RS : gt + (i0 ? j4.x : 0) * RS, *g1 = slot[1] >= 0 ? et + slot[1] * RS : gt + (i1 ? j4.y : 0) * RS,
+                *g2 = slot[2] >= 0 ? et + slot[2] * RS : gt + (i2 ? j4.z : 0) * RS, *g3 = slot[3] >= 0 ? et + slot[3] * RS : gt + (i3 ? j4.w : 0) * RS;
     const int cmax = q.C - c0 < IN_CG ? q.C - c0 : IN_CG;
     const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
     const bool all4 = fill || (m0 && m1 && m2 && m3);
@@ -546,18 +595,15 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
     auto channel = [&](int c) {
         return finish(c, load_x(c), make_float4(g0[c], g1[c], g2[c], g3[c]), make_float4(g0[IN_CG + c], g1[IN_CG + c], g2[IN_CG + c], g3[IN_CG + c]));
     };
-    if (e0 || e1 || e2 || e3) {
-        // ---- a thread with straight-edge pixels: gamma / beta of such a pixel = its code's row of the ACE's table (bias included) + the
-        //      three column (row) sums of the style LUT that its 3x3 window selects; the other pixels as below.  Rows come from L1 / L2:
-        //      the pixels along an edge share them. ----------------------------------------------------------------------------------
-        const ushort4 k4 = *reinterpret_cast<const ushort4*>(q.e16 + (long long)b * HW + pix);
-        const unsigned short kk[4] = {k4.x, k4.y, k4.z, k4.w};
-        const bool ee[4] = {e0, e1, e2, e3};
+    const bool ov[4] = {e0 && slot[0] < 0, e1 && slot[1] < 0, e2 && slot[2] < 0, e3 && slot[3] < 0};
+    if (ov[0] || ov[1] || ov[2] || ov[3]) {
+        // ---- overflow of the block table (slow path): gamma / beta of such a pixel straight from global memory = its code's row of the
+        //      ACE's table (bias included) + the three column (row) sums of the style LUT that its 3x3 window selects ----------------
         const float* gl[4] = {g0, g1, g2, g3};
         unsigned eo[4], po[4][3];                            // float offsets of the gamma rows (beta: + C)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int code = ee[s] ? kk[s] : 0;
+            const int code = ov[s] ? kk[s] : 0;
             const int sl = (code & 3) + 1, Bl = (code >> 2) % 19, A = ((code >> 2) / 19) % 19, o = (code >> 2) / 361;
             eo[s] = (unsigned)code * 2u * (unsigned)q.C + (unsigned)c0;
 #pragma unroll
@@ -570,7 +616,7 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
             float gm[4], bt[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                if (ee[s]) {
+                if (ov[s]) {
                     float g = q.etab[eo[s] + c], be = q.etab[eo[s] + q.C + c];
                     if (q.p6) {
                         g += q.p6[po[s][0] + c] + q.p6[po[s][1] + c] + q.p6[po[s][2] + c];
