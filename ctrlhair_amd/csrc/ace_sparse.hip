@@ -459,11 +459,11 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));      // (a 16-byte store the compiler keeps whole)
 // Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
 // values of a thread share their 32-byte sectors with the seven other rows of the block.
-__global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {
+__global__ __launch_bounds__(256, 8) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {      // (8 blocks per CU: <= 64 VGPR; it is a streaming kernel)
     constexpr int RS = 2 * IN_CG + 1, ES = 64;               // ES: slots of the block's table of straight-edge rows
     __shared__ float gt[19 * RS];
     __shared__ float et[ES * RS];
-    __shared__ int ekey[ES];
+    __shared__ int ekey[ES], olist[ES], nocc;
     __shared__ float pa[IN_CG], pd[IN_CG], pn[IN_CG];
     const int HW = q.H * q.W, tpr = (q.W + 127) >> 7, tpc = (q.H + 7) >> 3;
     const int b = blockIdx.x / (tpr * tpc), r = blockIdx.x - b * (tpr * tpc), tyi = r / tpr, c0 = blockIdx.y * IN_CG;
@@ -483,33 +483,8 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
         i2 = i3 = q1;
     }
     const bool m0 = i0 || e0, m1 = i1 || e1, m2 = i2 || e2, m3 = i3 || e3;      // pixels this pass owns
-    if (edges && threadIdx.x < ES) ekey[threadIdx.x] = -1;
     const int nmine = __syncthreads_count(m0) + __syncthreads_count(m1) + __syncthreads_count(m2) + __syncthreads_count(m3);
     if (nmine == 0) return;                                  // no pixel of this pass in this block
-    // straight-edge pixels: the block's distinct codes go into a 64-slot table (open addressing on the code, LDS compare-and-swap); the
-    // rows -- E[code] + the three style sums -- are then built once per block, cooperatively, and read like the interior rows.  A pixel
-    // whose code finds no slot (more than 64 distinct codes in 128 x 8 pixels: not seen) takes its row from global memory (slow path).
-    int slot[4] = {-1, -1, -1, -1};
-    unsigned short kk[4] = {0, 0, 0, 0};
-    const bool ee[4] = {e0, e1, e2, e3};
-    if (e0 || e1 || e2 || e3) {
-        const ushort4 k4 = *reinterpret_cast<const ushort4*>(q.e16 + (long long)b * HW + pix);
-        kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (!ee[s]) continue;
-            const int code = kk[s];
-            unsigned h = ((unsigned)code * 2654435761u) >> 26;
-            for (int probe = 0; probe < ES; ++probe) {
-                const int old = atomicCAS(&ekey[h], -1, code);
-                if (old == -1 || old == code) {
-                    slot[s] = (int)h;
-                    break;
-                }
-                h = (h + 1) & (ES - 1);
-            }
-        }
-    }
     // What is written.  A partially written 128-byte line costs more than a whole one (masked stores: 538 vs 423 us at 77 % interior
     // pixels, profiles/r05_interior_bench.txt), so boundary pixels next to owned ones are written too -- the boundary conv, launched
     // after this pass, overwrites them.  fill_min = 0 (default since round 6): per LINE -- the eight threads of a 128-byte line write
@@ -539,136 +514,117 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile4_kernel(const AceIn
         pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
         pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
     }
-    if (edges) {
-        __syncthreads();                                     // (the slots are final)
-        for (int i = threadIdx.x; i < ES * 2 * IN_CG; i += 256) {
-            const int sl = i / (2 * IN_CG), rr = i % (2 * IN_CG), gb = rr / IN_CG, c = c0 + rr % IN_CG;
-            const int code = ekey[sl];
-            if (code < 0) continue;
-            float v = 0.f;
-            if (c < q.C) {
-                v = q.etab[((long long)code * 2 + gb) * q.C + c];
-                if (q.p6) {
-                    const int sn = (code & 3) + 1, Bl = (code >> 2) % 19, A = ((code >> 2) / 19) % 19, o = (code >> 2) / 361;
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const int l = (1 + t < sn) ? A : Bl;        // line label 1 + t of A^s B^(5-s)
-                        v += q.p6[((((long long)b * 19 + l) * 6 + o * 3 + t) * 2 + gb) * q.C + c];
-                    }
-                }
-            }
-            et[sl * RS + rr] = v;
-        }
-    }
-    __syncthreads();
-    if (!any) return;
     const int xW = q.W >> q.x_up, xHW = xW * (q.H >> q.x_up);
     const float* __restrict__ xp = q.x + ((long long)b * q.C + c0) * xHW + (y >> q.x_up) * xW + (x >> q.x_up);
     float* __restrict__ op = reinterpret_cast<float*>(q.out) + ((long long)b * q.C + c0) * HW + pix;
-    // a pixel's gamma | beta row: the (sample, label) row of the interior pixels, the block-table row of a straight-edge pixel
-    const float *g0 = slot[0] >= 0 ? et + slot[0] * RS : gt + (i0 ? j4.x : 0) * RS, *g1 = slot[1] >= 0 ? et + slot[1] * RS : gt + (i1 ? j4.y : 0) * RS,
-                *g2 = slot[2] >= 0 ? et + slot[2] * RS : gt + (i2 ? j4.z : 0) * RS, *g3 = slot[3] >= 0 ? et + slot[3] * RS : gt + (i3 ? j4.w : 0) * RS;
     const int cmax = q.C - c0 < IN_CG ? q.C - c0 : IN_CG;
     const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
-    const bool all4 = fill || (m0 && m1 && m2 && m3);
-    auto load_x = [&](int c) {
-        float4 xv;
-        if (q.x_up) {
-            const float2 t = *reinterpret_cast<const float2*>(xp + (long long)c * xHW);
-            xv = make_float4(t.x, t.x, t.y, t.y);
-        } else {
-            xv = *reinterpret_cast<const float4*>(xp + (long long)c * xHW);
-        }
-        return xv;
-    };
-    auto finish = [&](int c, const float4& xv, const float4& gm, const float4& bt) {
-        const float a = pa[c], n = pn[c], d = pd[c];
-        float4 o;
-        o.x = (a * xv.x + n * nz0 + d) * (1.f + gm.x) + bt.x;
-        o.y = (a * xv.y + n * nz1 + d) * (1.f + gm.y) + bt.y;
-        o.z = (a * xv.z + n * nz2 + d) * (1.f + gm.z) + bt.z;
-        o.w = (a * xv.w + n * nz3 + d) * (1.f + gm.w) + bt.w;
-        o.x = fmaxf(o.x, slope * o.x); o.y = fmaxf(o.y, slope * o.y);
-        o.z = fmaxf(o.z, slope * o.z); o.w = fmaxf(o.w, slope * o.w);
-        return o;
-    };
-    auto channel = [&](int c) {
-        return finish(c, load_x(c), make_float4(g0[c], g1[c], g2[c], g3[c]), make_float4(g0[IN_CG + c], g1[IN_CG + c], g2[IN_CG + c], g3[IN_CG + c]));
-    };
-    const bool ov[4] = {e0 && slot[0] < 0, e1 && slot[1] < 0, e2 && slot[2] < 0, e3 && slot[3] < 0};
-    if (ov[0] || ov[1] || ov[2] || ov[3]) {
-        // ---- overflow of the block table (slow path): gamma / beta of such a pixel straight from global memory = its code's row of the
-        //      ACE's table (bias included) + the three column (row) sums of the style LUT that its 3x3 window selects ----------------
-        const float* gl[4] = {g0, g1, g2, g3};
-        unsigned eo[4], po[4][3];                            // float offsets of the gamma rows (beta: + C)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int code = ov[s] ? kk[s] : 0;
-            const int sl = (code & 3) + 1, Bl = (code >> 2) % 19, A = ((code >> 2) / 19) % 19, o = (code >> 2) / 361;
-            eo[s] = (unsigned)code * 2u * (unsigned)q.C + (unsigned)c0;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int l = (1 + t < sl) ? A : Bl;            // line label 1 + t of A^s B^(5-s)
-                po[s][t] = (unsigned)(((b * 19 + l) * 6 + o * 3 + t) * 2) * (unsigned)q.C + (unsigned)c0;
-            }
-        }
-        auto edge_channel = [&](int c) {
-            float gm[4], bt[4];
+    // Straight-edge pixels: the block's distinct codes go into a 64-slot table (open addressing on the code, LDS compare-and-swap); the
+    // rows -- E[code] + the three style sums -- are built once per block, cooperatively, and read like the interior rows.  Codes that
+    // find no slot (more than 64 distinct ones in 128 x 8 pixels: not seen on any label map of the tests) wait for another ROUND of the
+    // same code with a fresh table; a later round stores its pixels one by one.  pend: the edge pixels without a row yet.
+    unsigned short kk[4] = {0, 0, 0, 0};
+    bool pend[4] = {e0, e1, e2, e3};
+    if (e0 || e1 || e2 || e3) {
+        const ushort4 k4 = *reinterpret_cast<const ushort4*>(q.e16 + (long long)b * HW + pix);
+        kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
+    }
+    for (bool first = true;; first = false) {
+        int slot[4] = {-1, -1, -1, -1};
+        if (edges) {
+            if (threadIdx.x < ES) ekey[threadIdx.x] = -1;
+            __syncthreads();
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                if (ov[s]) {
-                    float g = q.etab[eo[s] + c], be = q.etab[eo[s] + q.C + c];
-                    if (q.p6) {
-                        g += q.p6[po[s][0] + c] + q.p6[po[s][1] + c] + q.p6[po[s][2] + c];
-                        be += q.p6[po[s][0] + q.C + c] + q.p6[po[s][1] + q.C + c] + q.p6[po[s][2] + q.C + c];
+                if (!pend[s]) continue;
+                const int code = kk[s];
+                unsigned h = ((unsigned)code * 2654435761u) >> 26;
+                for (int probe = 0; probe < ES; ++probe) {
+                    const int old = atomicCAS(&ekey[h], -1, code);
+                    if (old == -1 || old == code) {
+                        slot[s] = (int)h;
+                        pend[s] = false;
+                        break;
                     }
-                    gm[s] = g;
-                    bt[s] = be;
-                } else {
-                    gm[s] = gl[s][c];
-                    bt[s] = gl[s][IN_CG + c];
+                    h = (h + 1) & (ES - 1);
                 }
             }
-            return finish(c, load_x(c), make_float4(gm[0], gm[1], gm[2], gm[3]), make_float4(bt[0], bt[1], bt[2], bt[3]));
-        };
-        if (all4) {
-#pragma unroll 2
-            for (int c = 0; c < cmax; ++c) {
-                const float4 o = edge_channel(c);
-                *reinterpret_cast<nt_f32x4*>(op + (long long)c * HW) = (nt_f32x4){o.x, o.y, o.z, o.w};
+            __syncthreads();                                 // (the slots are final)
+            if (threadIdx.x < ES) {                          // the occupied slots, compacted (most blocks hold 0 ... 20 codes)
+                const bool occ = ekey[threadIdx.x] >= 0;
+                const unsigned long long om = __ballot(occ);
+                if (occ) olist[__popcll(om & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+                if (threadIdx.x == 0) nocc = __popcll(om);
             }
-        } else {
-#pragma unroll 2
-            for (int c = 0; c < cmax; ++c) {
-                const float4 o = edge_channel(c);
-                float* oc = op + (long long)c * HW;
-                if (m0) oc[0] = o.x;
-                if (m1) oc[1] = o.y;
-                if (m2) oc[2] = o.z;
-                if (m3) oc[3] = o.w;
+            __syncthreads();
+            const int ne = nocc * 2 * IN_CG;
+            for (int i = threadIdx.x; i < ne; i += 256) {
+                const int sl = olist[i / (2 * IN_CG)], rr = i % (2 * IN_CG), gb = rr / IN_CG, c = c0 + rr % IN_CG;
+                const int code = ekey[sl];
+                float v = 0.f;
+                if (c < q.C) {
+                    v = q.etab[((long long)code * 2 + gb) * q.C + c];
+                    if (q.p6) {
+                        const int sn = (code & 3) + 1, Bl = (code >> 2) % 19, A = ((code >> 2) / 19) % 19, o = (code >> 2) / 361;
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            const int l = (1 + t < sn) ? A : Bl;        // line label 1 + t of A^s B^(5-s)
+                            v += q.p6[((((long long)b * 19 + l) * 6 + o * 3 + t) * 2 + gb) * q.C + c];
+                        }
+                    }
+                }
+                et[sl * RS + rr] = v;
             }
         }
-        return;
-    }
-    // Two loops, not one loop with the choice inside: with `if (all4) 16-byte store else four masked stores` in one body hipcc
-    // if-converts both arms into four predicated 4-byte stores -- the shipped kernel of rounds 4-5 never issued a global_store_dwordx4
-    // (found in round 6 when an unrelated branch in the body changed the code: interior passes of a step 3.37 -> 2.75 ms).
-    if (all4) {
+        __syncthreads();
+        // this round's pixels: the first round takes the interior pixels, the edge pixels that found a slot and (fill) the line's others
+        const bool w0 = first ? (i0 || slot[0] >= 0) : slot[0] >= 0, w1 = first ? (i1 || slot[1] >= 0) : slot[1] >= 0,
+                   w2 = first ? (i2 || slot[2] >= 0) : slot[2] >= 0, w3 = first ? (i3 || slot[3] >= 0) : slot[3] >= 0;
+        if (first ? any : (w0 || w1 || w2 || w3)) {
+            // a pixel's gamma | beta row: the (sample, label) row of an interior pixel, the block-table row of a straight-edge pixel
+            const float *g0 = slot[0] >= 0 ? et + slot[0] * RS : gt + (i0 ? j4.x : 0) * RS, *g1 = slot[1] >= 0 ? et + slot[1] * RS : gt + (i1 ? j4.y : 0) * RS,
+                        *g2 = slot[2] >= 0 ? et + slot[2] * RS : gt + (i2 ? j4.z : 0) * RS, *g3 = slot[3] >= 0 ? et + slot[3] * RS : gt + (i3 ? j4.w : 0) * RS;
+            auto channel = [&](int c) {
+                float4 xv;
+                if (q.x_up) {
+                    const float2 t = *reinterpret_cast<const float2*>(xp + (long long)c * xHW);
+                    xv = make_float4(t.x, t.x, t.y, t.y);
+                } else {
+                    xv = *reinterpret_cast<const float4*>(xp + (long long)c * xHW);
+                }
+                const float a = pa[c], n = pn[c], d = pd[c];
+                float4 o;
+                o.x = (a * xv.x + n * nz0 + d) * (1.f + g0[c]) + g0[IN_CG + c];
+                o.y = (a * xv.y + n * nz1 + d) * (1.f + g1[c]) + g1[IN_CG + c];
+                o.z = (a * xv.z + n * nz2 + d) * (1.f + g2[c]) + g2[IN_CG + c];
+                o.w = (a * xv.w + n * nz3 + d) * (1.f + g3[c]) + g3[IN_CG + c];
+                o.x = fmaxf(o.x, slope * o.x); o.y = fmaxf(o.y, slope * o.y);
+                o.z = fmaxf(o.z, slope * o.z); o.w = fmaxf(o.w, slope * o.w);
+                return o;
+            };
+            // Two loops, not one loop with the choice inside: with `if (all4) 16-byte store else four masked stores` in one body hipcc
+            // if-converts both arms into four predicated 4-byte stores -- the shipped kernel of rounds 4-5 never issued a
+            // global_store_dwordx4 (found in round 6 when an unrelated branch in the body changed the code: 3.37 -> 2.75 ms per step).
+            if (first && (fill || (w0 && w1 && w2 && w3))) {
 #pragma unroll 4
-        for (int c = 0; c < cmax; ++c) {
-            const float4 o = channel(c);
-            *reinterpret_cast<nt_f32x4*>(op + (long long)c * HW) = (nt_f32x4){o.x, o.y, o.z, o.w};
-        }
-    } else {
+                for (int c = 0; c < cmax; ++c) {
+                    const float4 o = channel(c);
+                    *reinterpret_cast<nt_f32x4*>(op + (long long)c * HW) = (nt_f32x4){o.x, o.y, o.z, o.w};
+                }
+            } else {
 #pragma unroll 4
-        for (int c = 0; c < cmax; ++c) {
-            const float4 o = channel(c);
-            float* oc = op + (long long)c * HW;
-            if (i0) oc[0] = o.x;
-            if (i1) oc[1] = o.y;
-            if (i2) oc[2] = o.z;
-            if (i3) oc[3] = o.w;
+                for (int c = 0; c < cmax; ++c) {
+                    const float4 o = channel(c);
+                    float* oc = op + (long long)c * HW;
+                    if (w0) oc[0] = o.x;
+                    if (w1) oc[1] = o.y;
+                    if (w2) oc[2] = o.z;
+                    if (w3) oc[3] = o.w;
+                }
+            }
         }
+        if (!edges) break;
+        if (!__syncthreads_or(pend[0] || pend[1] || pend[2] || pend[3])) break;      // (block-uniform; also orders this round's table reads before the next clear)
     }
 }
 
