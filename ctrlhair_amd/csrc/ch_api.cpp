@@ -376,6 +376,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.wino4_force = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.patch") == 0) {        // 1 = pre-gathered hidden-activation patches for levels with few boundary quads (default), 0 = planes only
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.patch) must precede ch_finalize");
+        h->sean.patch = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.edge") == 0) {         // 1 = straight-edge pixels from per-code table rows in the interior pass (default), 0 = through the boundary conv
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.edge) must precede ch_finalize");
         h->sean.edge = value != 0;

@@ -595,6 +595,15 @@ struct WinoAceParams {
     const int* gq_n;        // [B] quads per sample
     int gq_cap;             // work entries in this mode: sample | chunk of 64 quads << 5 | row pair << 16
     unsigned* claim;        // gather mode: eight zeroed counters (dynamic task claiming, above) or null (static split)
+    // gather mode, PATCH source (round 6): when a level is left with few boundary quads (straight-edge reduction, ace_sparse.h) their 4 x 4
+    // patches are scattered 16-byte pieces of the hidden planes -- every piece pulls a whole 128-byte line through L1: the gather becomes
+    // L1-fill bound at a quarter of its matrix rate.  spade_hidden_patch (sean_kernels.hip) then writes the patches of every chunk of 64
+    // quads directly, in the stage layout [k-step][channel 4][patch row 4][slot 64][4 floats] (16 KB per k-step, contiguous), and the
+    // patch DMA of a task becomes a flat copy.  chunk_base[b] = first chunk of sample b (chunk_base[B] = all), *patch_mode = 1 when the
+    // level's chunks fit the buffer (decided on the device: wino_chunk_base); the same arithmetic on the same values: bit-identical.
+    const float* patch;     // patch buffer, or null
+    const int* chunk_base;  // [B + 1]
+    const int* patch_mode;  // device flag
     int nrt, ntx, nty, K;   // set by the launcher
 };
 // Tile height 32 (16 x 16 quads) or 16 (16 x 8 quads), chosen per resolution level by the caller: a sparse tile must hold enough
@@ -974,7 +983,8 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
     const unsigned va = (unsigned)tid * 16u;
     wino_u32x4 d_in, d_h0, d_h1, d_s0, d_s1, dA0, dA1;
     unsigned so_in = 0, so_a = 0;
-    const unsigned APL4 = (unsigned)APL * 4u;
+    const bool from_patch = p.patch != nullptr && p.patch_mode != nullptr && __builtin_amdgcn_readfirstlane(*p.patch_mode) == 1;
+    const unsigned APL4 = from_patch ? 4096u : (unsigned)APL * 4u;      // bytes from one channel's patch rows to the next one's
     auto task_quad = [&](int t, int slot) {                       // entry `slot` of task t's chunk (clamped to the sample's list)
         const unsigned wk = p.work[t];
         const int b = wk & 31, chunk = (wk >> 5) & 2047;
@@ -987,9 +997,15 @@ __global__ __launch_bounds__(512, 1) void wino_ace_gather_kernel(const WinoAcePa
         const unsigned wk = p.work[t];
         const int ib = wk & 31, pair = wk >> 16;
         const int y = (int)(q >> 16) - 1 + irow, x = (int)(q & 0xFFFFu);      // (x - 1 + WINO_AXOFF: always inside the padded row)
-        vb = (unsigned)y < (unsigned)p.H ? (unsigned)(y * AP + x + WINO_AXOFF - 1) * 4u : 0x80000000u;
         const int r0 = 2 * pair, r1 = 2 * pair + 1 < p.nrt ? 2 * pair + 1 : 2 * pair;      // (odd row-tile count: the last pair repeats)
-        d_in = wino_rsrc(p.actv + (long long)ib * p.K * APL, (unsigned)p.K * APL * 4u);
+        if (from_patch) {        // the chunk's pre-gathered patches: channel c of k-step s at (4 s + c) * 4 KB, row irow, this lane's slot
+            const int chunk = (wk >> 5) & 2047;
+            vb = (unsigned)irow * 1024u + (unsigned)lane * 16u;
+            d_in = wino_rsrc(p.patch + (long long)(p.chunk_base[ib] + chunk) * p.K * 1024, (unsigned)p.K * 4096u);
+        } else {
+            vb = (unsigned)y < (unsigned)p.H ? (unsigned)(y * AP + x + WINO_AXOFF - 1) * 4u : 0x80000000u;
+            d_in = wino_rsrc(p.actv + (long long)ib * p.K * APL, (unsigned)p.K * APL * 4u);
+        }
         d_h0 = wino_rsrc(p.wpk + (long long)r0 * nks * 2048, (unsigned)nks * 8192u);
         d_h1 = wino_rsrc(p.wpk + (long long)r1 * nks * 2048, (unsigned)nks * 8192u);
         if (p.wsty) {

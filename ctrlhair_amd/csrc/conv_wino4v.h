@@ -245,6 +245,10 @@ __global__ __launch_bounds__(512, 1) void wino4v_kernel(const std::conditional_t
         if constexpr (W4V_CARRY) a8[1] = (f32x4){0.f, 0.f, 0.f, 0.f};       // (k-step 0 loads the quad of k-step 1 itself)
         else issue_direct(a8[1]);
         issue_tail();
+        // W4V_CARRY: the second k-step of the prologue is seven loads, not eight -- the counted wait at the top of k-step 0 would let the LAST
+        // load of stage 0 (V round 4: fragments 5..8 of tile group 3) stay in flight while the k-step reads it.  Once per block: wait for it here.
+        // (Found as a one-in-ten-runs difference between this route and the in-kernel transform; both k-steps counted eight before the carry.)
+        if constexpr (W4V_CARRY) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     }
     unsigned rslot = lds0;
     auto mfma4 = [&](const f32x4& a, const f32x4& b, int g) {

@@ -26,7 +26,12 @@ hipError_t ace_finish_f32(const float* gb, int rowsP, const float* x, int x_up, 
                           const float* bn_d, const float* nv, const float* noise, long long noise_bstride, const uint8_t* lab, const float* lut,
                           float* out, int B, int C, int H, int W, int act, hipStream_t s);
 hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* table, const float* bias, float* out, int B, int H, int W,
-                           int kout, int onehot, hipStream_t s, int pitch = 0, int xoff = 0);
+                           int kout, int onehot, hipStream_t s, int pitch = 0, int xoff = 0, const int* skip_if_patch = nullptr);
+// the same activations as pre-gathered 4 x 4 patches of the boundary quads, chunk by chunk of 64 (conv_wino.h WinoAceParams::patch); both
+// kernels read the device flag *mode (wino_chunk_base): exactly one of them does the work
+hipError_t spade_hidden_patch(const uint8_t* lab, const unsigned* gq, const int* gq_n, int gq_cap, const int* chunk_base, const int* mode,
+                              const float* table, const float* bias, float* patch, int B, int H, int W, int kout, hipStream_t s);
+hipError_t wino_chunk_base(const int* gq_n, int B, int cap_chunks, int* chunk_base, int* mode, hipStream_t s);
 // `scale`: power-of-two scale of an SH16 output / input tensor (sh16.h)
 hipError_t onehot_conv3x3_sh16(const uint8_t* lab, const float* table, const float* bias, void* out, int B, int H, int W,
                                int K, int relu, float scale, hipStream_t s, int bf16 = 0, const uint8_t* need = nullptr,

@@ -224,8 +224,10 @@ __global__ __launch_bounds__(1024) void spade_hidden_wq_kernel(const uint8_t* __
                                                                const float* __restrict__ table, const float* __restrict__ bias,
                                                                float* __restrict__ out, int B, int H, int W, int kout, int onehot,
                                                                int tcs,        // tcs = log2(TC)
-                                                               int pitch, int xoff) {      // output planes: H rows of `pitch` floats, image column x at x + xoff
+                                                               int pitch, int xoff,        // output planes: H rows of `pitch` floats, image column x at x + xoff
+                                                               const int* __restrict__ skip_if_patch) {      // device flag: 1 = spade_hidden_patch serves this level
     using namespace hid;
+    if (skip_if_patch && *skip_if_patch == 1) return;
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     float* T = hsm;
     float* A = T + T_FLOATS;
@@ -379,7 +381,7 @@ bool spade_hidden_wq_supported(int H, int W) {
 }
 
 hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* table, const float* bias, float* out, int B, int H, int W,
-                           int kout, int onehot, hipStream_t s, int pitch, int xoff) {
+                           int kout, int onehot, hipStream_t s, int pitch, int xoff, const int* skip_if_patch) {
     if (!spade_hidden_wq_supported(H, W) || kout < hid::K + (onehot ? 20 : 0)) return hipErrorInvalidValue;
     if (pitch <= 0) { pitch = W; xoff = 0; }
     if (xoff < 0 || (xoff > 0 && pitch < W + xoff + 1)) return hipErrorInvalidValue;
@@ -402,7 +404,108 @@ hipError_t spade_hidden_wq(const uint8_t* lab, const uint8_t* u5, const float* t
     const int ntasks = B * (H * W / 1024);
     const int grid = ntasks < cus[dev] ? ntasks : cus[dev];
     hipLaunchKernelGGL(spade_hidden_wq_kernel, dim3(grid), dim3(1024), hid::LDS_BYTES, s, lab, u5, table, bias, out, B, H, W, kout, onehot, tcs,
-                       pitch, xoff);
+                       pitch, xoff, skip_if_patch);
+    return hipGetLastError();
+}
+
+// ---- the same hidden activations as pre-gathered PATCHES of the boundary quads (conv_wino.h WinoAceParams::patch) ---------------------------
+// For levels that the straight-edge reduction leaves with few, scattered boundary quads.  Block = one chunk of 64 consecutive quads of a
+// sample's list (clamped like the gather kernel's task_quad), thread = (patch row py, slot, patch column px): its pixel's 128 hidden
+// channels (bias + nine table rows in tap order + ReLU: the arithmetic of spade_hidden_wq_kernel, bit for bit) and, for a styled ACE, the
+// 20 one-hot planes -- written as [channel][py][slot][px]: 256 consecutive threads store one contiguous KB.  A pixel outside the image
+// is zero in every channel (the zero padding of the gamma / beta conv).  Runs only when *mode == 1 (wino_chunk_base).
+__global__ __launch_bounds__(1024) void spade_hidden_patch_kernel(const uint8_t* __restrict__ lab, const unsigned* __restrict__ gq, const int* __restrict__ gq_n,
+                                                                  int gq_cap, const int* __restrict__ chunk_base, const int* __restrict__ mode,
+                                                                  const float* __restrict__ table, const float* __restrict__ bias, float* __restrict__ patch,
+                                                                  int B, int H, int W, int kout) {
+    using namespace hid;
+    if (*mode != 1) return;
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    float* T = hsm;
+    float* bs = T + T_FLOATS;
+    __shared__ int cb[34];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (ZROW + 1) * K; i += 1024) {
+        const int jt = i / K, kk = i % K;
+        T[jt * RS + kk] = jt < ZROW ? table[(long long)jt * K + kk] : 0.f;
+    }
+    if (tid < K) bs[tid] = bias[tid];
+    if (tid <= B) cb[tid] = chunk_base[tid];
+    __syncthreads();
+    const int py = tid >> 8, slot = (tid >> 2) & 63, px = tid & 3;
+    const int total = cb[B];
+    const long long HW = (long long)H * W;
+    for (int g = blockIdx.x; g < total; g += gridDim.x) {
+        int b = 0;
+        while (b + 1 < B && cb[b + 1] <= g) ++b;
+        const int chunk = g - cb[b], nq = gq_n[b];
+        int qi = chunk * 64 + slot;
+        qi = qi < nq ? qi : nq - 1;
+        const unsigned q = gq[(long long)b * gq_cap + qi];
+        const int Y = (int)(q >> 16) - 1 + py, X = (int)(q & 0xFFFFu) - 1 + px;
+        const bool in = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        const uint8_t* lb = lab + (long long)b * HW;
+        int jt[9], jc = 255;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = Y + t / 3 - 1, xx = X + t % 3 - 1;
+            const int j = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? lb[(long long)yy * W + xx] : 255;
+            if (t == 4) jc = j;
+            jt[t] = (j < 19 ? j * 9 + t : ZROW) * RS;
+        }
+        float* op = patch + (long long)g * kout * 1024 + (py * 64 + slot) * 4 + px;        // channel c at + c * 1024
+#pragma unroll 2
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            float4 a = *reinterpret_cast<const float4*>(bs + k0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4 r = *reinterpret_cast<const float4*>(T + jt[t] + k0);
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            }
+            a.x = (in && a.x > 0.f) ? a.x : 0.f; a.y = (in && a.y > 0.f) ? a.y : 0.f;
+            a.z = (in && a.z > 0.f) ? a.z : 0.f; a.w = (in && a.w > 0.f) ? a.w : 0.f;
+            op[0] = a.x; op[1024] = a.y; op[2048] = a.z; op[3072] = a.w;
+            op += 4096;
+        }
+        if (kout > K) {
+#pragma unroll
+            for (int j = 0; j < 20; ++j) op[j * 1024] = (in && j == jc && jc < 19) ? 1.f : 0.f;      // (plane K + 19 stays zero)
+        }
+    }
+}
+hipError_t spade_hidden_patch(const uint8_t* lab, const unsigned* gq, const int* gq_n, int gq_cap, const int* chunk_base, const int* mode,
+                              const float* table, const float* bias, float* patch, int B, int H, int W, int kout, hipStream_t s) {
+    if (B < 1 || B > 32 || (kout != hid::K && kout != hid::K + 20)) return hipErrorInvalidValue;
+    static bool done[64] = {};
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    constexpr int LDS = (hid::T_FLOATS + hid::K) * 4;
+    if (!done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spade_hidden_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(spade_hidden_patch_kernel, dim3(cus[dev]), dim3(1024), LDS, s, lab, gq, gq_n, gq_cap, chunk_base, mode, table, bias, patch, B, H, W,
+                       kout);
+    return hipGetLastError();
+}
+// chunk_base[b] = chunks of 64 quads of the samples before b (chunk_base[B]: all); *mode = 1 when they fit `cap_chunks` (and there are any)
+__global__ void wino_chunk_base_kernel(const int* __restrict__ gq_n, int B, int cap_chunks, int* __restrict__ chunk_base, int* __restrict__ mode) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int o = 0;
+    for (int b = 0; b < B; ++b) {
+        chunk_base[b] = o;
+        o += (gq_n[b] + 63) >> 6;
+    }
+    chunk_base[B] = o;
+    *mode = (o > 0 && o <= cap_chunks) ? 1 : 0;
+}
+hipError_t wino_chunk_base(const int* gq_n, int B, int cap_chunks, int* chunk_base, int* mode, hipStream_t s) {
+    hipLaunchKernelGGL(wino_chunk_base_kernel, dim3(1), dim3(64), 0, s, gq_n, B, cap_chunks, chunk_base, mode);
     return hipGetLastError();
 }
 

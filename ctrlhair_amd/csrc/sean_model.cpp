@@ -683,6 +683,8 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                         L.gq = static_cast<unsigned*>(B.dalloc((size_t)mb * L.gq_cap * sizeof(unsigned)));
                         L.gq_n = static_cast<int*>(B.dalloc(32 * sizeof(int)));
                         L.qoff = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
+                        L.chunk_base = static_cast<int*>(B.dalloc(34 * sizeof(int)));
+                        L.patch_mode = static_cast<int*>(B.dalloc(sizeof(int)));
                     }
                 }
                 const int nrt = (a->C + 15) / 16;
@@ -700,6 +702,14 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 if (a->styled && a->spade_wino4) wsty4_max = std::max(wsty4_max, (size_t)mb * nrt * 6 * wino4::ADW);
             }
         if (wsty_max) wsty = B.falloc(wsty_max);
+        // patch source of the gather kernel (conv_wino.h): up to 32 chunks of 64 boundary quads per sample (3 % of the quads of a 512^2
+        // level) x 148 channels x 4 KB -- what the straight-edge reduction leaves on label maps with straight region borders
+        patchbuf = nullptr;
+        patch_cap_chunks = 0;
+        if (patch && wino_gather && mb <= 32) {
+            patch_cap_chunks = 32 * mb;
+            patchbuf = B.falloc((size_t)patch_cap_chunks * (HID + 20) * 1024);
+        }
         if (wsty4_max) wsty4 = B.falloc(wsty4_max);
         // pre-transformed-input route (conv_wino4v.h): one V image, sized for the largest layer that takes it at (mb, ms)
         vbuf = nullptr;
@@ -982,6 +992,7 @@ struct Runner {
         if (!wq_done[k]) {
             check(wino_quad_lists(o.S ? o.S->u5 : nullptr, L.qlist, L.qcnt, L.pcnt, B, r, r, L.TH, st), "wino_quad_lists");
             if (L.gq) check(wino_gather_lists(L.qlist, L.qcnt, L.qoff, L.gq, L.gq_n, L.gq_cap, B, r, r, st), "wino_gather_lists");
+            if (L.gq && L.chunk_base) check(wino_chunk_base(L.gq_n, B, m.patchbuf ? m.patch_cap_chunks : 0, L.chunk_base, L.patch_mode, st), "wino_chunk_base");
             wq_done[k] = true;
         }
         bool done = false;
@@ -1052,7 +1063,7 @@ struct Runner {
     }
     AcePrep ace_prepare(const AceW& a, const uint8_t* labfull, const float* codes, hipStream_t s, float* actv_buf, float* lut_buf,
                         float* splitk, bool prof, int what = 3, const uint8_t* need = nullptr, const int* tile_cnt = nullptr,
-                        const uint8_t* u5 = nullptr) {
+                        const uint8_t* u5 = nullptr, const SeanModel::WinoLevel* PL = nullptr) {      // PL: the level, when its patch source may serve this ACE
         const int r = S / a.res_div;
         const uint8_t* lab = labels_at(labfull, a.res_div);
         AcePrep q;
@@ -1145,8 +1156,12 @@ struct Runner {
                 check(hipMemsetAsync(actv_buf, 0, (size_t)m.max_batch * kout * r * wino_apitch(r) * sizeof(float), s), "hidden activations: zero pads");
                 m.pad_state[actv_buf] = geo;
             }
+            const bool pm = PL && PL->gq && PL->patch_mode && m.patchbuf;
             check(spade_hidden_wq(lab, m.hidden_wq ? u5 : nullptr, a.actv_table, a.actv_bias, actv_buf, B, r, r, kout, a.styled ? 1 : 0, s,
-                                  wino_apitch(r), WINO_AXOFF), "mlp_shared (boundary-quad patches)");
+                                  wino_apitch(r), WINO_AXOFF, pm ? PL->patch_mode : nullptr), "mlp_shared (boundary-quad patches)");
+            // few, scattered boundary quads: their patches pre-gathered instead (one of the two kernels returns at once: device flag)
+            if (pm) check(spade_hidden_patch(lab, PL->gq, PL->gq_n, PL->gq_cap, PL->chunk_base, PL->patch_mode, a.actv_table, a.actv_bias, m.patchbuf,
+                                             B, r, r, kout, s), "mlp_shared (pre-gathered patches)");
         } else
             check(onehot_conv3x3(lab, a.actv_table, a.actv_bias, actv_buf, B, r, r, HID, 1, s, 0, need), "mlp_shared");
         return q;
@@ -1243,6 +1258,8 @@ struct Runner {
         const int* tile_cnt = (SL && m.use_sh16 && !compact) ? SL->cnt : nullptr;
         AcePrep q;
         const uint8_t* u5 = (wino_ace && wp.L && wp.S) ? wp.S->u5 : nullptr;      // (F(4x4,3x3) levels: every pixel is read)
+        // the level whose pre-gathered patches may serve this ACE (gather mode, not run-ahead: the ahead buffers are per ACE)
+        const SeanModel::WinoLevel* patch_level = (wino_ace && !f4_ace && wp.L && wp.L->gq && !ahead && m.patchbuf && !overlap) ? wp.L : nullptr;
         float* abuf = m.actv;                      // hidden activations: the Winograd ACE levels own padded buffers (pads zeroed once per size)
         if (wino_ace) {
             int lk = 0;
@@ -1253,16 +1270,16 @@ struct Runner {
             q = prepared[a.index];
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else if (luts_ready && a.styled) {
-            (void)ace_prepare(a, labfull, codes, st, abuf, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
+            (void)ace_prepare(a, labfull, codes, st, abuf, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5, patch_level);     // label table inline
             q = prepared[a.index];
             q.actv = abuf;
         } else if (ahead_luts && a.styled) {
-            (void)ace_prepare(a, labfull, codes, st, abuf, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5);     // label table inline
+            (void)ace_prepare(a, labfull, codes, st, abuf, nullptr, m.splitk_ws, true, 2, need, tile_cnt, u5, patch_level);     // label table inline
             q = prepared[a.index];
             q.actv = abuf;
             check(hipStreamWaitEvent(st, m.ev_join[a.index], 0), "join wait");
         } else {
-            q = ace_prepare(a, labfull, codes, st, abuf, m.lut, m.splitk_ws, true, 3, need, tile_cnt, u5);
+            q = ace_prepare(a, labfull, codes, st, abuf, m.lut, m.splitk_ws, true, 3, need, tile_cnt, u5, patch_level);
         }
         if (f4_ace) {
             Wino4AceParams w{};
@@ -1381,6 +1398,9 @@ struct Runner {
             w.nv = a.nv;
             w.noise = noise + noff;
             w.noise_bstride = (long long)nf;
+            w.patch = patch_level ? m.patchbuf : nullptr;
+            w.chunk_base = wp.L->chunk_base;
+            w.patch_mode = wp.L->patch_mode;
             w.qlist = wp.L->qlist;
             w.TH = wp.L->TH;
             w.qcnt = wp.L->qcnt;

@@ -129,7 +129,12 @@ struct SeanModel {
         uint8_t* qlist = nullptr; int* qcnt = nullptr; int* pcnt = nullptr; int cap_tiles = 0, TH = 16; std::vector<WinoWork> works;
         // gather mode (conv_wino.h): one list of boundary quads per sample, tasks of 64 consecutive entries
         unsigned* gq = nullptr; int* gq_n = nullptr; int* qoff = nullptr; int gq_cap = 0;
+        int* chunk_base = nullptr;        // [33] first chunk of 64 quads of every sample (patch source of the gather kernel, conv_wino.h)
+        int* patch_mode = nullptr;        // device flag: 1 = this chunk's patches come pre-gathered from SeanModel::patchbuf
     };
+    float* patchbuf = nullptr;                 // pre-gathered hidden-activation patches of the ACE being run (few, scattered boundary quads)
+    int patch_cap_chunks = 0;
+    int patch = 1;                             // option "sean.patch": 0 = the gather kernel always fetches from the hidden planes
     // Overlap mode (round 5; option "sean.overlap" = CUs of the side streams, 0 = off; exact-f32 Winograd path, jobs beyond the
     // run-ahead sizes): the HBM-bound kernels -- label tables of all ACEs, interior passes -- run on streams whose CU mask holds
     // `overlap` CUs (hipExtStreamCreateWithCUMask: every XCD gives overlap / 8 of its CUs), beside the matrix-bound convs on the
