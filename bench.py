@@ -70,6 +70,7 @@ def csrc_sha(path='f32'):
     traffic figure is stale and is not reported.  Per path, and only those kernels' files, so that a late edit elsewhere in csrc/
     does not void the evidence of a kernel it did not touch (round 5: the driver line lost its traffic that way)."""
     files = {'f32': ('conv_mfma.h', 'conv_wino.h', 'conv_wino4.h', 'conv_wino4v.h', 'conv_ace_sparse.h'),
+             'f32_plain': ('conv_wino.h', 'conv_wino4.h', 'conv_wino4v.h', 'conv_pw.h'),
              'f16x3': ('conv_sh16.h', 'sh16.h', 'ace_sparse.h')}.get(path, ('conv_sh16.h', 'sh16.h', 'ace_sparse.h'))
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'ctrlhair_amd', 'csrc')
@@ -417,12 +418,39 @@ def roofline_block(path, prof, value, B, sustained):
                  'tasks of 64 boundary quads, fused ACE epilogue: the levels above 64 pixels) + wino4v_kernel<1> (the same conv as F(4x4,3x3) over '
                  'every tile with the hidden activations pre-transformed by wino4v_pack_kernel, csrc/conv_wino4v.h: 32 / 64 pixels; '
                  'sean.wino4v=0: wino4_ace_kernel) + conv_mfma_kernel<KS=3,...,EPI_ACE> for the ACEs below 32 pixels; --wino 0: conv_ace_sparse_kernel')
+    # Which kernel set is the DOMINANT one?  Until round 6 the SPADE convs were (22 of 46 ms); with the straight-edge reduction (sean.edge,
+    # csrc/ace_sparse.h) most of their boundary pixels leave the matrix cores and on label maps with straight region borders the ResBlock
+    # convs (3x3 as Winograd F(4x4,3x3) + the learned 1x1 shortcuts) take more of the step: the block describes whichever set took longer
+    # in this run, the other one is kept beside it (`other_set`).
+    other = None
+    tkey = path
+    dom = 'spade_convs'
+    if path == 'f32':
+        spade_blk = {'set': 'spade_convs', 'kernel': kname, 'achieved': round(useful, 2), 'frac': round(useful / peak, 4), 'launches': ace['launches'],
+                     'avg_launch_ms': round(ace['ms'] / n, 4), 'ms_per_step': round(ace['ms'] / prof['steps'], 3),
+                     'executed_over_dense': round(ace['flops_executed'] / max(ace['flops'], 1.0), 4)}
+        if plain['ms'] > ace['ms'] and plain['launches'] > 0:
+            dom, tkey, other = 'resblock_convs', 'f32_plain', spade_blk
+            ace = plain
+            n = max(ace['launches'], 1)
+            t_ace = ace['ms'] * 1e-3
+            dense = ace['flops'] / t_ace / 1e12
+            useful = executed = ace['flops_executed'] / t_ace / 1e12
+            kname = ('wino4_plain_kernel (ResBlock 3x3 convs as Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, in-kernel input transform: the levels above '
+                     '64 pixels) + wino4v_kernel<0> (the same with the input pre-transformed by wino4v_pack_kernel, csrc/conv_wino4v.h: G_middle / up_0) + '
+                     'wino_plain_kernel (F(2x2,3x3): the 16-pixel head block) + pw_conv_kernel (the learned 1x1 shortcuts, csrc/conv_pw.h)')
+        else:
+            pt = plain['ms'] * 1e-3
+            other = None if not plain['launches'] else {
+                'set': 'resblock_convs', 'achieved': round(plain['flops_executed'] / pt / 1e12, 2),
+                'frac': round(plain['flops_executed'] / pt / 1e12 / peak, 4), 'launches': plain['launches'],
+                'avg_launch_ms': round(plain['ms'] / plain['launches'], 4), 'ms_per_step': round(plain['ms'] / prof['steps'], 3)}
     traffic = traffic_raw = detail = note = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath):      # HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
         try:
-            detail = json.load(open(tpath)).get(path)
-            if detail and detail.get('csrc_sha') == csrc_sha(path):
+            detail = json.load(open(tpath)).get(tkey)
+            if detail and detail.get('csrc_sha') == csrc_sha(tkey):
                 traffic = round(float(detail['hbm_bytes']))
                 traffic_raw = round(float(detail['fetch_raw']) + float(detail['write']))
             elif detail:
@@ -435,7 +463,8 @@ def roofline_block(path, prof, value, B, sustained):
     steps = prof['steps']
     sus = (sustained or {}).get(pk)
     blk = {
-        'bound': 'mfma', 'kernel': kname, 'achieved': round(executed, 2), 'peak': peak, 'unit': 'TFLOP/s',
+        'bound': 'mfma', 'dominant_set': dom, 'other_set': other, 'ms_per_step': round(ace['ms'] / prof['steps'], 3),
+        'kernel': kname, 'achieved': round(executed, 2), 'peak': peak, 'unit': 'TFLOP/s',
         'frac': round(executed / peak, 4),
         'peak_sustained': sus, 'frac_of_sustained': round(executed / sus, 4) if sus else None,
         'peak_note': 'peak = spec at the 2.4 GHz boost clock; peak_sustained = MFMA-only loop measured on this device in this run '
@@ -611,7 +640,9 @@ def main():
                              ('dense_all_levels_f4x4', {'sparse': 0, 'opt': (args.opt or []) + ['sean.wino4_ace=512']}),
                              # what bit-identical results across batch sizes cost at B = 16 (option sean.batch_invariant: no split-K, no sample-pair
                              # tiles at 16 pixels; the F(4x4) / F(2x2) rule does not bind at this size)
-                             ('batch_invariant_mode', {'opt': (args.opt or []) + ['sean.batch_invariant=1']})]
+                             ('batch_invariant_mode', {'opt': (args.opt or []) + ['sean.batch_invariant=1']}),
+                             # round 6's two label-dependent reductions off: straight-edge pixels through the boundary conv again, patches from the planes
+                             ('no_straight_edge_reduction', {'opt': (args.opt or []) + ['sean.edge=0']})]
             for name, over in variants:
                 a2 = argparse.Namespace(**vars(args))
                 vpath = over.get('_path', 'f32')

@@ -17,6 +17,8 @@ for P in f16x3 f32; do
   if [ $P = f16x3 ]; then K='conv_sh16_ws_kernel<3, 32, 16, 1, 1, 3|conv_sh16_kernel<3, 16, 16, 2, 1, 3|conv_sh16_kernel<3, 32, 16, 1, 1, 3'
   else K='wino_ace_gather_kernel|wino4v_kernel<1>|wino4_ace_kernel|wino_ace_kernel|conv_ace_sparse_kernel|conv_mfma_kernel<3, 1, 2, 32, 8, 1, 16, 1,|conv_mfma_kernel<3, 1, 2, 16, 16, 1, 16, 1,'; fi
   python $R/tools/make_traffic.py $D $P "$K" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/${TAG}_${P}_pmc.md" >> $OUT/${P}_run.log 2>&1
+  # exact f32: also the ResBlock conv set (3x3 as F(4x4,3x3) / F(2x2,3x3) + the 1x1 shortcuts) -- the dominant set once the straight-edge reduction applies
+  if [ $P = f32 ]; then python $R/tools/make_traffic.py $D f32_plain 'wino4_plain_kernel|wino4v_kernel<0>|wino_plain_kernel|pw_conv_kernel' "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/${TAG}_${P}_pmc.md" >> $OUT/${P}_run.log 2>&1; fi
   grep '^{' $D/trace.log | tail -1 > $OUT/${TAG}_${P}_bench_line.json      # (rocprofv3 logs after the JSON line)
   cp $D/peak.log $OUT/${TAG}_${P}_mfma_peak.log 2>/dev/null
   rm -rf $D
