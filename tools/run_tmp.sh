@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 exec < /dev/null
-for i in 1 2 3; do timeout 900 python -m pytest tests/test_hip_wino.py -x -q -m gpu 2>&1 | grep -E 'passed|failed|AssertionError|assert |max \||^E ' | cut -c1-300; done > gpurun_out/t_patch.txt
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/t_full3.txt
+bash tools/profile_round.sh r06 > gpurun_out/profile_round_r06.log 2>&1
