@@ -456,6 +456,9 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
     }
 }
 
+#ifndef ACE_T4_UNROLL
+#define ACE_T4_UNROLL 1      // channel-loop unroll of the four-pixel interior kernel: 1 = 68 VGPRs (seven blocks per CU), 4 = 97 (five): 4.0 vs 5.3 ms per step (profiles/r06_interior_ab.txt)
+#endif
 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));      // (a 16-byte store the compiler keeps whole)
 // Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
 // values of a thread share their 32-byte sectors with the seven other rows of the block.
@@ -606,13 +609,13 @@ __global__ __launch_bounds__(256, 8) void ace_interior_f32_tile4_kernel(const Ac
             // if-converts both arms into four predicated 4-byte stores -- the shipped kernel of rounds 4-5 never issued a
             // global_store_dwordx4 (found in round 6 when an unrelated branch in the body changed the code: 3.37 -> 2.75 ms per step).
             if (first && (fill || (w0 && w1 && w2 && w3))) {
-#pragma unroll 4
+#pragma unroll ACE_T4_UNROLL
                 for (int c = 0; c < cmax; ++c) {
                     const float4 o = channel(c);
                     *reinterpret_cast<nt_f32x4*>(op + (long long)c * HW) = (nt_f32x4){o.x, o.y, o.z, o.w};
                 }
             } else {
-#pragma unroll 4
+#pragma unroll ACE_T4_UNROLL
                 for (int c = 0; c < cmax; ++c) {
                     const float4 o = channel(c);
                     float* oc = op + (long long)c * HW;
