@@ -773,8 +773,10 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_kernel(const AceInterio
 //    the boundary conv runs after this pass on the same stream and overwrites the boundary pixels.  Those pixels never enter
 //    the recorded maximum.
 __global__ __launch_bounds__(256) void ace_interior_sh16_tile_kernel(const AceInteriorParams q) {
-    constexpr int CB = IS_GPB * 8, RS = 2 * CB + 4;
+    constexpr int CB = IS_GPB * 8, RS = 2 * CB + 4, ES = 64;
     __shared__ __attribute__((aligned(16))) float gt[19 * RS];
+    __shared__ __attribute__((aligned(16))) float et[ES * RS];      // rows of the tile's straight-edge codes (round 6, ace_sparse.h), per channel slab
+    __shared__ int ekey[ES], olist[ES], nocc;
     __shared__ __attribute__((aligned(16))) float pa[CB], pd[CB], pn[CB];
     sh16_mode_on();
     float extra = 1.f;
@@ -789,84 +791,141 @@ __global__ __launch_bounds__(256) void ace_interior_sh16_tile_kernel(const AceIn
     const float slope = q.act == ACT_NONE ? 1.f : (q.act == ACT_LRELU ? 0.2f : 0.f);
     const float osc = q.out_scale * extra;
     const int fill_min = q.variant == 1 ? (q.fill_min > 0 ? q.fill_min : 128) : 257;
+    const bool edges = q.e16 != nullptr && q.etab != nullptr;
     float amax = 0.f;
     for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
         const int b = t / (tpr * tpc), r = t - b * (tpr * tpc), tyi = r / tpr;
         const int x = (r - tyi * tpr) * 32 + (threadIdx.x & 31), y = tyi * 8 + (threadIdx.x >> 5);
         const bool inimg = x < q.W && y < q.H;
         const int pix = y * q.W + x;
-        bool mine = false;
-        int j = 255;
+        bool mine = false, edge = false;
+        int j = 255, code = 0;
         if (inimg) {
             mine = q.variant == 1 || q.cnt[(b * tiles_y + (y >> 4)) * tiles_x + (x >> 5)] == 0;
             if (mine) j = q.u5[(long long)b * HW + pix];
+            edge = edges && mine && j == ACE_EDGE;            // a straight-edge pixel: its row comes from the tile's table of codes
+            if (edge) code = q.e16[(long long)b * HW + pix];
             mine = mine && j < 19;
         }
-        const int nmine = __syncthreads_count(mine);
+        const bool own = mine || edge;
+        const int nmine = __syncthreads_count(own);
         if (nmine == 0) continue;
-        const bool wr = inimg && (mine || nmine >= fill_min);
+        const bool wr0 = inimg && (own || nmine >= fill_min);
         if (!mine) j = 0;
-        const float nz = wr ? q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y] : 0.f;
+        const float nz = wr0 ? q.noise[(long long)b * q.noise_bstride + (long long)x * q.H + y] : 0.f;
         const long long xpix = (long long)(y >> q.x_up) * xW + (x >> q.x_up);
         const float4* __restrict__ xp = reinterpret_cast<const float4*>(q.x) + (long long)b * (q.C >> 2) * xHW + (inimg ? xpix : 0);
         uint4* __restrict__ op = reinterpret_cast<uint4*>(q.out) + (long long)b * Go * 2 * HW + pix;
-        for (int c0 = 0; c0 < q.C; c0 += CB) {
-            float4 xa[IS_GPB][2];
-#pragma unroll
-            for (int gq = 0; gq < IS_GPB; ++gq) {
-                const int c = c0 + gq * 8;
-                xa[gq][0] = xa[gq][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (wr && c < q.C) {
-                    xa[gq][0] = xp[(long long)(c >> 2) * xHW];
-                    if (c + 4 < q.C) xa[gq][1] = xp[(long long)((c >> 2) + 1) * xHW];
-                }
-            }
-            __syncthreads();                                  // the previous slab's table is no longer read
-            for (int i = threadIdx.x; i < 19 * 2 * (CB / 4); i += 256) {
-                const int jj = i / (2 * (CB / 4)), r4 = i % (2 * (CB / 4)), gb = r4 / (CB / 4), c = c0 + (r4 % (CB / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < q.C) v = *reinterpret_cast<const float4*>(q.gtab + (((long long)b * 19 + jj) * 2 + gb) * q.C + c);
-                *reinterpret_cast<float4*>(gt + jj * RS + gb * CB + (r4 % (CB / 4)) * 4) = v;
-            }
-            if (threadIdx.x < CB) {
-                const int c = c0 + threadIdx.x;
-                pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
-                pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
-                pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
-            }
-            __syncthreads();
-            if (!wr) continue;
-            const float* g = gt + j * RS;
-#pragma unroll
-            for (int gq = 0; gq < IS_GPB; ++gq) {
-                const int c = c0 + gq * 8;
-                if (c >= q.C) break;
-                const float xv[8] = {xa[gq][0].x, xa[gq][0].y, xa[gq][0].z, xa[gq][0].w, xa[gq][1].x, xa[gq][1].y, xa[gq][1].z, xa[gq][1].w};
-                is_h8 vh, vl;
-                float am = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int cc = gq * 8 + e;
-                    const float nrm = pa[cc] * xv[e] + pn[cc] * nz + pd[cc];
-                    float o = nrm * (1.f + g[cc]) + g[CB + cc];
-                    o = fmaxf(o, slope * o) * osc;
-                    if (c + e >= q.C) o = 0.f;                 // padding channels of the last group hold zeros
-                    am = fmaxf(am, fabsf(o));
-                    if (q.bf16) {
-                        const __bf16 tb = (__bf16)o;
-                        vh[e] = __builtin_bit_cast(_Float16, tb);
-                        vl[e] = (_Float16)0.f;
-                    } else {
-                        const _Float16 h = (_Float16)o;
-                        vh[e] = h;
-                        vl[e] = (_Float16)(o - (float)h);
+        // rounds: the codes that find no slot in the 64-entry table of a round are served by the next one (not seen on the tests' label maps)
+        bool pend = edge;
+        for (bool first = true;; first = false) {
+            int slot = -1;
+            if (edges) {
+                __syncthreads();                              // (the previous tile's / round's table is no longer read)
+                if (threadIdx.x < ES) ekey[threadIdx.x] = -1;
+                __syncthreads();
+                if (pend) {
+                    unsigned h = ((unsigned)code * 2654435761u) >> 26;
+                    for (int probe = 0; probe < ES; ++probe) {
+                        const int old = atomicCAS(&ekey[h], -1, code);
+                        if (old == -1 || old == code) {
+                            slot = (int)h;
+                            pend = false;
+                            break;
+                        }
+                        h = (h + 1) & (ES - 1);
                     }
                 }
-                if (mine) amax = fmaxf(amax, am);              // filler pixels are overwritten: they do not set the scale
-                const long long u = (long long)(c >> 3) * 2 * HW;
-                op[u] = __builtin_bit_cast(uint4, vh);
-                if (!q.single) op[u + HW] = __builtin_bit_cast(uint4, vl);
+                __syncthreads();
+                if (threadIdx.x < ES) {
+                    const bool occ = ekey[threadIdx.x] >= 0;
+                    const unsigned long long om = __ballot(occ);
+                    if (occ) olist[__popcll(om & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+                    if (threadIdx.x == 0) nocc = __popcll(om);
+                }
             }
+            const bool wr = first ? wr0 : slot >= 0;          // later rounds: only the pixels that just got their row
+            for (int c0 = 0; c0 < q.C; c0 += CB) {
+                float4 xa[IS_GPB][2];
+#pragma unroll
+                for (int gq = 0; gq < IS_GPB; ++gq) {
+                    const int c = c0 + gq * 8;
+                    xa[gq][0] = xa[gq][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (wr && c < q.C) {
+                        xa[gq][0] = xp[(long long)(c >> 2) * xHW];
+                        if (c + 4 < q.C) xa[gq][1] = xp[(long long)((c >> 2) + 1) * xHW];
+                    }
+                }
+                __syncthreads();                              // the previous slab's tables are no longer read
+                for (int i = threadIdx.x; i < 19 * 2 * (CB / 4); i += 256) {
+                    const int jj = i / (2 * (CB / 4)), r4 = i % (2 * (CB / 4)), gb = r4 / (CB / 4), c = c0 + (r4 % (CB / 4)) * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < q.C) v = *reinterpret_cast<const float4*>(q.gtab + (((long long)b * 19 + jj) * 2 + gb) * q.C + c);
+                    *reinterpret_cast<float4*>(gt + jj * RS + gb * CB + (r4 % (CB / 4)) * 4) = v;
+                }
+                if (edges) {                                  // rows of the occupied slots: E[code] + the three style sums (C % 4 == 0)
+                    const int ne = nocc * 2 * (CB / 4);
+                    for (int i = threadIdx.x; i < ne; i += 256) {
+                        const int sl = olist[i / (2 * (CB / 4))], r4 = i % (2 * (CB / 4)), gb = r4 / (CB / 4), c = c0 + (r4 % (CB / 4)) * 4;
+                        const int kc = ekey[sl];
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (c < q.C) {
+                            v = *reinterpret_cast<const float4*>(q.etab + ((long long)kc * 2 + gb) * q.C + c);
+                            if (q.p6) {
+                                const int sn = (kc & 3) + 1, Bl = (kc >> 2) % 19, A = ((kc >> 2) / 19) % 19, o = (kc >> 2) / 361;
+#pragma unroll
+                                for (int tt = 0; tt < 3; ++tt) {
+                                    const int l = (1 + tt < sn) ? A : Bl;
+                                    const float4 u = *reinterpret_cast<const float4*>(q.p6 + ((((long long)b * 19 + l) * 6 + o * 3 + tt) * 2 + gb) * q.C + c);
+                                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                                }
+                            }
+                        }
+                        *reinterpret_cast<float4*>(et + sl * RS + gb * CB + (r4 % (CB / 4)) * 4) = v;
+                    }
+                }
+                if (threadIdx.x < CB) {
+                    const int c = c0 + threadIdx.x;
+                    pa[threadIdx.x] = c < q.C ? q.bn_a[c] : 0.f;
+                    pd[threadIdx.x] = c < q.C ? q.bn_d[c] : 0.f;
+                    pn[threadIdx.x] = c < q.C ? q.nv[c] : 0.f;
+                }
+                __syncthreads();
+                if (!wr) continue;
+                const float* g = slot >= 0 ? et + slot * RS : gt + j * RS;
+#pragma unroll
+                for (int gq = 0; gq < IS_GPB; ++gq) {
+                    const int c = c0 + gq * 8;
+                    if (c >= q.C) break;
+                    const float xv[8] = {xa[gq][0].x, xa[gq][0].y, xa[gq][0].z, xa[gq][0].w, xa[gq][1].x, xa[gq][1].y, xa[gq][1].z, xa[gq][1].w};
+                    is_h8 vh, vl;
+                    float am = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int cc = gq * 8 + e;
+                        const float nrm = pa[cc] * xv[e] + pn[cc] * nz + pd[cc];
+                        float o = nrm * (1.f + g[cc]) + g[CB + cc];
+                        o = fmaxf(o, slope * o) * osc;
+                        if (c + e >= q.C) o = 0.f;                 // padding channels of the last group hold zeros
+                        am = fmaxf(am, fabsf(o));
+                        if (q.bf16) {
+                            const __bf16 tb = (__bf16)o;
+                            vh[e] = __builtin_bit_cast(_Float16, tb);
+                            vl[e] = (_Float16)0.f;
+                        } else {
+                            const _Float16 h = (_Float16)o;
+                            vh[e] = h;
+                            vl[e] = (_Float16)(o - (float)h);
+                        }
+                    }
+                    if (mine || slot >= 0) amax = fmaxf(amax, am);  // filler pixels are overwritten: they do not set the scale
+                    const long long u = (long long)(c >> 3) * 2 * HW;
+                    op[u] = __builtin_bit_cast(uint4, vh);
+                    if (!q.single) op[u + HW] = __builtin_bit_cast(uint4, vl);
+                }
+            }
+            if (!edges) break;
+            if (!__syncthreads_or(pend)) break;
         }
     }
     if (q.pass == 0 && q.out_amax) sh16_block_slot_max(q.out_amax, amax);

@@ -273,7 +273,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 // 128 pixels and more (res_div <= 4), from the hidden vectors of the windows AAB / ABB (double, host) and the column / row sums
                 // of the gamma / beta weights, contracted on the device in double (ace_edge_table).  vbg / vbb (blended biases) are added.
                 a.edge_tab = nullptr;
-                if (edge && !use_sh16 && wino && s.res_div <= 4) {
+                if (edge && (use_sh16 ? sparse : wino) && s.res_div <= 4) {
                     edge_hv.assign((size_t)2 * 741 * HID, 0.0);
                     edge_W6.assign((size_t)2 * HID * 6 * C, 0.0);
                     std::vector<double>&hv = edge_hv, &W6 = edge_W6;
@@ -765,7 +765,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                     L.TH = th;
                     L.cap_tiles = mb * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
                     L.u5 = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
-                    L.e16 = (edge && !use_sh16 && wino && r >= 128) ? static_cast<uint16_t*>(B.dalloc((size_t)mb * r * r * sizeof(uint16_t))) : nullptr;
+                    L.e16 = (edge && (use_sh16 || wino) && r >= 128) ? static_cast<uint16_t*>(B.dalloc((size_t)mb * r * r * sizeof(uint16_t))) : nullptr;
                     L.need = static_cast<uint8_t*>(B.dalloc((size_t)mb * r * r));
                     L.list = static_cast<uint16_t*>(B.dalloc((size_t)L.cap_tiles * 32 * L.TH * sizeof(uint16_t)));
                     L.cnt = static_cast<int*>(B.dalloc((size_t)L.cap_tiles * sizeof(int)));
@@ -792,7 +792,7 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
             }
         if (cmax) gtab = B.falloc((size_t)mb * LABEL_NC * 2 * cmax);
         if (cmax && overlap_on) gtab_side = B.falloc((size_t)mb * LABEL_NC * 2 * cmax);
-        p6 = (cmax && edge && !use_sh16 && wino) ? B.falloc((size_t)mb * LABEL_NC * 6 * 2 * cmax) : nullptr;      // (straight-edge pixels: ace_sparse.h)
+        p6 = (cmax && edge && (use_sh16 || wino)) ? B.falloc((size_t)mb * LABEL_NC * 6 * 2 * cmax) : nullptr;      // (straight-edge pixels: ace_sparse.h)
     }
     if (!B.err.empty()) return B.err;
     if (hipDeviceSynchronize() != hipSuccess) return "hipDeviceSynchronize failed after weight upload";
@@ -919,6 +919,11 @@ struct Runner {
         if (!m.claim_pool || claim_next >= SeanModel::CLAIM_SLOTS) return nullptr;
         return m.claim_pool + (size_t)SeanModel::CLAIM_WORDS * claim_next++;
     }
+    static int lk_of(const AceW& a) {
+        int k = 0;
+        while ((1 << k) < a.res_div) ++k;
+        return k;
+    }
     // exact SPADE-interior reduction: the level's classification and the work list of (level, row tiles), once per chunk
     bool lvl_done[6][2] = {};
     std::vector<int> work_done[6];
@@ -933,14 +938,17 @@ struct Runner {
                 const SparseLevel& L = m.sp_level[k][ti];
                 if (!L.u5) return nullptr;
                 const int ntiles = B * ((r + 31) / 32) * ((r + L.TH - 1) / L.TH);
-                if (!lvl_done[k][ti] || lvl_edges[k][ti]) {
-                    // (a level classified WITH straight-edge marks for the Winograd ACEs and then needed by the direct sparse kernels, which do not
-                    //  know them: classified again without, and the quad lists of the level with it -- not expected to happen: every ACE of a
-                    //  level takes the same route)
-                    check(ace_classify(lab, L.u5, L.need, L.list, L.cnt, B, r, r, L.TH, st), "ace_classify");
+                // f16x3 / f16 / bf16 path, pixel-level compaction: the interior pass knows the straight-edge pixels (ace_interior_sh16_tile_kernel)
+                const bool want = m.use_sh16 && m.edge && L.e16 && r >= 128 && a.edge_tab && (!a.styled || m.p6) && w.mode >= 2;
+                if (!lvl_done[k][ti] || lvl_edges[k][ti] != want) {
+                    // (a level classified WITH straight-edge marks for the Winograd ACEs and then needed by the direct sparse kernels of the
+                    //  exact-f32 path, which do not know them: classified again without, and the quad lists of the level with it -- not
+                    //  expected to happen: every ACE of a level takes the same route)
+                    check(ace_classify(lab, L.u5, L.need, L.list, L.cnt, B, r, r, L.TH, st, want ? L.e16 : nullptr), "ace_classify");
+                    const bool again = lvl_done[k][ti];
                     lvl_done[k][ti] = true;
-                    if (lvl_edges[k][ti]) {
-                        lvl_edges[k][ti] = false;
+                    lvl_edges[k][ti] = want;
+                    if (again) {
                         wq_done[k] = false;
                         wwork_done[k].clear();
                         work_done[k].clear();
@@ -1487,6 +1495,11 @@ struct Runner {
             // dbg bit 2097152: the row-shaped kernels of the first version (A/B)
             ip.impl = CH_ABL(m.dbg & 2097152) ? 1 : 0;
             ip.fill_min = m.use_sh16 ? 128 : (x_up ? 257 : 128);
+            if (m.use_sh16 && compact && lvl_edges[lk_of(a)][sw->TH == 16 ? 1 : 0]) {      // straight-edge pixels served by the interior pass
+                ip.e16 = L.e16;
+                ip.etab = a.edge_tab;
+                ip.p6 = (a.styled && q.lut) ? m.p6 : nullptr;
+            }
             // (impl 2, four pixels per thread: 10 % ahead at 512^2 in tools/interior_bench.hip, no difference in the generator
             // step -- 159.7 vs 159.9 images/s -- so the one-pixel kernel stays; dbg bit 16777216 selects it)
             if (!m.use_sh16 && CH_ABL(m.dbg & 16777216) && r >= 128) {
@@ -1504,6 +1517,7 @@ struct Runner {
                 // (the f16x3 LUT is stored pre-multiplied by the ACE output scale)
                 check(ace_gtable(a.bias_g, a.bias_b, a.gconst, q.lut, q.lut_rs, q.lut_ns, q.lut_bs, m.use_sh16 ? 1.f / a.out_scale : 1.f,
                                  m.gtab, B, a.C, st), "ace_gtable");
+                if (ip.p6) check(ace_p6table(q.lut, q.lut_rs, q.lut_ns, q.lut_bs, 1.f / a.out_scale, m.p6, B, a.C, st), "ace_p6table");
                 check(m.use_sh16 ? ace_interior_sh16(ip, st) : ace_interior_f32(ip, st), "ace interior");
             });
             timed(1, 2.0 * 2 * a.C * HID * 9 * npix, 0.0, sw->total, 32.0 * 64 * 2.0 * HID * 9, 4.0 * HID + xpp + opp,

@@ -152,6 +152,44 @@ def test_interior_and_label_table_kernels_match_their_first_versions(hip_lib, pa
     old.handle.close()
 
 
+@pytest.mark.parametrize('mode,ngf,S,B,tol', [(1, 64, 256, 3, 2e-5), (1, 16, 512, 2, 2e-5), (2, 64, 256, 2, 2e-2), (3, 16, 512, 2, 1e-1)])
+def test_straight_edge_pixels_on_the_f16_paths(hip_lib, mode, ngf, S, B, tol):
+    """Option sean.edge on the f16x3 (mode 1) / single-term f16 (2) / bf16 (3) paths: with pixel-level compaction the 32 x 8 interior pass
+    (ace_interior_sh16_tile_kernel) serves the straight-edge pixels from a per-block table of their codes' rows -- E[code] of the ACE plus
+    the three style-LUT column / row sums -- instead of the boundary conv.  Against the conv evaluation of the same library
+    (sean.edge = 0): f16x3 at 2e-5 (two f32-class evaluations of the same sums), the reduced-precision paths at their own tolerance
+    (the table rows are exact f32, the conv they replace is not; bf16: two evaluations, each inside 5e-2 of the exact image); fewer boundary tiles must run where straight edges exist.
+    normalization.py:117-153,172-187,249-257."""
+    from ctrlhair_amd import procedural as P
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    sd = P.sean_state_dict(0, ngf)
+
+    def gen(edge):
+        g = SeanGenerator(0, f16x3=mode, options={'sean.edge': edge}).load_state_dict(sd, max_batch=B, max_size=S)
+        g.handle.set_option('sean.dbg', 64)
+        return g
+    on, off = gen(1), gen(0)
+    codes, noise = P.style_codes(B, seed=91), P.noise_planes(B, S, ngf, seed=92)
+    sets = _label_sets(B, S)
+    for name in ('blocky', 'face', 'noclass', 'stripes5', 'diag', 'one_region'):
+        a, b = _run(on, sets[name], codes, noise), _run(off, sets[name], codes, noise)
+        d = float(np.abs(a - b).max())
+        print(f'mode {mode} ngf{ngf} S={S} {name}: max |edge rows - boundary conv| = {d:.3e}')
+        assert np.isfinite(a).all() and d <= tol, (name, d)
+        assert np.array_equal(a, _run(on, sets[name], codes, noise)), 'repeated call differs'
+    ex = {}
+    for g, key in ((on, 1), (off, 0)):
+        g.handle.profile_enable(True)
+        _run(g, sets['blocky'], codes, noise)
+        g.handle.profile_enable(False)
+        ex[key] = g.handle.profile_read(1)['flops_executed']
+        g.handle.profile_read(-1)
+    print(f'SPADE conv FLOPs executed on blocky labels: {ex[0]:.3e} -> {ex[1]:.3e}')
+    assert ex[1] < 0.8 * ex[0]
+    on.handle.close()
+    off.handle.close()
+
+
 def test_pair_and_quad_entries_match_single_row_tile_entries(hip_lib):
     """f16x3 compacting kernel: tiles with at most four sub-tiles of boundary pixels are served two or four row tiles per
     iteration, with the A fragments streamed by the consumer waves (conv_sh16_ws_kernel<..., CP = 2 / 3>); option

@@ -1,10 +1,15 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
+#!/bin/bash
 exec < /dev/null
-cp ctrlhair_amd/libctrlhair_hip.so /tmp/lib_u4.so
-for U in u4 u2 u1 u4 u2 u1; do
-  if [ $U = u4 ]; then cp /tmp/lib_u4.so ctrlhair_amd/libctrlhair_hip.so; else cp ctrlhair_amd/libctrlhair_$U.so ctrlhair_amd/libctrlhair_hip.so; fi
-  timeout 300 python bench.py --only-headline --no-cpu-baseline --steps 20 > gpurun_out/b_$U.json 2> gpurun_out/b_$U.err
-  timeout 20 python tools/bench_brief.py $U < gpurun_out/b_$U.json
-done > gpurun_out/b_unroll_brief.txt 2>&1
-cp /tmp/lib_u4.so ctrlhair_amd/libctrlhair_hip.so
+cd /root/repo
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_hip_sparse_ace.py -x -q -s -k "straight_edge or sparse_equals_dense" 2>&1 | tail -60 > gpurun_out/t_edge16.log
+for p in bf16 f16 f16x3; do
+  timeout 300 python bench.py --only-headline --path $p --batch 32 --steps 6 --warmup 2 --no-cpu-b16 > gpurun_out/b_$p.json 2> gpurun_out/b_$p.err
+done
+timeout 300 python bench.py --only-headline --path bf16 --batch 16 --steps 6 --warmup 2 --no-cpu-b16 > gpurun_out/b_bf16_16.json 2>> gpurun_out/b_bf16.err
+cat gpurun_out/t_edge16.log
+for f in gpurun_out/b_bf16.json gpurun_out/b_f16.json gpurun_out/b_f16x3.json gpurun_out/b_bf16_16.json; do python -c "
+import json,sys
+l=[x for x in open('$f') if x.startswith('{')]
+j=json.loads(l[-1]); print('$f', j['value'], j['ms_per_step'])
+"; done
