@@ -267,6 +267,9 @@ class PipelineJob:
             opts['sean.dbg'] = args.dbg
         if args.compact is not None:
             opts['sean.sh16_compact'] = args.compact
+        for kv in (args.opt or []):              # experiments: any ch_set_option pair of the generator
+            k, v = kv.split('=')
+            opts[k] = int(v)
         self.pipe = EditPipeline(weights, device=dev.index, img_size=S, max_batch=B, f16x3=PATH_OPTION[path], options=opts)
         self.img = torch.from_numpy(P.synthetic_images(B, S, seed=11 + rank * B)).to(dev)
         self.handle = self.pipe.models.generator.handle

@@ -190,11 +190,13 @@ def test_device_noise_is_standard_normal_and_is_what_generate_uses(hip_lib):
     assert torch.equal(x, y)
 
 
-def test_graph_replay_equals_eager(hip_lib):
-    """hipGraph capture of a batch-1 render (SeanGenerator.capture): replays with refilled inputs equal eager calls."""
+@pytest.mark.parametrize('path', ['f16x3', 'f32'])
+def test_graph_replay_equals_eager(hip_lib, path):
+    """hipGraph capture of a batch-1 render (SeanGenerator.capture): replays with refilled inputs equal eager calls, on the f16x3 and
+    on the exact-f32 path (Winograd levels, interior / straight-edge reduction and run-ahead side stream inside the capture)."""
     from ctrlhair_amd import procedural as P
     ngf, S = 16, 128
-    gen = gen_for(ngf, path='f16x3')
+    gen = gen_for(ngf, path=path)
     dev = gen.device
     lab = torch.from_numpy(P.blocky_labels(1, S, grid=8)).to(dev)
     cd = torch.from_numpy(P.style_codes(1)).to(dev)
