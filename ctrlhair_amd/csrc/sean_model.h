@@ -165,7 +165,7 @@ struct SeanModel {
     int wino4_force = 0;                       // option "sean.wino4_force": 1 = F(4x4,3x3) wherever the shape allows, whatever the task count (tests)
     int wino4_ace_max_r = 64;                  // option "sean.wino4_ace": largest level whose SPADE convs run as F(4x4,3x3) over EVERY tile (0 = none)
     int edge = 1;                              // option "sean.edge": 1 = straight-edge pixels of the levels >= 128 pixels are modulated by the interior pass from
-                                               //   per-code table rows instead of going through the boundary conv (exact-f32 Winograd path; ace_sparse.h)
+                                               //   per-code table rows instead of going through the boundary conv (exact-f32 Winograd path, f16 paths in compaction mode; ace_sparse.h)
     float* p6 = nullptr;                       // per-call column / row sums of the style LUT of the ACE being run: [mb][19][6][2][C]
     int batch_inv = 0;                         // option "sean.batch_invariant": 1 = every choice that follows the number of tasks of a call (F(4x4) vs F(2x2),
                                                //   split-K, sample-pair tiles at 16 pixels, the small-batch LUT / tiny-level routes) is made as for a large

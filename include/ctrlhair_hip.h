@@ -88,11 +88,12 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   Both F(4x4,3x3) choices are made per call: with fewer tasks of 32 x 32 pixels than a round of F(2x2,3x3) tasks would need CUs (single
  *   images, small batches of small images) the F(2x2,3x3) kernels run instead (wino4_pays, conv_wino4.h); "sean.wino4_force" = 1 (any
  *   time) switches that rule off.
- * "sean.edge" (default 1; before ch_finalize; exact-f32 Winograd path): a boundary pixel whose 5 x 5 label neighbourhood is five uniform
+ * "sean.edge" (default 1; before ch_finalize; exact-f32 Winograd path and the f16x3 / f16 / bf16 paths with pixel-level compaction): a boundary pixel whose 5 x 5 label neighbourhood is five uniform
  *   columns (or rows) A..A B..B -- one straight, axis-aligned piece of a region border -- takes gamma / beta from the row of its code
  *   (orientation, A, B, number of A columns: 2888 rows per ACE, built at ch_finalize in double) plus three column / row sums of the style
  *   LUT, in the interior pass, on the levels of 128 pixels and more; only corners, curved pieces and the image frame go through the
- *   boundary conv (csrc/ace_sparse.h).  Same real number, another association of the f32 sums (<= 1e-6 against "sean.edge" = 0).
+ *   boundary conv (csrc/ace_sparse.h).  Same real number, another association of the f32 sums (<= 1e-6 against "sean.edge" = 0;
+ *   f16x3: <= 5e-6; on the single-term f16 / bf16 paths the table rows are exact f32 where the conv they replace is not).
  *   Costs 52 MB of tables at ngf = 64.  0 = every non-interior pixel through the conv.
  * "sean.patch" (default 1; before ch_finalize): when a level is left with few boundary quads (at most 32 chunks of 64 per sample) their
  *   hidden-activation patches are written pre-gathered, in the conv kernel's stage layout, instead of being fetched piecewise from the
