@@ -2,6 +2,23 @@
 // direct convolution on the GPU (double accumulation), over the ResBlock conv shapes of the ngf = 64 generator at 512^2, B = 16.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino4_bench.hip -o tools/wino4_bench.bin ; run on the GPU box.
 #include "../ctrlhair_amd/csrc/conv_inst_wino4.hip"
+#ifdef W4S_EXPERIMENT      // the shared-transform variant (tools/wino4s_experiment.h): measured, not adopted
+#include "wino4s_experiment.h"
+namespace chk {
+static hipError_t conv_wino4s_plain(Wino4Params p, hipStream_t s) {
+    if (!wino4_supported(p.H, p.W, p.Cin) || !p.in || !p.wpk || !p.out) return hipErrorInvalidValue;
+    wino4_fill_launch(p);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4s_plain_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, wino4s::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4s_plain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, wino4s::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int grid = p.ntasks < 256 ? p.ntasks : 256;
+    if (p.reflect) hipLaunchKernelGGL(wino4s_plain_kernel<1>, dim3(grid), dim3(512), wino4s::LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(wino4s_plain_kernel<0>, dim3(grid), dim3(512), wino4s::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+}  // namespace chk
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,7 +64,7 @@ int main(int argc, char** argv) {
         {16, 256, 128, 256, 0, "up_2 conv_0"}, {16, 128, 128, 256, 1, "up_2 conv_1 (+xs)"},
         {16, 128, 64, 512, 0, "up_3 conv_0"}, {16, 64, 64, 512, 1, "up_3 conv_1 (+xs)"},
     };
-    double tot_ms = 0, tot_fl = 0;
+    double tot_ms = 0, tot_fl = 0, tot_ms_s = 0;
     for (const Shape& c : all) {
         if (quick && c.B * (long long)c.H * c.H * c.Cout > (1 << 22)) continue;
         const int B = c.B, Cin = c.Cin, Cout = c.Cout, H = c.H, W = c.H;
@@ -112,6 +129,41 @@ int main(int argc, char** argv) {
             ms /= it;
             if (B == 16) { tot_ms += ms * (strstr(c.name, "G_middle") ? 2 : 1); tot_fl += fl * (strstr(c.name, "G_middle") ? 2 : 1); }
         }
+#ifdef W4S_EXPERIMENT
+        // one input transform per pair of waves (tools/wino4s_experiment.h): must equal the result above bit for bit
+        {
+            float* d_out3;
+            CK(hipMalloc(&d_out3, nout * 4));
+            CK(hipMemset(d_out3, 0xFF, nout * 4));
+            Wino4Params ps = p;
+            ps.out = d_out3;
+            CK(conv_wino4s_plain(ps, 0));
+            CK(hipDeviceSynchronize());
+            std::vector<float> h1(nout), h3(nout);
+            CK(hipMemcpy(h1.data(), d_out, nout * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h3.data(), d_out3, nout * 4, hipMemcpyDeviceToHost));
+            const bool same = memcmp(h1.data(), h3.data(), nout * 4) == 0;
+            double sd = 0;
+            if (!same) for (size_t i = 0; i < nout; ++i) { const double d = fabs((double)h1[i] - h3[i]); if (!(d <= sd)) sd = d; }
+            float mss = 0;
+            if (!quick) {
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                const int it = 5;
+                CK(conv_wino4s_plain(ps, 0));
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < it; ++i) CK(conv_wino4s_plain(ps, 0));
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&mss, e0, e1));
+                mss /= it;
+                if (B == 16) tot_ms_s += mss * (strstr(c.name, "G_middle") ? 2 : 1);
+            }
+            printf("   shared transform: %s (max diff %.3e)  %8.3f ms  executed %6.1f TF/s\n", same ? "BITEQ" : "DIFF ", sd, mss,
+                   mss > 0 ? 2.0 * B * (H / 4) * (W / 4) * (double)Cout * Cin * 36.0 / mss * 1e-9 : 0.0);
+            (void)hipFree(d_out3);
+        }
+#endif
         // pre-transformed input route (conv_wino4v.h): pack pass + contraction; must equal the in-kernel-transform result bit for bit
         float msv = 0, msp = 0;
         double vdiff = -1;
@@ -156,6 +208,6 @@ int main(int argc, char** argv) {
         (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_pk); (void)hipFree(d_out); (void)hipFree(d_ref);
         if (d_res) (void)hipFree(d_res);
     }
-    if (!quick) printf("sum over the ResBlock convs of one step from 32^2 up (G_middle x2): %.2f ms, dense-equivalent %.1f TF/s\n", tot_ms, tot_fl / tot_ms * 1e-9);
+    if (!quick) printf("sum over the ResBlock convs of one step from 32^2 up (G_middle x2): %.2f ms, dense-equivalent %.1f TF/s; shared transform: %.2f ms\n", tot_ms, tot_fl / tot_ms * 1e-9, tot_ms_s);
     return 0;
 }
