@@ -152,13 +152,14 @@ def test_interior_and_label_table_kernels_match_their_first_versions(hip_lib, pa
     old.handle.close()
 
 
-@pytest.mark.parametrize('mode,ngf,S,B,tol', [(1, 64, 256, 3, 2e-5), (1, 16, 512, 2, 2e-5), (2, 64, 256, 2, 2e-2), (3, 16, 512, 2, 1e-1)])
+@pytest.mark.parametrize('mode,ngf,S,B,tol', [(1, 64, 256, 3, 2e-5), (1, 16, 512, 2, 2e-5), (1, 16, 416, 3, 2e-5), (2, 64, 256, 2, 2e-2), (3, 16, 512, 2, 1e-1)])
 def test_straight_edge_pixels_on_the_f16_paths(hip_lib, mode, ngf, S, B, tol):
     """Option sean.edge on the f16x3 (mode 1) / single-term f16 (2) / bf16 (3) paths: with pixel-level compaction the 32 x 8 interior pass
     (ace_interior_sh16_tile_kernel) serves the straight-edge pixels from a per-block table of their codes' rows -- E[code] of the ACE plus
     the three style-LUT column / row sums -- instead of the boundary conv.  Against the conv evaluation of the same library
     (sean.edge = 0): f16x3 at 2e-5 (two f32-class evaluations of the same sums), the reduced-precision paths at their own tolerance
-    (the table rows are exact f32, the conv they replace is not; bf16: two evaluations, each inside 5e-2 of the exact image); fewer boundary tiles must run where straight edges exist.
+    (the table rows are exact f32, the conv they replace is not; bf16: two evaluations, each inside 5e-2 of the exact image); S = 416: levels of
+    208 and 416 pixels, i.e. partial 32 x 8 blocks and partial classification tiles; fewer boundary tiles must run where straight edges exist.
     normalization.py:117-153,172-187,249-257."""
     from ctrlhair_amd import procedural as P
     from ctrlhair_amd.sean.generator import SeanGenerator
