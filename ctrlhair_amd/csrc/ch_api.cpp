@@ -381,6 +381,11 @@ int ch_set_option(ch_handle* h, const char* key, int value) {
         h->sean.patch = value != 0;
         return CH_OK;
     }
+    if (std::strcmp(key, "sean.convt_gemm") == 0) {   // exact-f32 Zencoder: 1 = the ConvTranspose as four phase GEMMs over shifted views (default), 0 = four Winograd phase convs
+        if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.convt_gemm) must precede ch_finalize");
+        h->sean.convt_gemm = value != 0;
+        return CH_OK;
+    }
     if (std::strcmp(key, "sean.edge") == 0) {         // 1 = straight-edge pixels from per-code table rows in the interior pass (default), 0 = through the boundary conv
         if (h->sean_ready) return fail(h, CH_ERR_STATE, "ch_set_option(sean.edge) must precede ch_finalize");
         h->sean.edge = value != 0;

@@ -31,6 +31,7 @@ struct PwParams {
     int B, Cin, Cout, HW;   // Cin % 16 == 0, HW % (512 / RT) == 0
     const PwGroup* groups;  // device array of ngroups entries, or null (plain launch)
     int ngroups;
+    long long in_bs;        // plain launch: floats between the samples of `in`; 0 = Cin * HW (a launch over the first Cin planes of wider samples: sean_model.cpp, Zencoder ConvTranspose)
     // set by the launcher
     int nrg, npt, ntasks, nst;
 };
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void pw_conv_kernel(const PwParams p) {
             const int u = i * 512 + tid, ch = u / (PXB / 4), q = u - ch * (PXB / 4);
             vp[i] = (unsigned)(ch * HW + pt * PXB + 4 * q) * 4u;
         }
-        d_in = wino_rsrc(tin + (long long)ib * p.Cin * HW, (unsigned)p.Cin * HW * 4u);
+        d_in = wino_rsrc(tin + (long long)ib * (p.in_bs ? p.in_bs : (long long)p.Cin * HW), (unsigned)p.Cin * HW * 4u);
         // the RT row tiles of a group are consecutive images of nst * 2 KB each: thread tid copies unit (tid & 127) of row tile tid >> 7
         const int nrt = (p.Cout + 31) / 32, have = nrt - rg * RT < RT ? nrt - rg * RT : RT;       // (last group may be partial)
         d_a = wino_rsrc(twpk + (long long)rg * RT * nst * 512, (unsigned)have * nst * 2048u);

@@ -61,6 +61,11 @@ float instnorm_sh16_scale(int HW);
 // pairs and large planes, where one block per pair would leave most CUs idle
 hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16 = nullptr, int C = 0,
                         float* scratch = nullptr);
+// ConvTranspose2d(k3, s2, p1, op1) as four phase GEMMs (misc_kernels.hip): the four shifted views of x [B][C][H][W] as xs [B][4][C][H][W]
+// (shift order (0,1) | (0,0) | (1,0) | (1,1)); InstanceNorm + activation over the phase planes t [4][B][C][H][W] (+ bias), written
+// depth-to-space into out [B][C][2H][2W]
+hipError_t convt_shift4(const float* x, float* xs, int B, int C, int H, int W, hipStream_t s);
+hipError_t instnorm_act_d2s(const float* t, const float* bias, float* out, int B, int C, int H, int W, float eps, int act, hipStream_t s);
 hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float eps, int act, void* sh16, hipStream_t s,
                                float* scratch = nullptr);
 hipError_t layernorm_act(float* x, const float* gamma, const float* beta, float* part, int B, int C, int HW, float eps,

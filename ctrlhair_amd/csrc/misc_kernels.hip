@@ -350,6 +350,91 @@ hipError_t instnorm_c4_to_sh16(const float* x_c4, int B, int C, int HW, float ep
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k3, s2, p1, op1) as four phase GEMMs (sean_model.cpp, Zencoder model.10; architecture.py:167-170):
+//   out[2y+py][2x+px] = sum over dy <= py, dx <= px of Wt[:, :, py+1-2dy, px+1-2dx]^T x[y+dy][x+dx]        (x = 0 outside the image)
+// convt_shift4: the four shifted views of x as planes of ONE buffer, xs[b][s][c][y][x] = x[b][c][y+dy][x+dx] with the shift order
+// s = (0,1) | (0,0) | (1,0) | (1,1), so that every phase reads a contiguous range of planes: (0,0): s1; (0,1): s0..s1; (1,0): s1..s2;
+// (1,1): s0..s3.  One thread = four pixels of a row.
+__global__ __launch_bounds__(256) void convt_shift4_kernel(const float* __restrict__ x, float* __restrict__ xs, int C, int H, int W, long long n4) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n4) return;
+    const int W4 = W >> 2;
+    const int x4 = (int)(i % W4), y = (int)((i / W4) % H);
+    const long long pc = i / ((long long)W4 * H);             // plane b * C + c
+    const int c = (int)(pc % C);
+    const long long b = pc / C;
+    const long long HW = (long long)H * W;
+    const float* r0 = x + pc * HW + (long long)y * W + 4 * x4;
+    const float4 a = *reinterpret_cast<const float4*>(r0);
+    const float an = 4 * x4 + 4 < W ? r0[4] : 0.f;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dn = 0.f;
+    if (y + 1 < H) {
+        d = *reinterpret_cast<const float4*>(r0 + W);
+        dn = 4 * x4 + 4 < W ? r0[W + 4] : 0.f;
+    }
+    float* o = xs + ((b * 4) * C + c) * HW + (long long)y * W + 4 * x4;
+    const long long ss = (long long)C * HW;
+    *reinterpret_cast<float4*>(o) = make_float4(a.y, a.z, a.w, an);                 // (0, 1)
+    *reinterpret_cast<float4*>(o + ss) = a;                                         // (0, 0)
+    *reinterpret_cast<float4*>(o + 2 * ss) = d;                                     // (1, 0)
+    *reinterpret_cast<float4*>(o + 3 * ss) = make_float4(d.y, d.z, d.w, dn);        // (1, 1)
+}
+hipError_t convt_shift4(const float* x, float* xs, int B, int C, int H, int W, hipStream_t s) {
+    if (W & 3) return hipErrorInvalidValue;
+    const long long n4 = (long long)B * C * H * (W >> 2);
+    hipLaunchKernelGGL(convt_shift4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, xs, C, H, W, n4);
+    return hipGetLastError();
+}
+
+// InstanceNorm2d(affine=False) + activation over the plane (b, c) of the ConvTranspose output, read from the four phase planes
+// t[phase = 2 py + px][b][c][H][W] (+ bias[c]) and written depth-to-space: out[b][c][2y+py][2x+px].  Same three passes as
+// instnorm_act_wide_kernel (mean, biased variance, write); one thread of the last pass = four output pixels of a row.
+__global__ __launch_bounds__(1024) void instnorm_act_d2s_kernel(const float* __restrict__ t, const float* __restrict__ bias, float* __restrict__ out,
+                                                                int BC, int C, int H, int W, float eps, int act) {
+    __shared__ float red[16];
+    const int HW = H * W, n4 = HW >> 2;
+    const float bs = bias ? bias[blockIdx.x % C] : 0.f;
+    const float4* p[4];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) p[ph] = reinterpret_cast<const float4*>(t + ((long long)ph * BC + blockIdx.x) * HW);
+    float s = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const float4 v = p[ph][i];
+            s += ((v.x + bs) + (v.y + bs)) + ((v.z + bs) + (v.w + bs));
+        }
+    const float mean = block_sum1024(s, red) / (4.f * HW);
+    float q = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const float4 v = p[ph][i];
+            const float a = v.x + bs - mean, b = v.y + bs - mean, c = v.z + bs - mean, d = v.w + bs - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    const float var = block_sum1024(q, red) / (4.f * HW);
+    const float rstd = 1.f / sqrtf(var + eps);
+    float* o = out + (long long)blockIdx.x * 4 * HW;
+    const int W2 = W >> 1;                                       // pairs of input pixels per row = float4 units per output row
+    for (int i = threadIdx.x; i < 2 * H * W2; i += 1024) {       // (output row, unit): row 2 y + py, columns 4 u .. 4 u + 3 = input x = 2 u, 2 u + 1
+        const int u = i % W2, oy = i / W2, y = oy >> 1, py = oy & 1;
+        const float2 e = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(p[2 * py]) + y * W + 2 * u);        // px = 0
+        const float2 f = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(p[2 * py + 1]) + y * W + 2 * u);    // px = 1
+        float4 v;
+        v.x = act_fn((e.x + bs - mean) * rstd, act); v.y = act_fn((f.x + bs - mean) * rstd, act);
+        v.z = act_fn((e.y + bs - mean) * rstd, act); v.w = act_fn((f.y + bs - mean) * rstd, act);
+        *reinterpret_cast<float4*>(o + (long long)oy * (2 * W) + 4 * u) = v;
+    }
+}
+hipError_t instnorm_act_d2s(const float* t, const float* bias, float* out, int B, int C, int H, int W, float eps, int act, hipStream_t s) {
+    if ((W & 3) || ((H * W) & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(instnorm_act_d2s_kernel, dim3(B * C), dim3(1024), 0, s, t, bias, out, B * C, C, H, W, eps, act);
+    return hipGetLastError();
+}
+
 hipError_t instnorm_act(float* x, int planes, int HW, float eps, int act, hipStream_t s, void* sh16, int C, float* scratch) {
     const float sc = instnorm_sh16_scale(HW);
     if (sh16 && (C & 7) == 0 && instnorm_sliced(x, false, planes / C, C, HW, eps, act, sh16, scratch, s)) return hipGetLastError();

@@ -463,6 +463,20 @@ std::string SeanModel::build(const TensorStore& ts, int mb, int ms) {
                 const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
                 return (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) ? w10[((size_t)ci * 256 + co) * 9 + ky * 3 + kx] : 0.f;
             }));
+            // The same four phases as plain GEMMs (conv_pw.h) over shifted views of the input (misc_kernels.hip convt_shift4: planes
+            // (0,1) | (0,0) | (1,0) | (1,1)): phase (py, px) contracts only its OWN taps -- 1 + 2 + 2 + 4 = 9 products per 2 x 2 outputs and
+            // channel pair, against 16 of the Winograd phase convs above (whose 3x3 kernels are mostly zeros).  Option "sean.convt_gemm".
+            if (convt_gemm) {
+                static const int first[4] = {1, 0, 1, 0}, cnt[4] = {1, 2, 2, 4}, sdy[4] = {0, 0, 1, 1}, sdx[4] = {1, 0, 0, 1};
+                for (int ph = 0; ph < 4; ++ph) {
+                    const int py = ph >> 1, px = ph & 1;
+                    z10_pw[ph] = B.upload(pack_pw_A(256, cnt[ph] * 128, [&](int co, int ci) {
+                        const int sh = first[ph] + ci / 128, c = ci % 128;
+                        const int ky = py + 1 - 2 * sdy[sh], kx = px + 1 - 2 * sdx[sh];
+                        return (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) ? w10[((size_t)c * 256 + co) * 9 + ky * 3 + kx] : 0.f;
+                    }));
+                }
+            }
         }
         if (use_sh16) {   // the 256->512 conv is 91 % of the Zencoder FLOPs: run it on the f16x3 path too
             auto w14 = B.vec("Zencoder.model.14.weight", (size_t)512 * 256 * 9);
@@ -1843,6 +1857,7 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
         last.act = ACT_TANH;
         const int h2 = S / 2, h4 = S / 4;
         const bool f16path = use_sh16 && h4 * h4 >= 4096;
+        bool in4_done = false;       // the ConvTranspose route already applied the InstanceNorm + lrelu that follows it
         if (phase != 2) {
         ck(conv3x3_c3_reflect(x, z1_w, z1.bias, hs, B, 32, S, S, st), "zenc conv1");
         if (f16path) {
@@ -1906,7 +1921,29 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             ck(instnorm_c4_to_sh16(hs, B, 256, h2 * h2, 1e-5f, ACT_LRELU, h1, st, splitk_ws), "zenc in4");
         } else {
             ck(instnorm_act(h1, B * 128, h4 * h4, 1e-5f, ACT_LRELU, st), "zenc in3");
-            if (z10_wino && !use_sh16 && wino_supported(h4, h4, 128)) {
+            const long long hw4 = (long long)h4 * h4;
+            if (z10_pw[3] && !use_sh16 && !batch_inv && pw_supported(128, 256, (int)hw4) && (h4 & 3) == 0 && (long long)B * hw4 >= 16384 && vbuf &&
+                (size_t)B * (512 + 4 * 256) * hw4 * sizeof(float) <= vbuf_bytes) {
+                // four phase GEMMs over the shifted views (enough pixel tiles to fill the device; the V buffer is free until conv5's transform pass);
+                // the InstanceNorm + lrelu that follows reads the phase planes and writes the depth-to-space plane
+                float *xs = vbuf, *tph = vbuf + (size_t)B * 512 * hw4;
+                ck(convt_shift4(h1, xs, B, 128, h4, h4, st), "zenc convT shifted views");
+                static const int first[4] = {1, 0, 1, 0}, cnt[4] = {1, 2, 2, 4};
+                for (int ph = 0; ph < 4; ++ph) {
+                    PwParams q{};
+                    q.in = xs + (size_t)first[ph] * 128 * hw4;
+                    q.in_bs = 512 * hw4;
+                    q.wpk = z10_pw[ph];
+                    q.out = tph + (size_t)ph * B * 256 * hw4;
+                    q.B = B;
+                    q.Cin = cnt[ph] * 128;
+                    q.Cout = 256;
+                    q.HW = (int)hw4;
+                    ck(conv_pw(q, st), "zenc convT (phase GEMM)");
+                }
+                ck(instnorm_act_d2s(tph, z10.bias, hs, B, 256, h4, h4, 1e-5f, ACT_LRELU, st), "zenc in4 (depth-to-space)");
+                in4_done = true;
+            } else if (z10_wino && !use_sh16 && wino_supported(h4, h4, 128)) {
                 WinoParams q{};
                 q.in = h1;
                 q.wpk = z10_wino;
@@ -1942,7 +1979,7 @@ std::string SeanModel::encode(const float* img, const uint8_t* labels, float* co
             p.pad_mode = PAD_REFLECT;
             ck(conv_sh16_plain(p, 3, st), "zenc conv5 (f16x3)");
         } else {
-            ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
+            if (!in4_done) ck(instnorm_act(hs, B * 256, h2 * h2, 1e-5f, ACT_LRELU, st), "zenc in4");
             if (z14_wino4 && wino4_supported(h2, h2, 256) && (wino4_force || batch_inv || wino4_pays((long long)B * (h2 / 32) * (h2 / 32) * 16, num_cus))) {
                 Wino4Params q{};
                 q.in = hs;

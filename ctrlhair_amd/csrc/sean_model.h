@@ -84,6 +84,8 @@ struct SeanModel {
     ConvLayer z1, z4, z7, z10, z14;                    // architecture.py:158-176
     float *z14_sh = nullptr, *z10_sh = nullptr;        // z14 / the ConvTranspose packed for the f16x3 kernel
     float* z10_wino = nullptr;                         // exact-f32 path: the ConvTranspose as four Winograd phase convs of the input grid (rows 4 co + phase)
+    float* z10_pw[4] = {};                             // option "sean.convt_gemm": the same ConvTranspose as four phase GEMMs over shifted views (conv_pw.h; phase = 2 py + px)
+    int convt_gemm = 1;
     float* z14_wino = nullptr;                         // exact-f32 path: z14 as Winograd A images (conv_wino.h, reflection padding)
     float* z14_wino4 = nullptr;                        // ... and as F(4x4,3x3) images (conv_wino4.h), sean.wino = 2
     float *z14_ws = nullptr, *z10_ws = nullptr;        // their per-row inverse weight scales

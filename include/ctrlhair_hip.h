@@ -95,6 +95,10 @@ int  ch_load_tensor(ch_handle* h, int model, const char* name, const void* host,
  *   boundary conv (csrc/ace_sparse.h).  Same real number, another association of the f32 sums (<= 1e-6 against "sean.edge" = 0;
  *   f16x3: <= 5e-6; on the single-term f16 / bf16 paths the table rows are exact f32 where the conv they replace is not).
  *   Costs 52 MB of tables at ngf = 64.  0 = every non-interior pixel through the conv.
+ * "sean.convt_gemm" (default 1; before ch_finalize; exact-f32 path): the Zencoder's ConvTranspose2d(128, 256, k3, s2, p1, op1)
+ *   (architecture.py:167-170) as four phase GEMMs over shifted views of its input -- 9 products per 2 x 2 outputs and channel pair -- with the
+ *   InstanceNorm + lrelu that follows reading the phase planes; calls with fewer than 16384 input pixels and 0 = four Winograd F(2x2,3x3)
+ *   phase convs (16 products).  Same sums in another order (<= 1e-6 on the style codes).
  * "sean.patch" (default 1; before ch_finalize): when a level is left with few boundary quads (at most 32 chunks of 64 per sample) their
  *   hidden-activation patches are written pre-gathered, in the conv kernel's stage layout, instead of being fetched piecewise from the
  *   planes (csrc/conv_wino.h WinoAceParams::patch); decided per level and call on the device; bit-identical.  0 = planes only.

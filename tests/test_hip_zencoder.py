@@ -88,3 +88,34 @@ def test_split_encode_equals_encode(hip_lib):
     assert float((whole - parts).abs().max()) <= 1e-6
     with pytest.raises(RuntimeError):
         g.encode_regions(lab)                  # consumed: needs a new encode_features
+
+
+def test_convtranspose_as_phase_gemms(hip_lib):
+    """Option sean.convt_gemm (exact-f32 path, default 1): ConvTranspose2d(128, 256, k3, s2, p1, op1) (architecture.py:167-170) as four phase
+    GEMMs over shifted views of its input, the following InstanceNorm + lrelu reading the phase planes (misc_kernels.hip convt_shift4 /
+    instnorm_act_d2s), taken by calls with at least 16384 input pixels per chunk -- against the Winograd phase convs of the same library
+    (option 0) on the feature map and the codes, and against the oracle."""
+    from ctrlhair_amd import procedural as P
+    from ctrlhair_amd.sean.generator import SeanGenerator
+    from oracle import sean_oracle as O
+    sd = P.sean_state_dict(0, 16)
+    B, S = 4, 256
+    on = SeanGenerator(0, f16x3=0).load_state_dict(sd, max_batch=B, max_size=S)
+    off = SeanGenerator(0, f16x3=0, options={'sean.convt_gemm': 0}).load_state_dict(sd, max_batch=B, max_size=S)
+    lab, img = P.blocky_labels(B, S, grid=8, seed=39), P.synthetic_images(B, S, seed=40)
+    out = {}
+    for name, g in (('on', on), ('off', off)):
+        feat = torch.zeros(B, 512, S // 2, S // 2, device=g.device)
+        g.handle.sean_set_tap('zenc.feat', feat.data_ptr())
+        codes = g.encode(torch.from_numpy(img).to(g.device), torch.from_numpy(lab).to(g.device))
+        torch.cuda.synchronize()
+        g.handle.sean_set_tap('zenc.feat', None)
+        out[name] = (feat.cpu().numpy(), codes.cpu().numpy())
+    df, dc = float(np.abs(out['on'][0] - out['off'][0]).max()), float(np.abs(out['on'][1] - out['off'][1]).max())
+    ref = O.zencoder_forward(O.to_torch(sd), img, lab).numpy()
+    dr = float(np.abs(out['on'][1] - ref).max())
+    print(f'phase GEMMs vs Winograd phase convs: feature map {df:.3e}, codes {dc:.3e}; codes vs oracle {dr:.3e}')
+    assert np.isfinite(out['on'][0]).all() and df <= 2e-5 and dc <= 2e-6 and dr <= TOL
+    assert df > 0, 'both handles took the same route'
+    on.handle.close()
+    off.handle.close()
