@@ -3,6 +3,7 @@ Every public method of ui/backend.py:67-462 is present with the same name, argum
 references are given per method.  Shape transfer by photo (`transfer_latent_representation('shape')`) needs the
 reference's ARAP warping tool chain (wrap_codes/, dlib) and accepts an injected `warper` instead.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -54,6 +55,14 @@ class Backend(HairEditor):
         self.blender = blender
         self.noise = None          # optional pinned noise planes for repeatable output() (tests / A-B comparisons)
 
+    def _side_stream(self):
+        """The side stream of parse_img (None when overlap is off: Backend.overlap = False, or without a GPU)."""
+        if not getattr(self, 'overlap', True) or not torch.cuda.is_available():
+            return None
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
+
     # ---- analysis (ui/backend.py:67-106) ---------------------------------------------------------------------
     def _mask_for_sean(self, mask256):
         """The shape branch is fixed at 256x256 (shape_branch/model.py:85-89); for img_size 512 the label map is
@@ -64,21 +73,47 @@ class Backend(HairEditor):
 
     def parse_img(self, img_rgb, target_img=False):
         img_ts = U.resize_bilinear(np.asarray(img_rgb), (self.target_size, self.target_size))
+        # Batch-1 latency: the networks of this call are chains of small kernels that leave most of the device idle, and only some of them
+        # depend on each other -- the Zencoder's convolutions need the image only (the parsing enters its region means at the end:
+        # ch_sean_encode_features / _regions), the shape branch (two encoders, two decoders: :81-90) the parsing only.  With a side stream
+        # the Zencoder's convolutions run underneath BiSeNet and the shape branch underneath the region means and the colour MLPs (same
+        # kernels, same results; Backend.overlap = False keeps everything on one stream).
+        side = self._side_stream() if self.device.type == 'cuda' else None
+        main = torch.cuda.current_stream(self.device) if side is not None else None
+        img_pre = self.preprocess_img(img_rgb)
+        gen = self.models.generator if side is not None and hasattr(self, 'models') and hasattr(self.models, 'generator') else None
+        if gen is not None and img_pre.shape[0] <= gen.max_batch:
+            img_dev = torch.as_tensor(img_pre).to(self.device).float()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gen.encode_features(img_dev)
+        else:
+            gen = None
         mask = self.get_mask(img_rgb)                                     # [img_size, img_size] CelebA ids
         lr = LatentRepresentation()
         mask256 = U.resize_nearest(mask, (256, 256)) if mask.shape[0] != 256 else mask
         mask_batch = self.preprocess_mask(mask)
         mask_tensor = torch.tensor(mask256[None], dtype=torch.uint8, device=self.device)
-        lr.shape, lr.face = self.mask_generator.encode_labels(mask_tensor)   # == one-hot, split, two encoders (:81-86)
-        decoded = U.to_host(self.mask_generator.decode_labels(lr.shape, lr.face))[0]      # :87-90
+        if side is not None:
+            main.wait_stream(side)                # (the Zencoder's feature map)
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            lr.shape, lr.face = self.mask_generator.encode_labels(mask_tensor)   # == one-hot, split, two encoders (:81-86)
+            decoded_dev = self.mask_generator.decode_labels(lr.shape, lr.face)   # :87-90
         # hair appearance: Zencoder code of the hair region -> colour statistics and texture / curliness latents (:93-105)
-        codes = self.get_code(self.preprocess_img(img_rgb), mask_batch)
+        if gen is not None:
+            codes = gen.encode_regions(torch.as_tensor(np.asarray(mask_batch)).to(self.device).to(torch.uint8)[:, 0].contiguous())
+        else:
+            codes = self.get_code(img_pre, mask_batch)
         hair = codes[:, HAIR_IDX]
         stats = self.feature_rgb_predictor({'code': hair})
         rgb_u8 = np.clip(U.to_host(stats['rgb_mean']), 0, 255).astype('uint8')
         lr.color = {'hsv': torch.tensor(U.rgb_to_hsv_u8(rgb_u8[None, ...])).to(self.device)[0], 'pca_std': stats['pca_std']}
         latents = self.feature_encoder({'code': hair})
         lr.curliness, lr.texture = latents['noise_curliness'], latents['noise']
+        if side is not None:
+            main.wait_stream(side)
+        decoded = U.to_host(decoded_dev)[0]
         return img_ts, decoded, lr, mask, codes, hair
 
     def _convert_u8(self, t, fn):

@@ -15,6 +15,8 @@ from ctrlhair_amd.ui.backend import Backend
 path = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 w = procedural_weights(0, 64)
 be = Backend(2.5, blending=False, weights=w, device=0, f16x3=(path == 'f16x3'))
+if len(sys.argv) > 2 and sys.argv[2] == 'serial':      # everything on one stream (Backend.overlap)
+    be.overlap = False
 img = np.ascontiguousarray(P.synthetic_images(1, 256, seed=11)[0].transpose(1, 2, 0))
 img = np.clip((img * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
 steps = [('set_input_img', lambda: be.set_input_img(img_rgb=img)), ('change_curliness', lambda: be.change_curliness(1.0)),
