@@ -161,10 +161,10 @@ class HairEditor:
 
     def _obj_dic(self, code):
         obj_dic = self.load_average_feature()
+        present = (code[0] != 0).any(dim=1).tolist()  # ONE reduction + read-back instead of the reference's 19 `torch.all(...)` tests
         for idx in range(19):
-            cur_code = code[0, idx]
-            if not torch.all(cur_code == 0):          # all-zero row (absent region) -> keep the median code, :165-168
-                obj_dic[str(idx)]['ACE'] = cur_code
+            if present[idx]:                          # all-zero row (absent region) -> keep the median code, :165-168
+                obj_dic[str(idx)]['ACE'] = code[0, idx]
         return obj_dic
 
     def gen_img(self, code, parsing, noise=None):
@@ -243,6 +243,12 @@ class HairEditor:
     def postprocess_blending(self, face_img, res_img, face_parsing, target_parsing, verbose_print=False, blending=True,
                              blender=None):
         def from_tensor_order_to_cv2(tensor_img, is_mask=False):
+            if isinstance(tensor_img, torch.Tensor) and tensor_img.is_cuda and not is_mask and tensor_img.dtype == torch.float32 and \
+                    tensor_img.shape[-3:-2] == (3,) and tensor_img.dim() in (3, 4) and tensor_img.shape[-1] > 3:
+                # the same float32 multiply, add and truncation as below, on the device: a quarter of the bytes cross the bus and the
+                # host does no arithmetic (the caller's .astype('uint8') is then a no-op)
+                t = tensor_img[0] if tensor_img.dim() == 4 else tensor_img
+                return U.to_host((t * 127.5 + 127.5).to(torch.uint8).permute(1, 2, 0).contiguous())
             if isinstance(tensor_img, torch.Tensor):
                 tensor_img = U.to_host(tensor_img)
             if len(tensor_img.shape) == 4:

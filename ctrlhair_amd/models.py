@@ -13,6 +13,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from . import hostutil as U
 from . import lib as _lib
 
 HAIR_IDX = 13   # global_value_utils.py:52
@@ -235,8 +236,9 @@ class FaceParsing:
     def normalise(self, img_u8_hwc: np.ndarray) -> torch.Tensor:
         """ToTensor + Normalize (my_parsing_util.py:25-28) on device."""
         t = torch.from_numpy(np.array(img_u8_hwc, copy=True)).to(self.device).permute(2, 0, 1).float() / 255.0
-        mean = torch.tensor(_MEAN, device=self.device).view(3, 1, 1)
-        std = torch.tensor(_STD, device=self.device).view(3, 1, 1)
+        if getattr(self, '_norm', None) is None:          # (two tiny host-to-device copies per call otherwise)
+            self._norm = (torch.tensor(_MEAN, device=self.device).view(3, 1, 1), torch.tensor(_STD, device=self.device).view(3, 1, 1))
+        mean, std = self._norm
         return ((t - mean) / std)[None]
 
     def parsing_img(self, img, image_size: int = 512):
@@ -246,7 +248,7 @@ class FaceParsing:
         pil = img if isinstance(img, Image.Image) else Image.fromarray(np.asarray(img).astype('uint8'))
         image = pil.resize((image_size, image_size), Image.BILINEAR)
         lab, _ = self.parse_tensor(self.normalise(np.asarray(image)))
-        parsing = _CELEBA_TO_BISENET[lab[0].cpu().numpy()]
+        parsing = _CELEBA_TO_BISENET[U.to_host(lab[0])]          # (pinned staging buffer: hostutil.to_host)
         return parsing, image
 
     @staticmethod

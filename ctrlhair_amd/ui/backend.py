@@ -89,11 +89,24 @@ class Backend(HairEditor):
                 gen.encode_features(img_dev)
         else:
             gen = None
-        mask = self.get_mask(img_rgb)                                     # [img_size, img_size] CelebA ids
         lr = LatentRepresentation()
-        mask256 = U.resize_nearest(mask, (256, 256)) if mask.shape[0] != 256 else mask
-        mask_batch = self.preprocess_mask(mask)
-        mask_tensor = torch.tensor(mask256[None], dtype=torch.uint8, device=self.device)
+        fp = getattr(self, 'face_parsing', None)
+        mask_dev = None
+        if side is not None and self.img_size in (256, 512) and hasattr(fp, 'parse_tensor') and hasattr(fp, 'normalise'):
+            # get_mask (hair_editor.py:331-335) with the label map kept on the device: BiSeNet's ids come back as CelebAMask ids, the
+            # nearest resize 512 -> img_size (-> 256 for the shape branch) is a strided view (cv2.INTER_NEAREST: floor(dst * 2)), and the
+            # networks below start from it without a round trip through the host; the host copy the caller gets is taken at the end.
+            from PIL import Image
+            pil = img_rgb if isinstance(img_rgb, Image.Image) else Image.fromarray(np.asarray(img_rgb).astype('uint8'))
+            lab512, _ = fp.parse_tensor(fp.normalise(np.asarray(pil.resize((512, 512), Image.BILINEAR))))
+            mask_dev = lab512[0, ::512 // self.img_size, ::512 // self.img_size].contiguous()
+            mask_tensor = (mask_dev[::self.img_size // 256, ::self.img_size // 256].contiguous() if self.img_size != 256 else mask_dev)[None]
+            mask = mask_batch = None
+        else:
+            mask = self.get_mask(img_rgb)                                     # [img_size, img_size] CelebA ids
+            mask256 = U.resize_nearest(mask, (256, 256)) if mask.shape[0] != 256 else mask
+            mask_batch = self.preprocess_mask(mask)
+            mask_tensor = torch.tensor(mask256[None], dtype=torch.uint8, device=self.device)
         if side is not None:
             main.wait_stream(side)                # (the Zencoder's feature map)
             side.wait_stream(main)
@@ -101,9 +114,13 @@ class Backend(HairEditor):
             lr.shape, lr.face = self.mask_generator.encode_labels(mask_tensor)   # == one-hot, split, two encoders (:81-86)
             decoded_dev = self.mask_generator.decode_labels(lr.shape, lr.face)   # :87-90
         # hair appearance: Zencoder code of the hair region -> colour statistics and texture / curliness latents (:93-105)
-        if gen is not None:
+        if gen is not None and mask_dev is not None:
+            codes = gen.encode_regions(mask_dev[None])
+        elif gen is not None:
             codes = gen.encode_regions(torch.as_tensor(np.asarray(mask_batch)).to(self.device).to(torch.uint8)[:, 0].contiguous())
         else:
+            if mask_batch is None:
+                mask_batch = self.preprocess_mask(U.to_host(mask_dev))
             codes = self.get_code(img_pre, mask_batch)
         hair = codes[:, HAIR_IDX]
         stats = self.feature_rgb_predictor({'code': hair})
@@ -114,6 +131,8 @@ class Backend(HairEditor):
         if side is not None:
             main.wait_stream(side)
         decoded = U.to_host(decoded_dev)[0]
+        if mask is None:
+            mask = U.to_host(mask_dev)
         return img_ts, decoded, lr, mask, codes, hair
 
     def _convert_u8(self, t, fn):
@@ -283,7 +302,16 @@ class Backend(HairEditor):
 
     def refresh_cur_mask(self, target_latent=None):      # :304-315
         lat = self.cur_latent if target_latent is None else target_latent
-        self.cur_mask = U.to_host(self.mask_generator.decode_labels(lat.shape, lat.face))[0]
+        # The reference decodes twice per shape move (change_shape -> continue_change_with_direction -> refresh_cur_mask, then
+        # refresh_cur_mask again, :217-218,461-462): the second call sees the very same latent tensors and gets the first call's mask.
+        key = (lat.shape, lat.shape._version, lat.face, lat.face._version)
+        c = getattr(self, '_mask_cache', None)
+        if c is not None and c[0][0] is key[0] and c[0][1] == key[1] and c[0][2] is key[2] and c[0][3] == key[3]:
+            self.cur_mask = c[1].copy()
+        else:
+            mask = U.to_host(self.mask_generator.decode_labels(lat.shape, lat.face))[0]
+            self._mask_cache = (key, mask)
+            self.cur_mask = mask.copy()
         return self.cur_mask, mask_to_rgb(self.cur_mask, draw_type=1)
 
     def get_cur_mask(self):
