@@ -172,9 +172,20 @@ class HairEditor:
         if not isinstance(code, torch.Tensor):
             code = torch.tensor(code)
         code = code.to(self.device)
+        # hair_editor.py:162-176 builds obj_dic from the median codes and the non-zero rows of code[0] (19 `torch.all` read-backs) and
+        # the model stacks it again: the same [19, 512] tensor from ONE device-side select, no read-back (the shim takes it as
+        # data['codes']; _obj_dic() stays for callers that want the dictionary)
         data = {'label': torch.as_tensor(np.asarray(parsing) if not isinstance(parsing, torch.Tensor) else parsing,
                                          dtype=torch.float32),
-                'instance': torch.tensor(0), 'image': None, 'obj_dic': self._obj_dic(code)}
+                'instance': torch.tensor(0), 'image': None}
+        if getattr(self.sean_model, 'accepts_codes', False):
+            if self._median is None:
+                self.load_average_feature()
+            present = (code[0] != 0).any(dim=1, keepdim=True)
+            data['obj_dic'] = None
+            data['codes'] = torch.where(present, code[0].float(), self._median.to(code.device))
+        else:                                             # a model object with the reference's interface only
+            data['obj_dic'] = self._obj_dic(code)
         if noise is not None:
             data['noise'] = noise
         change_status(self.sean_model, 'UI_mode')

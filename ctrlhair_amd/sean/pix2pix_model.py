@@ -22,6 +22,8 @@ class Pix2PixModel:
     def eval(self):
         return self
 
+    accepts_codes = True        # forward(mode='UI_mode') takes data['codes'] ([19,512]) in place of data['obj_dic'] (HairEditor.gen_img)
+
     def modules(self):          # change_status() walks .modules() looking for .status (hair_editor.py:33-36)
         return []
 
@@ -38,9 +40,12 @@ class Pix2PixModel:
         labels, image = self.preprocess_input(data)
         B = labels.shape[0]
         if mode == 'UI_mode':
-            obj_dic = data['obj_dic']
-            codes = torch.stack([torch.as_tensor(obj_dic[str(j)]['ACE']).to(self.device).float().reshape(512)
-                                 for j in range(19)])
+            if data.get('codes') is not None:           # extension: the [19,512] codes already assembled (HairEditor.gen_img)
+                codes = torch.as_tensor(data['codes']).to(self.device).float().reshape(19, 512)
+            else:
+                obj_dic = data['obj_dic']
+                codes = torch.stack([torch.as_tensor(obj_dic[str(j)]['ACE']).to(self.device).float().reshape(512)
+                                     for j in range(19)])
             # the reference styles batch element 0 only (normalization.py:124); every sample gets that treatment here
             codes = codes[None].expand(B, 19, 512).contiguous()
             noise = data.get('noise')
