@@ -112,27 +112,29 @@ def test_hip_backend_matches_cpu_plumbing(hip_lib, cpu_run):
 
 
 @pytest.mark.gpu
-def test_overlapped_parse_equals_serial(hip_lib):
+@pytest.mark.parametrize('f16x3', [True, False])
+def test_overlapped_parse_equals_serial(hip_lib, f16x3):
     """Backend.parse_img at batch 1: the Zencoder's convolutions underneath BiSeNet, the shape branch underneath the region means and the
     colour MLPs, the label map kept on the device (strided views instead of get_mask's host round trip), the rendered image
     converted to uint8 on the device, the second mask decode of a shape move served from the first (ui/backend.py:217-218,461-462) --
     all of it against the one-stream, host-side order of the reference (Backend.overlap = False): the same kernels on the same inputs.
-    Everything must be identical except what hangs on the Zencoder's region means, whose float atomics make the style codes
-    reproducible to 2.4e-7 only, run to run on either path (tests/test_hip_zencoder.py::test_split_encode_equals_encode): codes <= 1e-6,
-    the rendered uint8 image within one level on a vanishing share of the pixels."""
+    Exact-f32 kernels: every returned array identical.  f16x3 kernels (the default of procedural weights): identical except what hangs on
+    the Zencoder's region means, whose LDS float atomics on that path make the style codes reproducible to 2.4e-7 only, run to run in
+    either order (tests/test_hip_zencoder.py::test_split_encode_equals_encode): codes <= 1e-6, the rendered uint8 image within one
+    level on a vanishing share of the pixels."""
     res = {}
     for ov in (True, False):
         torch.manual_seed(0)
-        be = Backend(2.5, blending=False, weights=weights(), device=0)
+        be = Backend(2.5, blending=False, weights=weights(), device=0, f16x3=f16x3)
         be.overlap = ov
         res[ov] = script(be, torch.from_numpy(P.noise_planes(1, 256, NGF, seed=77)).cuda())
         res[ov]['input_mask'] = be.input_mask.copy()
         be.close() if hasattr(be, 'close') else None
     for k, v in res[True].items():
         v, w = np.asarray(v), np.asarray(res[False][k])
-        if k == 'code':
+        if k == 'code' and f16x3:
             assert float(np.abs(v - w).max()) <= 1e-6
-        elif k == 'out':
+        elif k == 'out' and f16x3:
             d = np.abs(v.astype(np.int32) - w.astype(np.int32))
             assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())
         else:
