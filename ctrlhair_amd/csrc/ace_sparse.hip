@@ -456,6 +456,9 @@ __global__ __launch_bounds__(256) void ace_interior_f32_tile_kernel(const AceInt
     }
 }
 
+#ifndef ACE_T4_AHEAD
+#define ACE_T4_AHEAD 0      // x of channel c loaded this many iterations early: 0 = 68 VGPRs, 1 = 80, 2 = 90, 3 = 100: 4.14 / 4.25 / 5.63 / 6.18 ms per step -- the
+#endif                      // pass lives on occupancy, not on loads in flight per wave (round 6, same-box A/B; kept as a switch)
 #ifndef ACE_T4_UNROLL
 #define ACE_T4_UNROLL 1      // channel-loop unroll of the four-pixel interior kernel: 1 = 68 VGPRs (seven blocks per CU), 4 = 97 (five): 4.0 vs 5.3 ms per step (profiles/r06_interior_ab.txt)
 #endif
@@ -587,7 +590,8 @@ __global__ __launch_bounds__(256, 8) void ace_interior_f32_tile4_kernel(const Ac
             // a pixel's gamma | beta row: the (sample, label) row of an interior pixel, the block-table row of a straight-edge pixel
             const float *g0 = slot[0] >= 0 ? et + slot[0] * RS : gt + (i0 ? j4.x : 0) * RS, *g1 = slot[1] >= 0 ? et + slot[1] * RS : gt + (i1 ? j4.y : 0) * RS,
                         *g2 = slot[2] >= 0 ? et + slot[2] * RS : gt + (i2 ? j4.z : 0) * RS, *g3 = slot[3] >= 0 ? et + slot[3] * RS : gt + (i3 ? j4.w : 0) * RS;
-            auto channel = [&](int c) {
+            // x of channel c (optionally loaded ACE_T4_AHEAD iterations before its use: measured slower, see the macro)
+            auto loadx = [&](int c) {
                 float4 xv;
                 if (q.x_up) {
                     const float2 t = *reinterpret_cast<const float2*>(xp + (long long)c * xHW);
@@ -595,6 +599,9 @@ __global__ __launch_bounds__(256, 8) void ace_interior_f32_tile4_kernel(const Ac
                 } else {
                     xv = *reinterpret_cast<const float4*>(xp + (long long)c * xHW);
                 }
+                return xv;
+            };
+            auto channel = [&](int c, const float4 xv) {
                 const float a = pa[c], n = pn[c], d = pd[c];
                 float4 o;
                 o.x = (a * xv.x + n * nz0 + d) * (1.f + g0[c]) + g0[IN_CG + c];
@@ -608,16 +615,30 @@ __global__ __launch_bounds__(256, 8) void ace_interior_f32_tile4_kernel(const Ac
             // Two loops, not one loop with the choice inside: with `if (all4) 16-byte store else four masked stores` in one body hipcc
             // if-converts both arms into four predicated 4-byte stores -- the shipped kernel of rounds 4-5 never issued a
             // global_store_dwordx4 (found in round 6 when an unrelated branch in the body changed the code: 3.37 -> 2.75 ms per step).
+            constexpr int QN = ACE_T4_AHEAD > 0 ? ACE_T4_AHEAD : 1;
+            float4 xq[QN];
+            if constexpr (ACE_T4_AHEAD > 0) {
+#pragma unroll
+                for (int k = 0; k < QN; ++k) xq[k] = loadx(k < cmax ? k : cmax - 1);
+            }
+            auto next_x = [&](int c) {                  // x of channel c; the queue moves on to channel c + ACE_T4_AHEAD
+                if constexpr (ACE_T4_AHEAD == 0) return loadx(c);
+                const float4 xv = xq[0];
+#pragma unroll
+                for (int k = 0; k + 1 < QN; ++k) xq[k] = xq[k + 1];
+                xq[QN - 1] = loadx(c + QN < cmax ? c + QN : cmax - 1);
+                return xv;
+            };
             if (first && (fill || (w0 && w1 && w2 && w3))) {
 #pragma unroll ACE_T4_UNROLL
                 for (int c = 0; c < cmax; ++c) {
-                    const float4 o = channel(c);
+                    const float4 o = channel(c, next_x(c));
                     *reinterpret_cast<nt_f32x4*>(op + (long long)c * HW) = (nt_f32x4){o.x, o.y, o.z, o.w};
                 }
             } else {
 #pragma unroll ACE_T4_UNROLL
                 for (int c = 0; c < cmax; ++c) {
-                    const float4 o = channel(c);
+                    const float4 o = channel(c, next_x(c));
                     float* oc = op + (long long)c * HW;
                     if (w0) oc[0] = o.x;
                     if (w1) oc[1] = o.y;
