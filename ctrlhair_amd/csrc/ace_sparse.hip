@@ -466,7 +466,10 @@ typedef float nt_f32x4 __attribute__((ext_vector_type(4)));      // (a 16-byte s
 // Four pixels of a row per thread, blocks of 128 x 8 pixels (W >= 128): 16-byte stores, 8- / 16-byte x loads, the four noise
 // values of a thread share their 32-byte sectors with the seven other rows of the block.
 __global__ __launch_bounds__(256, 8) void ace_interior_f32_tile4_kernel(const AceInteriorParams q) {      // (8 blocks per CU: <= 64 VGPR; it is a streaming kernel)
-    constexpr int RS = 2 * IN_CG + 1, ES = 64;               // ES: slots of the block's table of straight-edge rows
+#ifndef ACE_T4_ES_BITS
+#define ACE_T4_ES_BITS 6      // 64 slots.  32 (14 KB of LDS instead of 22: eight blocks per CU at 64 VGPRs) was measured: 5.6 vs 4.2 ms per step on the
+#endif                        // benchmark labels -- a 128 x 8 block of the 128-pixel level holds up to ~60 codes, so it takes a second round; 16: 9.1 ms
+    constexpr int RS = 2 * IN_CG + 1, ES = 1 << ACE_T4_ES_BITS;      // ES: slots of the block's table of straight-edge rows
     __shared__ float gt[19 * RS];
     __shared__ float et[ES * RS];
     __shared__ int ekey[ES], olist[ES], nocc;
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256, 8) void ace_interior_f32_tile4_kernel(const Ac
             for (int s = 0; s < 4; ++s) {
                 if (!pend[s]) continue;
                 const int code = kk[s];
-                unsigned h = ((unsigned)code * 2654435761u) >> 26;
+                unsigned h = ((unsigned)code * 2654435761u) >> (32 - ACE_T4_ES_BITS);
                 for (int probe = 0; probe < ES; ++probe) {
                     const int old = atomicCAS(&ekey[h], -1, code);
                     if (old == -1 || old == code) {
