@@ -1,8 +1,12 @@
 #!/bin/bash
-# scratch script for gpurun calls (always: stdin closed, every command under timeout)
 exec < /dev/null
 cd /root/repo
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-timeout 300 python bench.py --only-headline --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python tools/bench_brief.py
+for L in face blocky; do for o in 64 128; do
+  timeout 300 python bench.py --only-headline --steps 20 --warmup 5 --no-cpu-baseline --labels $L --opt sean.wino4_ace=$o 2>/dev/null > gpurun_out/w4a_${L}_$o.json
+  python - <<PY
+import json
+l=[x for x in open('gpurun_out/w4a_${L}_$o.json') if x.startswith('{')]
+j=json.loads(l[-1]); print('$L wino4_ace=$o', j['value'], j['ms_per_step'])
+PY
+done; done
