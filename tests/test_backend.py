@@ -112,8 +112,8 @@ def test_hip_backend_matches_cpu_plumbing(hip_lib, cpu_run):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('f16x3', [True, False])
-def test_overlapped_parse_equals_serial(hip_lib, f16x3):
+@pytest.mark.parametrize('f16x3,img_size', [(True, 256), (False, 256), (False, 512)])
+def test_overlapped_parse_equals_serial(hip_lib, f16x3, img_size):
     """Backend.parse_img at batch 1: the Zencoder's convolutions underneath BiSeNet, the shape branch underneath the region means and the
     colour MLPs, the label map kept on the device (strided views instead of get_mask's host round trip), the rendered image
     converted to uint8 on the device, the second mask decode of a shape move served from the first (ui/backend.py:217-218,461-462) --
@@ -121,13 +121,14 @@ def test_overlapped_parse_equals_serial(hip_lib, f16x3):
     Exact-f32 kernels: every returned array identical.  f16x3 kernels (the default of procedural weights): identical except what hangs on
     the Zencoder's region means, whose LDS float atomics on that path make the style codes reproducible to 2.4e-7 only, run to run in
     either order (tests/test_hip_zencoder.py::test_split_encode_equals_encode): codes <= 1e-6, the rendered uint8 image within one
-    level on a vanishing share of the pixels."""
+    level on a vanishing share of the pixels.  img_size = 512: the label map stays at 512 for the Zencoder and the generator, a strided view
+    of it feeds the 256 x 256 shape branch."""
     res = {}
     for ov in (True, False):
         torch.manual_seed(0)
-        be = Backend(2.5, blending=False, weights=weights(), device=0, f16x3=f16x3)
+        be = Backend(2.5, blending=False, weights=weights(), device=0, f16x3=f16x3, img_size=img_size)
         be.overlap = ov
-        res[ov] = script(be, torch.from_numpy(P.noise_planes(1, 256, NGF, seed=77)).cuda())
+        res[ov] = script(be, torch.from_numpy(P.noise_planes(1, img_size, NGF, seed=77)).cuda())
         res[ov]['input_mask'] = be.input_mask.copy()
         be.close() if hasattr(be, 'close') else None
     for k, v in res[True].items():
